@@ -1,0 +1,156 @@
+/*
+ * pcpx.h -- C ABI of libpcpx.so: MI355X (gfx950) kNN / radius search / PCA normals.
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of
+ * Q-Minh/point-cloud-processing (paths below are relative to the reference root):
+ *
+ *   pcp::basic_linked_octree_t ctor / nearest_neighbours / range_search
+ *       include/pcp/octree/linked_octree.hpp:83-121, :245-254, :264-276
+ *   pcp::basic_linked_kdtree_t ctor / nearest_neighbours / range_search
+ *       include/pcp/kdtree/linked_kdtree.hpp:100-135, :200-263, :270-277
+ *   pcp::estimate_normal / pcp::algorithm::estimate_normals
+ *       include/pcp/common/normals/normal_estimation.hpp:32-78
+ *       include/pcp/algorithm/estimate_normals.hpp:50-93, :116-164
+ *
+ * The reference is a header-only C++17 template library with no FFI; the C++17 mirror headers
+ * under include/pcp/ (same names, namespaces and signatures) call these entry points, and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.  Everything here is
+ * POD: plain pointers and sizes, no C++ or torch types.
+ *
+ * Conventions
+ *   - Points are float32 xyz, array-of-structures (pcp::point_t layout,
+ *     include/pcp/common/points/point.hpp:21-93), n < 2^32 - 1.
+ *   - Results are INDICES INTO THE INPUT ARRAY (the host wrappers map index -> Element).
+ *   - kNN rows are ascending in (squared distance, index); a row holds `count[q] <= k` valid
+ *     entries followed by 0xFFFFFFFF padding.  Points inside the eps-box around the query
+ *     (|dx|<eps && |dy|<eps && |dz|<eps, include/pcp/common/vector3d_queries.hpp:47-64) are
+ *     excluded, exactly like linked_octree_node.hpp:540 and linked_kdtree.hpp:461-475.
+ *   - Squared distances are computed as the reference does (include/pcp/common/norm.hpp:102-112):
+ *     d = p - q per axis, dx*dx + dy*dy + dz*dz left to right in float32, NO fused multiply-add.
+ *   - Sphere range search returns every point with d2 <= r*r (include/pcp/common/sphere.hpp:27-35),
+ *     the query point included, in unspecified order.
+ *   - Functions return PCPX_OK (0) or a negative pcpx_status; pcpx_last_error() gives the text of
+ *     the calling thread's last failure.  Nothing throws across this boundary.
+ *   - `*_dev` variants take DEVICE pointers and a hipStream_t (as void*); they enqueue work on that
+ *     stream and return without synchronising.  The others take HOST pointers and are synchronous.
+ *   - There is no CPU fallback: without a usable HIP device every compute entry point fails
+ *     with PCPX_ERR_DEVICE.
+ */
+#ifndef PCPX_H
+#define PCPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCPX_ABI_VERSION 1
+
+typedef enum pcpx_status {
+    PCPX_OK = 0,
+    PCPX_ERR_INVALID = -1,  /* bad argument */
+    PCPX_ERR_DEVICE = -2,   /* HIP error / no device */
+    PCPX_ERR_ALLOC = -3,    /* out of host or device memory */
+    PCPX_ERR_CAPACITY = -4, /* caller buffer too small; required size reported */
+    PCPX_ERR_UNSUPPORTED = -5
+} pcpx_status;
+
+typedef struct pcpx_index pcpx_index; /* opaque: device buffers + stream */
+
+/* Build flags */
+#define PCPX_BUILD_USE_GRID 1u /* voxel_grid given: points outside it are silently dropped         \
+                                  (linked_octree_node.hpp:174-175, linked_octree.hpp:83-91);        \
+                                  also the Morton quantisation box (e.g. the union of per-rank      \
+                                  boxes after the RCCL all-gather).  Otherwise the tight bounding   \
+                                  box of the input is used (linked_octree.hpp:103-121).           */
+
+typedef struct pcpx_build_params {
+    uint32_t struct_size; /* = sizeof(pcpx_build_params) */
+    uint32_t flags;
+    float grid_min[3];
+    float grid_max[3];
+} pcpx_build_params;
+
+int pcpx_abi_version(void);
+const char* pcpx_last_error(void);
+int pcpx_device_count(int* out_count);
+
+/* ---- index construction: replaces the octree / kd-tree constructors ---------------------- */
+int pcpx_index_create(const float* xyz, uint64_t n, const pcpx_build_params* params, int device,
+                      pcpx_index** out);
+int pcpx_index_create_dev(const float* d_xyz, uint64_t n, const pcpx_build_params* params, int device,
+                          void* stream, pcpx_index** out);
+/* Re-index a new cloud in place, reusing device buffers (BASELINE config 5: rebuild per iteration). */
+int pcpx_index_rebuild(pcpx_index* idx, const float* xyz, uint64_t n, const pcpx_build_params* params);
+int pcpx_index_rebuild_dev(pcpx_index* idx, const float* d_xyz, uint64_t n, const pcpx_build_params* params);
+void pcpx_index_destroy(pcpx_index* idx);
+/* size(): number of points inserted (linked_octree.hpp:127) -- input points minus out-of-grid ones. */
+int pcpx_index_size(pcpx_index* idx, uint64_t* out_n);
+/* voxel_grid() / aabb(): {minx,miny,minz,maxx,maxy,maxz} (linked_octree.hpp:144, linked_kdtree.hpp:187). */
+int pcpx_index_bbox(pcpx_index* idx, float out6[6]);
+/* pcp::bounding_box over a host slice (axis_aligned_bounding_box.hpp:214-251): the per-rank step
+ * before the bounding-box all-gather of the multi-GPU path. */
+int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6]);
+int pcpx_bounding_box_dev(const float* d_xyz, uint64_t n, int device, void* stream, float* d_out6);
+
+/* ---- k nearest neighbours: replaces nearest_neighbours ----------------------------------- */
+/* Every indexed point queries the cloud (the estimate_normals / kNN-graph shape).  Row i of the
+ * outputs belongs to input point i.  out_d2 may be NULL. */
+int pcpx_knn_self(pcpx_index* idx, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count,
+                  float* out_d2);
+/* Arbitrary query points. */
+int pcpx_knn_batch(pcpx_index* idx, const float* q_xyz, uint64_t nq, uint32_t k, float eps,
+                   uint32_t* out_idx, uint32_t* out_count, float* out_d2);
+/* Device-pointer form.  Only Morton-sorted positions [sorted_first, sorted_first+sorted_count) are
+ * processed (rows of the other points are left untouched) -- the per-rank query shard of the
+ * multi-GPU path; pass 0, UINT64_MAX for all.  sorted_first must be a multiple of 64. */
+int pcpx_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                      uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
+int pcpx_knn_batch_dev(pcpx_index* idx, const float* d_q_xyz, uint64_t nq, uint32_t k, float eps,
+                       uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
+
+/* ---- radius search: replaces range_search ------------------------------------------------ */
+/* Count only (what examples/filter_point_cloud_noise_by_density.cpp:81-90 consumes). */
+int pcpx_range_count_self(pcpx_index* idx, float radius, uint32_t* out_count);
+int pcpx_range_count_batch(pcpx_index* idx, const float* q_xyz, uint64_t nq, float radius, uint32_t* out_count);
+int pcpx_range_count_self_dev(pcpx_index* idx, float radius, uint64_t sorted_first, uint64_t sorted_count,
+                              uint32_t* d_out_count);
+/* Lists, CSR: out_offsets has nq+1 entries; out_idx receives offsets[nq] indices.  If idx_capacity is
+ * too small (or out_idx is NULL) the offsets are still filled and PCPX_ERR_CAPACITY is returned, so
+ * the caller can allocate offsets[nq] entries and call again. */
+int pcpx_range_sphere_batch(pcpx_index* idx, const float* q_xyz, const float* radii, float radius, uint64_t nq,
+                            uint64_t* out_offsets, uint32_t* out_idx, uint64_t idx_capacity);
+/* Axis-aligned box ranges, 6 floats each {min,max}, inclusive on both ends
+ * (axis_aligned_bounding_box.hpp:111-125). */
+int pcpx_range_aabb_batch(pcpx_index* idx, const float* boxes6, uint64_t nb, uint64_t* out_offsets,
+                          uint32_t* out_idx, uint64_t idx_capacity);
+
+/* ---- PCA normals: replaces estimate_normal / estimate_normals ---------------------------- */
+/* estimate_normals with knn_map = k nearest neighbours of each indexed point.  out_normals is n x 3
+ * (pcp::normal_t layout); opt_out_idx (n x k) / opt_out_count (n) may be NULL.  Sign is arbitrary,
+ * as in the reference (test/algorithm/estimate_normals.cpp:58-59). */
+int pcpx_normals_knn_self(pcpx_index* idx, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
+                          uint32_t* opt_out_count);
+int pcpx_normals_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first,
+                              uint64_t sorted_count, float* d_out_normals, uint32_t* d_opt_out_idx,
+                              uint32_t* d_opt_out_count);
+/* estimate_normal over explicit neighbourhoods: row q = nbr_idx[q*k .. q*k+count[q]) indexes the
+ * index's points.  opt_out_evals (nq x 3, ascending eigenvalues) may be NULL. */
+int pcpx_normals_from_knn(pcpx_index* idx, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq,
+                          uint32_t k, float* out_normals, float* opt_out_evals);
+/* estimate_normal over an arbitrary point set (no index needed): xyz is m x 3. */
+int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_normal[3]);
+
+/* ---- multi-GPU helper --------------------------------------------------------------------- */
+/* Contiguous, 64-aligned shard of the Morton-sorted query order for `rank` of `world`. */
+int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count);
+
+/* Block until everything enqueued on the index's stream has finished. */
+int pcpx_index_synchronize(pcpx_index* idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCPX_H */

@@ -1,0 +1,775 @@
+// pcp_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement (C++17, libstdc++ only, no Eigen / range-v3) of the hot path
+// of Q-Minh/point-cloud-processing: octree / kd-tree kNN + range search and the
+// PCA normal loop.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load this library; the product path (libpcpx.so) never
+// links, loads or calls it.
+//
+// Every function cites the reference file:line it follows (paths relative to
+// /root/reference).  The reference itself is unbuildable here (needs Eigen 3.3.8
+// and range-v3 0.11.0, both absent), so this restatement is pinned by the
+// reference's own known-answer tests transcribed in tests/golden/reference_kats.json:
+//   test/octree/octree_knn.cpp, test/kdtree/knn.cpp, test/octree/octree_range_search.cpp,
+//   test/kdtree/kdtree_range_search.cpp, test/octree/octree_insertion.cpp,
+//   test/common/normal_estimation.cpp, test/common/aabb.cpp.
+//
+// Third-party arithmetic not under /root/reference: Eigen 3.3.8
+// SelfAdjointEigenSolver<Matrix3f>::compute (called at
+// include/pcp/common/normals/normal_estimation.hpp:53).  Its published algorithm
+// (scale to [-1,1], closed-form 3x3 Householder tridiagonalisation, implicit
+// symmetric QR steps with Wilkinson shift, ascending selection sort) is restated
+// in eig3_tridiag_ql() below from the Eigen 3.3 sources
+// (Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h, Tridiagonalization.h,
+// Eigen/src/Jacobi/Jacobi.h).  It is pinned only by the 7-point KAT of
+// test/common/normal_estimation.cpp; beyond that, normal parity is by tolerance
+// (1e-4 cosine), see DESIGN.md.
+//
+// Build: oracle/Makefile (g++ -O2 -ffp-contract=off, no -march flags: the
+// reference on baseline x86-64 has no FMA, so neither has this).
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <queue>
+#include <thread>
+#include <vector>
+
+namespace {
+
+using u32 = std::uint32_t;
+using u64 = std::uint64_t;
+
+struct P3 {
+    float x, y, z;
+};
+
+// include/pcp/common/norm.hpp:102-112 (and :123-141, same value): d = p2 - p1,
+// dx*dx + dy*dy + dz*dz evaluated left to right in float.
+inline float sqdist(P3 const& p1, P3 const& p2)
+{
+    float const dx = p2.x - p1.x;
+    float const dy = p2.y - p1.y;
+    float const dz = p2.z - p1.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// include/pcp/common/vector3d_queries.hpp:30-35 and :47-64: |v1-v2| < eps on all three.
+inline bool fp_equals(float a, float b, float eps) { return std::abs(a - b) < eps; }
+inline bool vec_equal(P3 const& a, P3 const& b, float eps)
+{
+    return fp_equals(a.x, b.x, eps) && fp_equals(a.y, b.y, eps) && fp_equals(a.z, b.z, eps);
+}
+
+struct Box {
+    P3 min{0.f, 0.f, 0.f}, max{0.f, 0.f, 0.f};
+    // include/pcp/common/axis_aligned_bounding_box.hpp:111-125 (inclusive on both ends)
+    bool contains(P3 const& p) const
+    {
+        return (p.x >= min.x && p.y >= min.y && p.z >= min.z) &&
+               (p.x <= max.x && p.y <= max.y && p.z <= max.z);
+    }
+    // :130  (min + max) / 2.f
+    P3 center() const { return P3{(min.x + max.x) / 2.f, (min.y + max.y) / 2.f, (min.z + max.z) / 2.f}; }
+    // :138-148 and :81-90: std::clamp per axis
+    P3 nearest(P3 const& p) const
+    {
+        return P3{std::clamp(p.x, min.x, max.x), std::clamp(p.y, min.y, max.y), std::clamp(p.z, min.z, max.z)};
+    }
+};
+
+// include/pcp/common/axis_aligned_bounding_box.hpp:214-251 (strict < / > updates from +-FLT_MAX);
+// kd_bounding_box :164-201 yields the same box.
+Box bounding_box(P3 const* pts, u64 n)
+{
+    Box b;
+    float const hi = std::numeric_limits<float>::max(), lo = std::numeric_limits<float>::lowest();
+    b.min = P3{hi, hi, hi};
+    b.max = P3{lo, lo, lo};
+    for (u64 i = 0; i < n; ++i) {
+        P3 const& p = pts[i];
+        if (p.x < b.min.x) b.min.x = p.x;
+        if (p.y < b.min.y) b.min.y = p.y;
+        if (p.z < b.min.z) b.min.z = p.z;
+        if (p.x > b.max.x) b.max.x = p.x;
+        if (p.y > b.max.y) b.max.y = p.y;
+        if (p.z > b.max.z) b.max.z = p.z;
+    }
+    return b;
+}
+
+// include/pcp/common/sphere.hpp:27-35 / :52-56 : d2(position, p) <= radius * radius
+struct Sphere {
+    P3 c;
+    float r;
+    bool contains(P3 const& p) const { return sqdist(c, p) <= r * r; }
+};
+
+// include/pcp/common/intersections.hpp:87-102 and :113-130.  NOTE the reference compares the
+// squared distance against `radius`, not radius^2 -- restated as is.
+inline bool intersects(Box const& b, Sphere const& s)
+{
+    bool const in = (s.c.x >= b.min.x && s.c.x <= b.max.x) && (s.c.y >= b.min.y && s.c.y <= b.max.y) &&
+                    (s.c.z >= b.min.z && s.c.z <= b.max.z);
+    if (in) return true;
+    P3 const np = b.nearest(s.c);
+    return sqdist(np, s.c) <= s.r;
+}
+// include/pcp/common/intersections.hpp:25-32 and :43-54
+inline bool intersects(Box const& a, Box const& b)
+{
+    return (a.max.x >= b.min.x && a.max.y >= b.min.y && a.max.z >= b.min.z) &&
+           (a.min.x <= b.max.x && a.min.y <= b.max.y && a.min.z <= b.max.z);
+}
+struct BoxRange {
+    Box b;
+    bool contains(P3 const& p) const { return b.contains(p); }
+};
+inline bool intersects(Box const& a, BoxRange const& r) { return intersects(a, r.b); }
+
+// ---------------------------------------------------------------------------------------------
+// Octree: include/pcp/octree/linked_octree_node.hpp
+// ---------------------------------------------------------------------------------------------
+struct OctNode {
+    u32 capacity = 32;
+    std::uint8_t max_depth = 21;
+    Box grid;
+    std::array<std::unique_ptr<OctNode>, 8> oct;
+    std::vector<u32> elems;
+};
+
+struct Octree {
+    std::vector<P3> pts;  // element = index into pts (Element = index, PointViewMap = pts[i])
+    OctNode root;
+    u64 size = 0;
+};
+
+// linked_octree_node.hpp:163-331
+bool oct_insert(OctNode* node, std::vector<P3> const& pts, u32 e)
+{
+    for (;;) {
+        P3 const& p = pts[e];
+        if (!node->grid.contains(p)) return false;  // :174
+        if (node->max_depth == 1u) {                 // :184
+            node->elems.push_back(e);
+            return true;
+        }
+        if (node->elems.size() < node->capacity) {   // :194-199
+            node->elems.push_back(e);
+            return true;
+        }
+        P3 const c = node->grid.center();            // :209
+        unsigned m = 0;                              // :258-265 strict >
+        if (p.x > c.x) m |= 4u;
+        if (p.y > c.y) m |= 2u;
+        if (p.z > c.z) m |= 1u;
+        auto& child = node->oct[m];
+        if (!child) {                                // :289-330
+            child = std::make_unique<OctNode>();
+            child->capacity = node->capacity;
+            child->max_depth = static_cast<std::uint8_t>(node->max_depth - 1u);
+            child->grid.min.x = (m & 4u) ? c.x : node->grid.min.x;
+            child->grid.max.x = (m & 4u) ? node->grid.max.x : c.x;
+            child->grid.min.y = (m & 2u) ? c.y : node->grid.min.y;
+            child->grid.max.y = (m & 2u) ? node->grid.max.y : c.y;
+            child->grid.min.z = (m & 1u) ? c.z : node->grid.min.z;
+            child->grid.max.z = (m & 1u) ? node->grid.max.z : c.z;
+            child->elems.reserve(node->capacity);
+        }
+        node = child.get();
+    }
+}
+
+// linked_octree_node.hpp:453-570.  The reference's comparator recomputes both distances on every
+// comparison (:479-489); the key is a pure function of the heap node, so caching it leaves every
+// comparison outcome -- and therefore libstdc++'s heap order, ties included -- unchanged.
+struct OctHeapNode {
+    float d2;
+    u32 e;
+    OctNode const* o;
+    bool is_point;
+};
+struct OctGreater {
+    bool operator()(OctHeapNode const& a, OctHeapNode const& b) const { return a.d2 > b.d2; }
+};
+
+u32 oct_knn(Octree const& t, P3 const& target, u64 k, float eps, u32* out, float* out_d2)
+{
+    if (k == 0) return 0;  // :464
+    std::priority_queue<OctHeapNode, std::vector<OctHeapNode>, OctGreater> heap;
+    heap.push(OctHeapNode{sqdist(target, t.root.grid.nearest(target)), 0u, &t.root, false});  // :512
+    u32 found = 0;
+    while (found < k && !heap.empty()) {  // :525
+        OctHeapNode h = heap.top();
+        heap.pop();
+        if (h.is_point) {  // :536-543
+            if (!vec_equal(t.pts[h.e], target, eps)) {
+                out[found] = h.e;
+                if (out_d2) out_d2[found] = h.d2;
+                ++found;
+            }
+            continue;
+        }
+        for (u32 e : h.o->elems)  // :551-554
+            heap.push(OctHeapNode{sqdist(target, t.pts[e]), e, nullptr, true});
+        for (auto const& c : h.o->oct) {  // :560-566
+            if (!c) continue;
+            heap.push(OctHeapNode{sqdist(target, c->grid.nearest(target)), 0u, c.get(), false});
+        }
+    }
+    return found;
+}
+
+// linked_octree_node.hpp:581-614
+template <class Range>
+void oct_range(OctNode const* n, std::vector<P3> const& pts, Range const& range, std::vector<u32>& out)
+{
+    for (u32 e : n->elems)
+        if (range.contains(pts[e])) out.push_back(e);
+    for (auto const& c : n->oct) {
+        if (!c) continue;
+        if (!intersects(c->grid, range)) continue;  // :602
+        oct_range(c.get(), pts, range, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kd-tree: include/pcp/kdtree/linked_kdtree.hpp
+// ---------------------------------------------------------------------------------------------
+struct KdNode {
+    std::vector<u32*> points;  // pointers into storage, linked_kdtree_node.hpp
+    std::unique_ptr<KdNode> left, right;
+};
+
+struct KdTree {
+    std::vector<P3> pts;
+    std::vector<u32> storage;  // :107 copy of the elements (indices)
+    std::unique_ptr<KdNode> root;
+    Box aabb;
+    std::size_t max_depth = 12;
+    bool depth_unbounded = false;
+
+    float coord(u32 e, std::size_t d) const { return d == 0 ? pts[e].x : (d == 1 ? pts[e].y : pts[e].z); }
+};
+
+// linked_kdtree.hpp:350-424
+std::unique_ptr<KdNode> kd_build(KdTree& t, std::size_t first, std::size_t last, std::size_t depth)
+{
+    if (last < first) return nullptr;  // :359
+    auto node = std::make_unique<KdNode>();
+    std::size_t const size = (last + 1u) - first;
+    if (!t.depth_unbounded && depth == t.max_depth - 1u) {  // :371-382
+        node->points.resize(size);
+        for (std::size_t i = 0; i < size; ++i) node->points[i] = &t.storage[first + i];
+        return node;
+    }
+    if (first == last) {  // :387-391
+        node->points.push_back(&t.storage[first]);
+        return node;
+    }
+    std::size_t const dim = depth % 3u;  // :393
+    auto begin = t.storage.begin() + static_cast<std::ptrdiff_t>(first);
+    auto end = t.storage.begin() + static_cast<std::ptrdiff_t>(last + 1u);
+    auto mid = begin + static_cast<std::ptrdiff_t>(size / 2u);
+    std::nth_element(begin, mid, end, [&t, dim](u32 a, u32 b) { return t.coord(a, dim) < t.coord(b, dim); });
+    std::size_t const median = first + size / 2u;  // :406
+    node->points.push_back(&t.storage[median]);
+    // size >= 2 here, so median >= first + 1 and median - 1 cannot underflow (:410-419)
+    node->left = kd_build(t, first, median - 1u, depth + 1u);
+    node->right = kd_build(t, median + 1u, last, depth + 1u);
+    return node;
+}
+
+struct KdLess {  // :205-218  max-heap keyed on distance to target
+    KdTree const* t;
+    P3 target;
+    bool operator()(u32 const* a, u32 const* b) const
+    {
+        return sqdist(target, t->pts[*a]) < sqdist(target, t->pts[*b]);
+    }
+};
+using KdHeap = std::priority_queue<u32*, std::vector<u32*>, KdLess>;
+
+inline void set_axis(P3& p, std::size_t d, float v)
+{
+    if (d == 0) p.x = v;
+    else if (d == 1) p.y = v;
+    else p.z = v;
+}
+
+// linked_kdtree.hpp:436-552
+void kd_recurse_knn(KdTree const& t, P3 const& target, std::size_t k, KdNode const* node, Box const& box,
+                    std::size_t depth, KdHeap& heap, KdLess const& less, float eps)
+{
+    for (u32* e : node->points) {  // :456-489
+        bool const full = heap.size() == k;
+        if (vec_equal(target, t.pts[*e], eps)) continue;  // :461-475
+        if (!full) {
+            heap.push(e);
+            continue;
+        }
+        u32* root = heap.top();
+        if (!less(e, root)) continue;  // :484 strictly closer only
+        heap.pop();
+        heap.push(e);
+    }
+    std::size_t const dim = depth % 3u;
+    float const m = t.coord(*node->points.front(), dim);  // :495-496
+    Box lb = box, rb = box;
+    set_axis(lb.max, dim, m);  // :498-501
+    set_axis(rb.min, dim, m);
+    P3 const ln = lb.nearest(target), rn = rb.nearest(target);  // :503-504
+    auto visit = [&](KdNode const* child, Box const& cb, P3 const& np) {  // :510-535
+        if (!child) return;
+        bool recurse = heap.size() != k;
+        if (!recurse) recurse = sqdist(target, np) < sqdist(target, t.pts[*heap.top()]);
+        if (recurse) kd_recurse_knn(t, target, k, child, cb, depth + 1u, heap, less, eps);
+    };
+    if (sqdist(ln, target) < sqdist(rn, target)) {  // :541-551
+        visit(node->left.get(), lb, ln);
+        visit(node->right.get(), rb, rn);
+    } else {
+        visit(node->right.get(), rb, rn);
+        visit(node->left.get(), lb, ln);
+    }
+}
+
+// linked_kdtree.hpp:200-244
+u32 kd_knn(KdTree const& t, P3 const& target, u64 k, float eps, u32* out, float* out_d2)
+{
+    if (!t.root || k == 0) return 0;  // k == 0: heap.size()==k is true from the start, nothing is pushed
+    KdLess less{&t, target};
+    KdHeap heap(less);
+    kd_recurse_knn(t, target, k, t.root.get(), t.aabb, 0u, heap, less, eps);
+    u32 n = static_cast<u32>(heap.size());
+    for (u32 i = n; i-- > 0;) {  // pop + reverse => ascending (:237-243)
+        out[i] = *heap.top();
+        if (out_d2) out_d2[i] = sqdist(target, t.pts[*heap.top()]);
+        heap.pop();
+    }
+    return n;
+}
+
+// linked_kdtree.hpp:280-316
+template <class Range>
+void kd_range(KdTree const& t, Range const& range, Box const& box, KdNode const* node, std::vector<u32>& out,
+              std::size_t depth)
+{
+    for (u32* e : node->points)
+        if (range.contains(t.pts[*e])) out.push_back(*e);
+    std::size_t const dim = depth % 3u;
+    float const m = t.coord(*node->points.front(), dim);
+    Box lb = box, rb = box;
+    set_axis(lb.max, dim, m);
+    set_axis(rb.min, dim, m);
+    if (node->left && intersects(lb, range)) kd_range(t, range, lb, node->left.get(), out, depth + 1u);
+    if (node->right && intersects(rb, range)) kd_range(t, range, rb, node->right.get(), out, depth + 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCA normal: include/pcp/common/normals/normal_estimation.hpp:32-78 + Eigen 3.3.8 (restated)
+// ---------------------------------------------------------------------------------------------
+
+// Eigen/src/Jacobi/Jacobi.h  JacobiRotation<float>::makeGivens (real case)
+inline void make_givens(float p, float q, float& c, float& s)
+{
+    if (q == 0.f) {
+        c = p < 0.f ? -1.f : 1.f;
+        s = 0.f;
+    } else if (p == 0.f) {
+        c = 0.f;
+        s = q < 0.f ? 1.f : -1.f;
+    } else if (std::abs(p) > std::abs(q)) {
+        float t = q / p;
+        float u = std::sqrt(1.f + t * t);
+        if (p < 0.f) u = -u;
+        c = 1.f / u;
+        s = -t * c;
+    } else {
+        float t = p / q;
+        float u = std::sqrt(1.f + t * t);
+        if (q < 0.f) u = -u;
+        s = -1.f / u;
+        c = -t * s;
+    }
+}
+
+// Eigen 3.3 MathFunctions.h hypot_impl
+inline float eig_hypot(float x, float y)
+{
+    float ax = std::abs(x), ay = std::abs(y);
+    float p, qp;
+    if (ax > ay) {
+        p = ax;
+        qp = ay / p;
+    } else {
+        p = ay;
+        qp = ax / p;
+    }
+    if (p == 0.f) return 0.f;
+    return p * std::sqrt(1.f + qp * qp);
+}
+
+// SelfAdjointEigenSolver<Matrix3f>::compute(A, ComputeEigenvectors), reading the lower triangle.
+// evals ascending, evecs column-major: Q[r + 3*c] = component r of eigenvector c.
+void eig3_tridiag_ql(float const C[3][3], float evals[3], float Q[9])
+{
+    // lower triangle, scale by max |coeff|
+    float a00 = C[0][0], a10 = C[1][0], a20 = C[2][0], a11 = C[1][1], a21 = C[2][1], a22 = C[2][2];
+    float scale = std::max({std::abs(a00), std::abs(a10), std::abs(a20), std::abs(a11), std::abs(a21), std::abs(a22)});
+    // Eigen's maxCoeff over a matrix containing NaN propagates depending on order; NaN inputs stay NaN below anyway.
+    if (scale == 0.f) scale = 1.f;
+    a00 /= scale; a10 /= scale; a20 /= scale; a11 /= scale; a21 /= scale; a22 /= scale;
+
+    // Tridiagonalization.h  tridiagonalization_inplace_selector<MatrixType,3,false>
+    float diag[3], sub[2];
+    float const tol = std::numeric_limits<float>::min();
+    diag[0] = a00;
+    float const v1norm2 = a20 * a20;
+    if (v1norm2 <= tol) {
+        diag[1] = a11;
+        diag[2] = a22;
+        sub[0] = a10;
+        sub[1] = a21;
+        Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = 1; Q[5] = 0; Q[6] = 0; Q[7] = 0; Q[8] = 1;
+    } else {
+        float const beta = std::sqrt(a10 * a10 + v1norm2);
+        float const inv_beta = 1.f / beta;
+        float const m01 = a10 * inv_beta;
+        float const m02 = a20 * inv_beta;
+        float const q = 2.f * m01 * a21 + m02 * (a22 - a11);
+        diag[1] = a11 + m02 * q;
+        diag[2] = a22 - m02 * q;
+        sub[0] = beta;
+        sub[1] = a21 - m01 * q;
+        // mat << 1,0,0, 0,m01,m02, 0,m02,-m01  (row-wise fill; stored column-major)
+        Q[0] = 1; Q[1] = 0;   Q[2] = 0;
+        Q[3] = 0; Q[4] = m01; Q[5] = m02;
+        Q[6] = 0; Q[7] = m02; Q[8] = -m01;
+    }
+
+    // SelfAdjointEigenSolver.h computeFromTridiagonal_impl, n = 3, maxIterations = 30
+    int const n = 3;
+    int end = n - 1, start = 0, iter = 0;
+    float const consider_zero = std::numeric_limits<float>::min();
+    float const precision = 2.f * std::numeric_limits<float>::epsilon();
+    bool converged = true;
+    while (end > 0) {
+        for (int i = start; i < end; ++i) {
+            // isMuchSmallerThan(|sub|, |d_i|+|d_i+1|, precision)  <=>  |sub| <= (|d_i|+|d_i+1|) * precision
+            if (std::abs(sub[i]) <= (std::abs(diag[i]) + std::abs(diag[i + 1])) * precision ||
+                std::abs(sub[i]) <= consider_zero)
+                sub[i] = 0.f;
+        }
+        while (end > 0 && sub[end - 1] == 0.f) end--;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 30 * n) { converged = false; break; }
+        start = end - 1;
+        while (start > 0 && sub[start - 1] != 0.f) start--;
+
+        // tridiagonal_qr_step
+        float td = (diag[end - 1] - diag[end]) * 0.5f;
+        float e = sub[end - 1];
+        float mu = diag[end];
+        if (td == 0.f) {
+            mu -= std::abs(e);
+        } else {
+            float e2 = e * e;
+            float h = eig_hypot(td, e);
+            if (e2 == 0.f) mu -= (e / (td + (td > 0.f ? 1.f : -1.f))) * (e / h);
+            else mu -= e2 / (td + (td > 0.f ? h : -h));
+        }
+        float x = diag[start] - mu;
+        float z = sub[start];
+        for (int k = start; k < end; ++k) {
+            float c, s;
+            make_givens(x, z, c, s);
+            float sdk = s * diag[k] + c * sub[k];
+            float dkp1 = s * sub[k] + c * diag[k + 1];
+            diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+            diag[k + 1] = s * sdk + c * dkp1;
+            sub[k] = c * sdk - s * dkp1;
+            if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+            x = sub[k];
+            if (k < end - 1) {
+                z = -s * sub[k + 1];
+                sub[k + 1] = c * sub[k + 1];
+            }
+            // q.applyOnTheRight(k, k+1, rot): x_i' = c x_i - s y_i ; y_i' = s x_i + c y_i
+            for (int i = 0; i < 3; ++i) {
+                float xi = Q[i + 3 * k], yi = Q[i + 3 * (k + 1)];
+                Q[i + 3 * k] = c * xi - s * yi;
+                Q[i + 3 * (k + 1)] = s * xi + c * yi;
+            }
+        }
+    }
+    if (converged) {  // ascending selection sort with column swaps
+        for (int i = 0; i < n - 1; ++i) {
+            int kmin = 0;
+            float mv = diag[i];
+            for (int j = 1; j < n - i; ++j)
+                if (diag[i + j] < mv) { mv = diag[i + j]; kmin = j; }
+            if (kmin > 0) {
+                std::swap(diag[i], diag[kmin + i]);
+                for (int r = 0; r < 3; ++r) std::swap(Q[r + 3 * i], Q[r + 3 * (kmin + i)]);
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i) evals[i] = diag[i] * scale;
+}
+
+// normal_estimation.hpp:41-77.  Mu = sequential row sums / n (Eigen's non-vectorised strided
+// redux), Cov = V' V'^T accumulated sequentially over the neighbours without FMA.
+void estimate_normal(P3 const* pts, u32 const* idx, u64 n, float out[3], float* evals_out)
+{
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u64 i = 0; i < n; ++i) {
+        P3 const& p = pts[idx ? idx[i] : i];
+        if (i == 0) { sx = p.x; sy = p.y; sz = p.z; }
+        else { sx += p.x; sy += p.y; sz += p.z; }
+    }
+    float const fn = static_cast<float>(n);
+    float const mx = sx / fn, my = sy / fn, mz = sz / fn;  // n == 0 -> 0/0 = NaN like the reference
+    float C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (u64 i = 0; i < n; ++i) {
+        P3 const& p = pts[idx ? idx[i] : i];
+        float const v[3] = {p.x - mx, p.y - my, p.z - mz};
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c <= r; ++c) C[r][c] += v[r] * v[c];
+    }
+    float l[3], X[9];
+    eig3_tridiag_ql(C, l, X);
+    if (evals_out) { evals_out[0] = l[0]; evals_out[1] = l[1]; evals_out[2] = l[2]; }
+    float nx = 0.f, ny = 0.f, nz = 0.f;  // normal_t default-initialises to 0 (normals/normal.hpp:90)
+    if (l[0] <= l[1] && l[0] <= l[2]) { nx = X[0]; ny = X[1]; nz = X[2]; }  // :60-63
+    if (l[1] <= l[0] && l[1] <= l[2]) { nx = X[3]; ny = X[4]; nz = X[5]; }  // :65-68
+    if (l[2] <= l[0] && l[2] <= l[1]) { nx = X[6]; ny = X[7]; nz = X[8]; }  // :70-73
+    out[0] = nx; out[1] = ny; out[2] = nz;
+}
+
+template <class F>
+void parallel_for(u64 n, int nthreads, F&& f)
+{
+    if (nthreads <= 1 || n < 2) {
+        for (u64 i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    u64 const chunk = (n + static_cast<u64>(nthreads) - 1) / static_cast<u64>(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        u64 const b = static_cast<u64>(t) * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back([b, e, &f] { for (u64 i = b; i < e; ++i) f(i); });
+    }
+    for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_bbox(float const* xyz, u64 n, float out[6])
+{
+    Box b = bounding_box(reinterpret_cast<P3 const*>(xyz), n);
+    out[0] = b.min.x; out[1] = b.min.y; out[2] = b.min.z;
+    out[3] = b.max.x; out[4] = b.max.y; out[5] = b.max.z;
+}
+
+// Exact brute force: float d2 as the reference computes it, eps-box exclusion, ascending
+// (d2, index).  This is the tree-independent ground truth every reference kNN test asserts
+// (SURVEY.md section 4).  out_idx is nq x k, padded with 0xFFFFFFFF; out_cnt[q] <= k.
+void orc_knn_bruteforce(float const* xyz, u64 n, float const* qxyz, u64 nq, u32 k, float eps, u32* out_idx,
+                        u32* out_cnt, float* out_d2, int nthreads)
+{
+    P3 const* pts = reinterpret_cast<P3 const*>(xyz);
+    P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
+    parallel_for(nq, nthreads, [&](u64 q) {
+        std::vector<std::pair<float, u32>> cand;
+        cand.reserve(n);
+        for (u64 i = 0; i < n; ++i) {
+            if (vec_equal(pts[i], qs[q], eps)) continue;
+            cand.emplace_back(sqdist(qs[q], pts[i]), static_cast<u32>(i));
+        }
+        u64 const m = std::min<u64>(k, cand.size());
+        std::partial_sort(cand.begin(), cand.begin() + static_cast<std::ptrdiff_t>(m), cand.end());
+        for (u64 j = 0; j < k; ++j) {
+            out_idx[q * k + j] = j < m ? cand[j].second : 0xFFFFFFFFu;
+            if (out_d2) out_d2[q * k + j] = j < m ? cand[j].first : std::numeric_limits<float>::infinity();
+        }
+        out_cnt[q] = static_cast<u32>(m);
+    });
+}
+
+// Exact brute-force sphere range count / list (d2 <= r*r, query point included) and AABB.
+void orc_range_count_bruteforce(float const* xyz, u64 n, float const* qxyz, u64 nq, float r, u32* out_cnt,
+                                int nthreads)
+{
+    P3 const* pts = reinterpret_cast<P3 const*>(xyz);
+    P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
+    parallel_for(nq, nthreads, [&](u64 q) {
+        Sphere s{qs[q], r};
+        u32 c = 0;
+        for (u64 i = 0; i < n; ++i) c += s.contains(pts[i]) ? 1u : 0u;
+        out_cnt[q] = c;
+    });
+}
+
+// ---- octree ----
+void* orc_octree_create(float const* xyz, u64 n, u32 capacity, u32 max_depth, int use_grid, float const* grid6)
+{
+    auto* t = new Octree();
+    t->pts.assign(reinterpret_cast<P3 const*>(xyz), reinterpret_cast<P3 const*>(xyz) + n);
+    t->root.capacity = capacity;
+    t->root.max_depth = static_cast<std::uint8_t>(max_depth);
+    if (use_grid) {  // linked_octree.hpp:83-91
+        t->root.grid.min = P3{grid6[0], grid6[1], grid6[2]};
+        t->root.grid.max = P3{grid6[3], grid6[4], grid6[5]};
+    } else {  // linked_octree.hpp:103-121 auto bbox
+        t->root.grid = bounding_box(t->pts.data(), n);
+    }
+    t->root.elems.reserve(capacity);
+    for (u64 i = 0; i < n; ++i)  // linked_octree_node.hpp:143-153
+        if (oct_insert(&t->root, t->pts, static_cast<u32>(i))) ++t->size;
+    return t;
+}
+void orc_octree_destroy(void* h) { delete static_cast<Octree*>(h); }
+u64 orc_octree_size(void* h) { return static_cast<Octree*>(h)->size; }
+void orc_octree_grid(void* h, float out[6])
+{
+    Box const& b = static_cast<Octree*>(h)->root.grid;
+    out[0] = b.min.x; out[1] = b.min.y; out[2] = b.min.z; out[3] = b.max.x; out[4] = b.max.y; out[5] = b.max.z;
+}
+void orc_octree_knn(void* h, float const* qxyz, u64 nq, u32 k, float eps, u32* out_idx, u32* out_cnt,
+                    float* out_d2, int nthreads)
+{
+    Octree const& t = *static_cast<Octree*>(h);
+    P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
+    parallel_for(nq, nthreads, [&](u64 q) {
+        for (u32 j = 0; j < k; ++j) out_idx[q * k + j] = 0xFFFFFFFFu;
+        out_cnt[q] = oct_knn(t, qs[q], k, eps, out_idx + q * k, out_d2 ? out_d2 + q * k : nullptr);
+    });
+}
+// returns the number found; writes min(found, cap) indices in the reference's DFS order
+u64 orc_octree_range_sphere(void* h, float const* c, float r, u32* out, u64 cap)
+{
+    Octree const& t = *static_cast<Octree*>(h);
+    std::vector<u32> v;
+    oct_range(&t.root, t.pts, Sphere{P3{c[0], c[1], c[2]}, r}, v);
+    for (u64 i = 0; i < std::min<u64>(cap, v.size()); ++i) out[i] = v[i];
+    return v.size();
+}
+u64 orc_octree_range_aabb(void* h, float const* b6, u32* out, u64 cap)
+{
+    Octree const& t = *static_cast<Octree*>(h);
+    std::vector<u32> v;
+    BoxRange r{Box{P3{b6[0], b6[1], b6[2]}, P3{b6[3], b6[4], b6[5]}}};
+    oct_range(&t.root, t.pts, r, v);
+    for (u64 i = 0; i < std::min<u64>(cap, v.size()); ++i) out[i] = v[i];
+    return v.size();
+}
+void orc_octree_range_count(void* h, float const* qxyz, u64 nq, float r, u32* out_cnt, int nthreads)
+{
+    Octree const& t = *static_cast<Octree*>(h);
+    P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
+    parallel_for(nq, nthreads, [&](u64 q) {
+        std::vector<u32> v;
+        oct_range(&t.root, t.pts, Sphere{qs[q], r}, v);
+        out_cnt[q] = static_cast<u32>(v.size());
+    });
+}
+
+// ---- kd-tree ----
+void* orc_kdtree_create(float const* xyz, u64 n, u64 max_depth, int compute_max_depth, u64 max_elements_per_leaf)
+{
+    auto* t = new KdTree();
+    t->pts.assign(reinterpret_cast<P3 const*>(xyz), reinterpret_cast<P3 const*>(xyz) + n);
+    t->storage.resize(n);
+    std::iota(t->storage.begin(), t->storage.end(), 0u);
+    t->aabb = bounding_box(t->pts.data(), n);
+    t->max_depth = max_depth;
+    if (compute_max_depth) {  // linked_kdtree.hpp:117-124
+        double const d = std::log2(static_cast<double>(n) / static_cast<double>(max_elements_per_leaf));
+        if (d < 1.0) {
+            // (size_t)d is 0 (d in (-1,1)) or UB (d <= -1): in both cases `depth == max_depth_-1`
+            // never fires on x86-64, i.e. the tree splits down to single elements.
+            t->depth_unbounded = true;
+        } else {
+            t->max_depth = static_cast<std::size_t>(d);
+        }
+    }
+    if (t->max_depth == 0) t->depth_unbounded = true;
+    if (n > 0) t->root = kd_build(*t, 0u, n - 1u, 0u);  // empty tree is UB in the reference (:345-347)
+    return t;
+}
+void orc_kdtree_destroy(void* h) { delete static_cast<KdTree*>(h); }
+void orc_kdtree_knn(void* h, float const* qxyz, u64 nq, u32 k, float eps, u32* out_idx, u32* out_cnt,
+                    float* out_d2, int nthreads)
+{
+    KdTree const& t = *static_cast<KdTree*>(h);
+    P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
+    parallel_for(nq, nthreads, [&](u64 q) {
+        for (u32 j = 0; j < k; ++j) out_idx[q * k + j] = 0xFFFFFFFFu;
+        out_cnt[q] = kd_knn(t, qs[q], k, eps, out_idx + q * k, out_d2 ? out_d2 + q * k : nullptr);
+    });
+}
+u64 orc_kdtree_range_sphere(void* h, float const* c, float r, u32* out, u64 cap)
+{
+    KdTree const& t = *static_cast<KdTree*>(h);
+    std::vector<u32> v;
+    if (t.root) kd_range(t, Sphere{P3{c[0], c[1], c[2]}, r}, t.aabb, t.root.get(), v, 0);
+    for (u64 i = 0; i < std::min<u64>(cap, v.size()); ++i) out[i] = v[i];
+    return v.size();
+}
+u64 orc_kdtree_range_aabb(void* h, float const* b6, u32* out, u64 cap)
+{
+    KdTree const& t = *static_cast<KdTree*>(h);
+    std::vector<u32> v;
+    BoxRange r{Box{P3{b6[0], b6[1], b6[2]}, P3{b6[3], b6[4], b6[5]}}};
+    if (t.root) kd_range(t, r, t.aabb, t.root.get(), v, 0);
+    for (u64 i = 0; i < std::min<u64>(cap, v.size()); ++i) out[i] = v[i];
+    return v.size();
+}
+
+// ---- normals ----
+// pcp::estimate_normal over an explicit neighbourhood (idx == NULL: pts[0..n))
+void orc_estimate_normal(float const* xyz, u32 const* idx, u64 n, float out[3], float* evals3)
+{
+    estimate_normal(reinterpret_cast<P3 const*>(xyz), idx, n, out, evals3);
+}
+// normals from precomputed neighbour lists (nq x k, counts) -- the op the GPU normals kernel mirrors
+void orc_normals_from_knn(float const* xyz, u32 const* nbr, u32 const* cnt, u64 nq, u32 k, float* out_normals,
+                          float* out_evals, int nthreads)
+{
+    P3 const* pts = reinterpret_cast<P3 const*>(xyz);
+    parallel_for(nq, nthreads, [&](u64 q) {
+        estimate_normal(pts, nbr + q * k, cnt[q], out_normals + 3 * q, out_evals ? out_evals + 3 * q : nullptr);
+    });
+}
+// algorithm::estimate_normals (include/pcp/algorithm/estimate_normals.hpp:58-93) driven like
+// examples/simple_example.cpp:83-99: knn = octree.nearest_neighbours(p, k); normal = estimate_normal(knn).
+// tree_kind 0 = octree handle, 1 = kd-tree handle.  Queries are points [first, first+count) of the cloud.
+void orc_estimate_normals(void* h, int tree_kind, u64 first, u64 count, u32 k, float eps, float* out_normals,
+                          u32* out_idx, int nthreads)
+{
+    Octree const* ot = tree_kind == 0 ? static_cast<Octree*>(h) : nullptr;
+    KdTree const* kt = tree_kind == 1 ? static_cast<KdTree*>(h) : nullptr;
+    std::vector<P3> const& pts = ot ? ot->pts : kt->pts;
+    parallel_for(count, nthreads, [&](u64 i) {
+        std::vector<u32> nb(k);
+        u32 c = ot ? oct_knn(*ot, pts[first + i], k, eps, nb.data(), nullptr)
+                   : kd_knn(*kt, pts[first + i], k, eps, nb.data(), nullptr);
+        estimate_normal(pts.data(), nb.data(), c, out_normals + 3 * i, nullptr);
+        if (out_idx)
+            for (u32 j = 0; j < k; ++j) out_idx[i * k + j] = j < c ? nb[j] : 0xFFFFFFFFu;
+    });
+}
+
+int orc_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+"""pcp-mi355x: MI355X-native kNN / radius search / PCA normals behind the `pcp` API.
+
+The compute path is libpcpx.so (hand-written HIP for gfx950, C ABI in include/pcpx.h); importing the
+package does not load it, using any compute entry point does and fails loudly if it is missing.
+"""
+from . import ply, synthetic  # noqa: F401
+from .index import (Index, LinkedKdTree, LinkedOctree, PcpxError, bounding_box, device_count,  # noqa: F401
+                    estimate_normal, estimate_normals, shard_range)
+
+__all__ = ["Index", "LinkedOctree", "LinkedKdTree", "PcpxError", "bounding_box", "device_count", "estimate_normal",
+           "estimate_normals", "shard_range", "ply", "synthetic"]

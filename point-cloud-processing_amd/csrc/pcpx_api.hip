@@ -1,0 +1,613 @@
+// pcpx_api.hip -- the extern "C" boundary declared in include/pcpx.h.
+// Host-pointer entry points stage through device buffers and are synchronous; *_dev entry points
+// enqueue on the index's stream.  No CPU fallback exists: every compute call needs a HIP device.
+#include "pcpx_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+#include <vector>
+
+namespace pcpx {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int check_hip(hipError_t e, const char* what, const char* file, int line)
+{
+    if (e == hipSuccess) return PCPX_OK;
+    set_error("HIP error %d (%s) at %s:%d in %s", static_cast<int>(e), hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    return (e == hipErrorOutOfMemory) ? PCPX_ERR_ALLOC : PCPX_ERR_DEVICE;
+}
+
+namespace {
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return PCPX_ERR_ALLOC;
+        }
+        return PCPX_OK;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+int select_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("pcpx: no HIP device available (%s); libpcpx has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return PCPX_ERR_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("pcpx: device %d out of range [0,%d)", device, count);
+        return PCPX_ERR_INVALID;
+    }
+    PCPX_HIP(hipSetDevice(device));
+    return PCPX_OK;
+}
+
+int use(Index* ix)
+{
+    if (!ix) {
+        set_error("pcpx: null index handle");
+        return PCPX_ERR_INVALID;
+    }
+    PCPX_HIP(hipSetDevice(ix->device));
+    return PCPX_OK;
+}
+
+void slice_to_groups(const Index& ix, u64 sorted_first, u64 sorted_count, u64& gfirst, u64& gcount)
+{
+    u64 n = ix.n;
+    if (sorted_first > n) sorted_first = n;
+    u64 end = (sorted_count > n - sorted_first) ? n : sorted_first + sorted_count;
+    gfirst = sorted_first / GROUP;
+    u64 gend = (end + GROUP - 1) / GROUP;
+    gcount = gend > gfirst ? gend - gfirst : 0;
+}
+
+void free_index(Index* ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    (void)hipFree(ix->d_xyz);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(ix->d_codes[b]);
+        (void)hipFree(ix->d_vals[b]);
+    }
+    (void)hipFree(ix->d_sort_tmp);
+    (void)hipFree(ix->d_leaves);
+    (void)hipFree(ix->d_boxes);
+    (void)hipFree(ix->d_lvl);
+    (void)hipFree(ix->d_scalars);
+    (void)hipFree(ix->d_scratch);
+    if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+int exclusive_scan_host(const std::vector<u32>& cnt, u64* offsets)
+{
+    u64 acc = 0;
+    for (size_t i = 0; i < cnt.size(); ++i) {
+        offsets[i] = acc;
+        acc += cnt[i];
+    }
+    offsets[cnt.size()] = acc;
+    return PCPX_OK;
+}
+
+}  // namespace
+}  // namespace pcpx
+
+using namespace pcpx;
+
+extern "C" {
+
+int pcpx_abi_version(void) { return PCPX_ABI_VERSION; }
+const char* pcpx_last_error(void) { return g_err.c_str(); }
+
+int pcpx_device_count(int* out_count)
+{
+    if (!out_count) return PCPX_ERR_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *out_count = c;
+    return PCPX_OK;
+}
+
+static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_build_params* params, int device,
+                         void* stream, pcpx_index** out)
+{
+    if (!out || (n > 0 && !xyz)) {
+        set_error("pcpx_index_create: null argument");
+        return PCPX_ERR_INVALID;
+    }
+    if (params && params->struct_size != sizeof(pcpx_build_params)) {
+        set_error("pcpx_index_create: params->struct_size mismatch");
+        return PCPX_ERR_INVALID;
+    }
+    *out = nullptr;
+    int st = select_device(device);
+    if (st != PCPX_OK) return st;
+    Index* ix = new (std::nothrow) Index();
+    if (!ix) return PCPX_ERR_ALLOC;
+    ix->device = device;
+    if (stream) {
+        ix->stream = static_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ix;
+            return check_hip(e, "hipStreamCreate", __FILE__, __LINE__);
+        }
+        ix->own_stream = true;
+    }
+    DevBuf staged;
+    const float* d_src = xyz;
+    if (!on_device && n > 0) {
+        if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) {
+            free_index(ix);
+            return st;
+        }
+        hipError_t e = hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_index(ix);
+            return check_hip(e, "H2D copy of points", __FILE__, __LINE__);
+        }
+        d_src = staged.as<float>();
+    }
+    st = build_index(*ix, d_src, n, params);
+    if (st == PCPX_OK) st = check_hip(hipStreamSynchronize(ix->stream), "build sync", __FILE__, __LINE__);
+    if (st != PCPX_OK) {
+        free_index(ix);
+        return st;
+    }
+    *out = reinterpret_cast<pcpx_index*>(ix);
+    return PCPX_OK;
+}
+
+int pcpx_index_create(const float* xyz, uint64_t n, const pcpx_build_params* params, int device, pcpx_index** out)
+{
+    return create_common(xyz, false, n, params, device, nullptr, out);
+}
+int pcpx_index_create_dev(const float* d_xyz, uint64_t n, const pcpx_build_params* params, int device, void* stream,
+                          pcpx_index** out)
+{
+    return create_common(d_xyz, true, n, params, device, stream, out);
+}
+
+int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_build_params* params)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (n > 0 && !xyz) return PCPX_ERR_INVALID;
+    DevBuf staged;
+    if (n > 0) {
+        if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
+        PCPX_HIP(hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    st = build_index(*ix, staged.as<float>(), n, params);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+int pcpx_index_rebuild_dev(pcpx_index* h, const float* d_xyz, uint64_t n, const pcpx_build_params* params)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (n > 0 && !d_xyz) return PCPX_ERR_INVALID;
+    return build_index(*ix, d_xyz, n, params);
+}
+
+void pcpx_index_destroy(pcpx_index* h) { free_index(reinterpret_cast<Index*>(h)); }
+
+int pcpx_index_size(pcpx_index* h, uint64_t* out_n)
+{
+    if (!h || !out_n) return PCPX_ERR_INVALID;
+    *out_n = reinterpret_cast<Index*>(h)->n;
+    return PCPX_OK;
+}
+int pcpx_index_bbox(pcpx_index* h, float out6[6])
+{
+    if (!h || !out6) return PCPX_ERR_INVALID;
+    std::memcpy(out6, reinterpret_cast<Index*>(h)->bbox, 6 * sizeof(float));
+    return PCPX_OK;
+}
+int pcpx_index_synchronize(pcpx_index* h)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_bounding_box_dev(const float* d_xyz, uint64_t n, int device, void* stream, float* d_out6)
+{
+    int st = select_device(device);
+    if (st != PCPX_OK) return st;
+    if (!d_out6 || (n > 0 && !d_xyz)) return PCPX_ERR_INVALID;
+    // d_out6 must have room for the 6 floats; the encoded scratch is a temporary
+    DevBuf enc;
+    if ((st = enc.alloc(8 * sizeof(u32))) != PCPX_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    st = device_bbox(d_xyz, n, s, enc.as<u32>(), d_out6);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipStreamSynchronize(s));  // enc is freed on return
+    return PCPX_OK;
+}
+int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6])
+{
+    int st = select_device(device);
+    if (st != PCPX_OK) return st;
+    if (!out6 || (n > 0 && !xyz)) return PCPX_ERR_INVALID;
+    DevBuf pts, box;
+    if ((st = pts.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = box.alloc(6 * sizeof(float))) != PCPX_OK) return st;
+    if (n > 0) PCPX_HIP(hipMemcpy(pts.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    if ((st = pcpx_bounding_box_dev(pts.as<float>(), n, device, nullptr, box.as<float>())) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpy(out6, box.p, 6 * sizeof(float), hipMemcpyDeviceToHost));
+    return PCPX_OK;
+}
+
+// ---- kNN -----------------------------------------------------------------------------------------
+int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                      uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (k == 0) return PCPX_OK;  // linked_octree_node.hpp:464: k == 0 -> {}
+    if (!d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
+    if (sorted_first % GROUP != 0) {
+        set_error("pcpx_knn_self_dev: sorted_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
+    }
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, d_out_idx, d_out_count, d_out_d2);
+}
+
+int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count, float* out_d2)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
+    u64 rows = ix->n_in;
+    if (k == 0) {
+        std::memset(out_count, 0, rows * sizeof(u32));
+        return PCPX_OK;
+    }
+    DevBuf di, dc, dd;
+    if ((st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK) return st;
+    if ((st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
+    if (out_d2 && (st = dd.alloc(rows * k * sizeof(float))) != PCPX_OK) return st;
+    // rows of dropped (out-of-grid) points: count 0, padding
+    PCPX_HIP(hipMemsetAsync(di.p, 0xFF, rows * k * sizeof(u32), ix->stream));
+    PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
+    if (out_d2) PCPX_HIP(hipMemsetAsync(dd.p, 0x7F, rows * k * sizeof(float), ix->stream));
+    st = pcpx_knn_self_dev(h, k, eps, 0, UINT64_MAX, di.as<u32>(), dc.as<u32>(), out_d2 ? dd.as<float>() : nullptr);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_idx, di.p, rows * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipMemcpyAsync(out_count, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    if (out_d2) PCPX_HIP(hipMemcpyAsync(out_d2, dd.p, rows * k * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_t k, float eps, uint32_t* d_out_idx,
+                       uint32_t* d_out_count, float* d_out_d2)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (k == 0 || nq == 0) return PCPX_OK;
+    if (!d_q_xyz || !d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
+    QueryView qv;
+    if ((st = prepare_queries(*ix, d_q_xyz, nq, qv)) != PCPX_OK) return st;
+    return launch_knn(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, k, eps, d_out_idx, d_out_count, d_out_d2);
+}
+
+int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, float eps, uint32_t* out_idx,
+                   uint32_t* out_count, float* out_d2)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (nq == 0) return PCPX_OK;
+    if (!q_xyz || !out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
+    if (k == 0) {
+        std::memset(out_count, 0, nq * sizeof(u32));
+        return PCPX_OK;
+    }
+    DevBuf dq, di, dc, dd;
+    if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = di.alloc(nq * k * sizeof(u32))) != PCPX_OK) return st;
+    if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
+    if (out_d2 && (st = dd.alloc(nq * k * sizeof(float))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    st = pcpx_knn_batch_dev(h, dq.as<float>(), nq, k, eps, di.as<u32>(), dc.as<u32>(), out_d2 ? dd.as<float>() : nullptr);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_idx, di.p, nq * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipMemcpyAsync(out_count, dc.p, nq * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    if (out_d2) PCPX_HIP(hipMemcpyAsync(out_d2, dd.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+// ---- radius search -------------------------------------------------------------------------------
+int pcpx_range_count_self_dev(pcpx_index* h, float radius, uint64_t sorted_first, uint64_t sorted_count,
+                              uint32_t* d_out_count)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!d_out_count) return PCPX_ERR_INVALID;
+    if (sorted_first % GROUP != 0) {
+        set_error("pcpx_range_count_self_dev: sorted_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
+    }
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    return launch_range_count(*ix, qv, true, gf, gc, radius, nullptr, d_out_count);
+}
+
+int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_count) return PCPX_ERR_INVALID;
+    u64 rows = ix->n_in;
+    DevBuf dc;
+    if ((st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
+    if ((st = pcpx_range_count_self_dev(h, radius, 0, UINT64_MAX, dc.as<u32>())) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_count, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float radius, uint32_t* out_count)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (nq == 0) return PCPX_OK;
+    if (!q_xyz || !out_count) return PCPX_ERR_INVALID;
+    DevBuf dq, dc;
+    if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    QueryView qv;
+    if ((st = prepare_queries(*ix, dq.as<float>(), nq, qv)) != PCPX_OK) return st;
+    if ((st = launch_range_count(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, radius, nullptr, dc.as<u32>())) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(out_count, dc.p, nq * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radii, float radius, uint64_t nq,
+                            uint64_t* out_offsets, uint32_t* out_idx, uint64_t idx_capacity)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_offsets || (nq > 0 && !q_xyz)) return PCPX_ERR_INVALID;
+    if (nq == 0) {
+        out_offsets[0] = 0;
+        return PCPX_OK;
+    }
+    DevBuf dq, dr, dc, doff, dout;
+    if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    if (radii) {
+        if ((st = dr.alloc(nq * sizeof(float))) != PCPX_OK) return st;
+        PCPX_HIP(hipMemcpyAsync(dr.p, radii, nq * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    }
+    QueryView qv;
+    if ((st = prepare_queries(*ix, dq.as<float>(), nq, qv)) != PCPX_OK) return st;
+    if ((st = launch_range_count(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, radius, dr.as<float>(), dc.as<u32>())) != PCPX_OK)
+        return st;
+    std::vector<u32> cnt(nq);
+    PCPX_HIP(hipMemcpyAsync(cnt.data(), dc.p, nq * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    exclusive_scan_host(cnt, out_offsets);
+    u64 total = out_offsets[nq];
+    if (total == 0) return PCPX_OK;
+    if (!out_idx || idx_capacity < total) {
+        set_error("pcpx_range_sphere_batch: need room for %llu indices", static_cast<unsigned long long>(total));
+        return PCPX_ERR_CAPACITY;
+    }
+    if ((st = doff.alloc((nq + 1) * sizeof(u64))) != PCPX_OK) return st;
+    if ((st = dout.alloc(total * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(doff.p, out_offsets, (nq + 1) * sizeof(u64), hipMemcpyHostToDevice, ix->stream));
+    if ((st = launch_range_fill(*ix, qv, radius, dr.as<float>(), doff.as<u64>(), dout.as<u32>())) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_idx, dout.p, total * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint64_t* out_offsets, uint32_t* out_idx,
+                          uint64_t idx_capacity)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_offsets || (nb > 0 && !boxes6)) return PCPX_ERR_INVALID;
+    if (nb == 0) {
+        out_offsets[0] = 0;
+        return PCPX_OK;
+    }
+    DevBuf db, dc, doff, dout;
+    if ((st = db.alloc(nb * 6 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = dc.alloc(nb * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(db.p, boxes6, nb * 6 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    if ((st = launch_aabb_count(*ix, db.as<float>(), nb, dc.as<u32>())) != PCPX_OK) return st;
+    std::vector<u32> cnt(nb);
+    PCPX_HIP(hipMemcpyAsync(cnt.data(), dc.p, nb * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    exclusive_scan_host(cnt, out_offsets);
+    u64 total = out_offsets[nb];
+    if (total == 0) return PCPX_OK;
+    if (!out_idx || idx_capacity < total) {
+        set_error("pcpx_range_aabb_batch: need room for %llu indices", static_cast<unsigned long long>(total));
+        return PCPX_ERR_CAPACITY;
+    }
+    if ((st = doff.alloc((nb + 1) * sizeof(u64))) != PCPX_OK) return st;
+    if ((st = dout.alloc(total * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(doff.p, out_offsets, (nb + 1) * sizeof(u64), hipMemcpyHostToDevice, ix->stream));
+    if ((st = launch_aabb_fill(*ix, db.as<float>(), nb, doff.as<u64>(), dout.as<u32>())) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_idx, dout.p, total * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+// ---- normals -------------------------------------------------------------------------------------
+int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                              float* d_out_normals, uint32_t* d_opt_out_idx, uint32_t* d_opt_out_count)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!d_out_normals || k == 0) return PCPX_ERR_INVALID;
+    u32* d_idx = d_opt_out_idx;
+    u32* d_cnt = d_opt_out_count;
+    if (!d_idx || !d_cnt) {  // neighbour lists not wanted by the caller: keep them in index scratch
+        size_t need_idx = static_cast<size_t>(ix->n_in) * k * sizeof(u32), need_cnt = static_cast<size_t>(ix->n_in) * sizeof(u32);
+        need_idx = (need_idx + 255) / 256 * 256;
+        if ((st = ensure_scratch(*ix, need_idx + need_cnt)) != PCPX_OK) return st;
+        if (!d_idx) d_idx = static_cast<u32*>(ix->d_scratch);
+        if (!d_cnt) d_cnt = reinterpret_cast<u32*>(static_cast<char*>(ix->d_scratch) + need_idx);
+    }
+    if ((st = pcpx_knn_self_dev(h, k, eps, sorted_first, sorted_count, d_idx, d_cnt, nullptr)) != PCPX_OK) return st;
+    u64 n = ix->n;
+    u64 first = sorted_first > n ? n : sorted_first;
+    u64 count = (sorted_count > n - first) ? n - first : sorted_count;
+    return launch_normals(ix->d_xyz, d_idx, d_cnt, ix->perm(), first, count, k, d_out_normals, nullptr, ix->stream);
+}
+
+int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
+                          uint32_t* opt_out_count)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_normals || k == 0) return PCPX_ERR_INVALID;
+    u64 rows = ix->n_in;
+    DevBuf dn, di, dc;
+    if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK) return st;
+    if ((st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemsetAsync(dn.p, 0, rows * 3 * sizeof(float), ix->stream));
+    PCPX_HIP(hipMemsetAsync(di.p, 0xFF, rows * k * sizeof(u32), ix->stream));
+    PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
+    st = pcpx_normals_knn_self_dev(h, k, eps, 0, UINT64_MAX, dn.as<float>(), di.as<u32>(), dc.as<u32>());
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    if (opt_out_idx) PCPX_HIP(hipMemcpyAsync(opt_out_idx, di.p, rows * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    if (opt_out_count) PCPX_HIP(hipMemcpyAsync(opt_out_count, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq, uint32_t k,
+                          float* out_normals, float* opt_out_evals)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (nq == 0) return PCPX_OK;
+    if (!nbr_idx || !count || !out_normals || k == 0) return PCPX_ERR_INVALID;
+    for (u64 q = 0; q < nq; ++q) {
+        if (count[q] > k) {
+            set_error("pcpx_normals_from_knn: count[%llu] > k", static_cast<unsigned long long>(q));
+            return PCPX_ERR_INVALID;
+        }
+        for (u32 j = 0; j < count[q]; ++j)
+            if (nbr_idx[q * k + j] >= ix->n_in) {
+                set_error("pcpx_normals_from_knn: neighbour index out of range in row %llu", static_cast<unsigned long long>(q));
+                return PCPX_ERR_INVALID;
+            }
+    }
+    DevBuf di, dc, dn, de;
+    if ((st = di.alloc(nq * k * sizeof(u32))) != PCPX_OK) return st;
+    if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
+    if ((st = dn.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
+    if (opt_out_evals && (st = de.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(di.p, nbr_idx, nq * k * sizeof(u32), hipMemcpyHostToDevice, ix->stream));
+    PCPX_HIP(hipMemcpyAsync(dc.p, count, nq * sizeof(u32), hipMemcpyHostToDevice, ix->stream));
+    st = launch_normals(ix->d_xyz, di.as<u32>(), dc.as<u32>(), nullptr, 0, nq, k, dn.as<float>(),
+                        opt_out_evals ? de.as<float>() : nullptr, ix->stream);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, nq * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    if (opt_out_evals) PCPX_HIP(hipMemcpyAsync(opt_out_evals, de.p, nq * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_normal[3])
+{
+    int st = select_device(device);
+    if (st != PCPX_OK) return st;
+    if (!out_normal || (m > 0 && !xyz)) return PCPX_ERR_INVALID;
+    DevBuf dp, dn;
+    if ((st = dp.alloc(m * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = dn.alloc(3 * sizeof(float))) != PCPX_OK) return st;
+    if (m > 0) PCPX_HIP(hipMemcpy(dp.p, xyz, m * 3 * sizeof(float), hipMemcpyHostToDevice));
+    if ((st = launch_normal_single(dp.as<float>(), m, dn.as<float>(), nullptr)) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpy(out_normal, dn.p, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PCPX_OK;
+}
+
+int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count)
+{
+    if (!out_first || !out_count || world == 0 || rank >= world) return PCPX_ERR_INVALID;
+    u64 groups = (n + GROUP - 1) / GROUP;
+    u64 g0 = groups * rank / world, g1 = groups * (static_cast<u64>(rank) + 1) / world;
+    u64 first = g0 * GROUP, end = g1 * GROUP;
+    if (first > n) first = n;
+    if (end > n) end = n;
+    *out_first = first;
+    *out_count = end - first;
+    return PCPX_OK;
+}
+
+}  // extern "C"

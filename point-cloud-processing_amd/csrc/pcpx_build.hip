@@ -1,0 +1,362 @@
+// pcpx_build.hip -- index construction on the GPU.
+//
+// Replaces the reference's sequential octree insertion (include/pcp/octree/linked_octree_node.hpp:143-331)
+// and recursive nth_element kd-tree build (include/pcp/kdtree/linked_kdtree.hpp:343-424).  Only query
+// RESULTS are observable through the reference API, not the tree shape, so the structure here is a
+// Morton-sorted implicit AABB tree (pcpx_internal.h) built by:
+//   bbox reduce -> 63-bit Morton codes (+ out-of-grid drop) -> radix sort of (code, index)
+//   -> leaf records (SoA, NaN padded) -> leaf AABBs -> bottom-up sweep of the W-ary levels.
+#include "pcpx_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <limits>
+
+namespace pcpx {
+
+namespace {
+
+// order-preserving float <-> uint encoding for atomic min/max
+__device__ __forceinline__ u32 enc_f(float f)
+{
+    u32 b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(u32 e)
+{
+    u32 b = (e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e;
+    return __uint_as_float(b);
+}
+
+// pcp::bounding_box (include/pcp/common/axis_aligned_bounding_box.hpp:214-251): min/max per axis
+// from +-FLT_MAX with strict comparisons (NaN coordinates never update).
+__global__ void k_bbox_init(u32* enc6, u32* counter)
+{
+    if (threadIdx.x < 3) enc6[threadIdx.x] = enc_f(std::numeric_limits<float>::max());
+    else if (threadIdx.x < 6) enc6[threadIdx.x] = enc_f(std::numeric_limits<float>::lowest());
+    else if (threadIdx.x == 6) *counter = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, u64 n, u32* enc6)
+{
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(),
+                   std::numeric_limits<float>::max()};
+    float mx[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(),
+                   std::numeric_limits<float>::lowest()};
+    for (u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<u64>(gridDim.x) * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = xyz[3 * i + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&enc6[a], enc_f(mn[a]));
+            atomicMax(&enc6[3 + a], enc_f(mx[a]));
+        }
+    }
+}
+
+__global__ void k_bbox_decode(const u32* enc6, float* out6)
+{
+    if (threadIdx.x < 6) out6[threadIdx.x] = dec_f(enc6[threadIdx.x]);
+}
+
+__device__ __forceinline__ u64 spread21(u32 v)
+{
+    u64 x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__device__ __forceinline__ u32 quant21(float v, float lo, float hi)
+{
+    float ext = hi - lo;
+    float t = ext > 0.f ? (v - lo) / ext : 0.f;
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    u32 q = static_cast<u32>(t * 2097152.f);
+    return q > 2097151u ? 2097151u : q;
+}
+
+// Morton code of every point inside the grid; points outside (or NaN) get PAD_CODE and sort to the
+// end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive containment,
+// include/pcp/common/axis_aligned_bounding_box.hpp:111-125).
+__global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6,
+                                               u64* __restrict__ codes, u32* __restrict__ vals, u32* valid_counter)
+{
+    u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
+    bool ok = false;
+    if (i < n) {
+        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
+        ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
+        u64 c = PAD_CODE;
+        if (ok) c = (spread21(quant21(x, b0, b3)) << 2) | (spread21(quant21(y, b1, b4)) << 1) | spread21(quant21(z, b2, b5));
+        codes[i] = c;
+        vals[i] = static_cast<u32>(i);
+    }
+    u64 m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(valid_counter, static_cast<u32>(__popcll(m)));
+}
+
+__global__ __launch_bounds__(256) void k_fill_leaves(const float* __restrict__ xyz, const u32* __restrict__ perm,
+                                                     u32 n, u32 nslots, Leaf* __restrict__ leaves)
+{
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nslots) return;
+    float x = __builtin_nanf(""), y = x, z = x;
+    u32 id = INVALID_ID;
+    if (p < n) {
+        id = perm[p];
+        x = xyz[3 * static_cast<u64>(id)];
+        y = xyz[3 * static_cast<u64>(id) + 1];
+        z = xyz[3 * static_cast<u64>(id) + 2];
+    }
+    Leaf& lf = leaves[p / LEAF];
+    int s = p % LEAF;
+    lf.x[s] = x;
+    lf.y[s] = y;
+    lf.z[s] = z;
+    lf.id[s] = id;
+}
+
+__global__ __launch_bounds__(256) void k_leaf_boxes(const Leaf* __restrict__ leaves, u32 nleaves, u32 npadded,
+                                                    float* __restrict__ boxes)
+{
+    u32 l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= npadded) return;
+    float inf = std::numeric_limits<float>::infinity();
+    float b[6] = {inf, inf, inf, -inf, -inf, -inf};
+    if (l < nleaves) {
+        const Leaf& lf = leaves[l];
+#pragma unroll
+        for (int s = 0; s < LEAF; ++s) {  // NaN pads never win fminf/fmaxf
+            b[0] = fminf(b[0], lf.x[s]);
+            b[1] = fminf(b[1], lf.y[s]);
+            b[2] = fminf(b[2], lf.z[s]);
+            b[3] = fmaxf(b[3], lf.x[s]);
+            b[4] = fmaxf(b[4], lf.y[s]);
+            b[5] = fmaxf(b[5], lf.z[s]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) boxes[6 * static_cast<u64>(l) + a] = b[a];
+}
+
+__global__ __launch_bounds__(256) void k_upper_boxes(const float* __restrict__ child, u32 nchild, float* __restrict__ parent,
+                                                     u32 nparent, u32 nparent_padded)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparent_padded) return;
+    float inf = std::numeric_limits<float>::infinity();
+    float b[6] = {inf, inf, inf, -inf, -inf, -inf};
+    if (i < nparent) {
+        for (int c = 0; c < W; ++c) {
+            u32 ci = i * W + c;
+            if (ci >= nchild) break;
+            const float* cb = child + 6 * static_cast<u64>(ci);
+            b[0] = fminf(b[0], cb[0]);
+            b[1] = fminf(b[1], cb[1]);
+            b[2] = fminf(b[2], cb[2]);
+            b[3] = fmaxf(b[3], cb[3]);
+            b[4] = fmaxf(b[4], cb[4]);
+            b[5] = fmaxf(b[5], cb[5]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) parent[6 * static_cast<u64>(i) + a] = b[a];
+}
+
+template <class T>
+int dev_alloc(T*& p, size_t count)
+{
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return PCPX_ERR_ALLOC;
+    }
+    return PCPX_OK;
+}
+
+inline u32 round_up(u32 v, u32 m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n,
+                   hipStream_t s)
+{
+    // TODO(round 2): replace with the hand-written onesweep radix sort; rocPRIM is the first cut
+    // SURVEY.md section 7 (PR3) allows.
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, static_cast<size_t>(n), 0u, 64u, s);
+    return check_hip(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
+}
+
+int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6)
+{
+    k_bbox_init<<<1, 64, 0, s>>>(d_enc6, d_enc6 + 6);
+    if (n > 0) {
+        u64 blocks = (n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        k_bbox<<<static_cast<unsigned>(blocks), 256, 0, s>>>(d_xyz, n, d_enc6);
+    }
+    k_bbox_decode<<<1, 64, 0, s>>>(d_enc6, d_out6);
+    return check_hip(hipGetLastError(), "bbox kernels", __FILE__, __LINE__);
+}
+
+int ensure_scratch(Index& ix, size_t bytes)
+{
+    if (bytes <= ix.scratch_bytes) return PCPX_OK;
+    if (ix.d_scratch) {
+        PCPX_HIP(hipStreamSynchronize(ix.stream));
+        (void)hipFree(ix.d_scratch);
+        ix.d_scratch = nullptr;
+        ix.scratch_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ix.d_scratch, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for query scratch failed: %s", bytes, hipGetErrorString(e));
+        return PCPX_ERR_ALLOC;
+    }
+    ix.scratch_bytes = bytes;
+    return PCPX_OK;
+}
+
+// d_xyz_src: device pointer to n x 3 floats (copied into the index: the reference containers copy
+// their elements too, linked_kdtree.hpp:107).
+int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params)
+{
+    if (n >= 0xFFFFFFFEull) {
+        set_error("pcpx: n = %llu does not fit 32-bit point indices", static_cast<unsigned long long>(n));
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    bool use_grid = params && (params->flags & PCPX_BUILD_USE_GRID);
+    if (use_grid) {
+        for (int a = 0; a < 3; ++a)
+            if (!(params->grid_min[a] <= params->grid_max[a])) {
+                set_error("pcpx: voxel grid min must not exceed max on every axis");
+                return PCPX_ERR_INVALID;
+            }
+    }
+    hipStream_t s = ix.stream;
+    if (n > ix.cap || !ix.d_xyz) {
+        PCPX_HIP(hipStreamSynchronize(s));
+        u64 cap = n < 64 ? 64 : n;
+        int st;
+        if ((st = dev_alloc(ix.d_xyz, cap * 3)) != PCPX_OK) return st;
+        for (int b = 0; b < 2; ++b) {
+            if ((st = dev_alloc(ix.d_codes[b], cap)) != PCPX_OK) return st;
+            if ((st = dev_alloc(ix.d_vals[b], cap)) != PCPX_OK) return st;
+        }
+        u32 nl = static_cast<u32>((cap + LEAF - 1) / LEAF);
+        if ((st = dev_alloc(ix.d_leaves, nl)) != PCPX_OK) return st;
+        u64 nodes = 0;
+        for (u32 c = nl;; c = (c + W - 1) / W) {
+            nodes += round_up(c, W);
+            if (c <= 1) break;
+        }
+        if ((st = dev_alloc(ix.d_boxes, nodes * 6)) != PCPX_OK) return st;
+        ix.boxes_cap = nodes;
+        size_t tb = 0;
+        if ((st = sort_pairs_u64(nullptr, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], cap, s)) != PCPX_OK)
+            return st;
+        if (ix.d_sort_tmp) (void)hipFree(ix.d_sort_tmp);
+        ix.d_sort_tmp = nullptr;
+        PCPX_HIP(hipMalloc(&ix.d_sort_tmp, tb ? tb : 16));
+        ix.sort_tmp_bytes = tb;
+        ix.cap = cap;
+    }
+    if (!ix.d_lvl) {
+        int st;
+        if ((st = dev_alloc(ix.d_lvl, 2 * MAXLVL)) != PCPX_OK) return st;
+        if ((st = dev_alloc(ix.d_scalars, 16)) != PCPX_OK) return st;
+    }
+    ix.n_in = n;
+    if (n > 0 && d_xyz_src != ix.d_xyz)
+        PCPX_HIP(hipMemcpyAsync(ix.d_xyz, d_xyz_src, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    float* d_box = reinterpret_cast<float*>(ix.d_scalars + 8);
+    if (use_grid) {
+        float g[6] = {params->grid_min[0], params->grid_min[1], params->grid_min[2],
+                      params->grid_max[0], params->grid_max[1], params->grid_max[2]};
+        PCPX_HIP(hipMemcpyAsync(d_box, g, sizeof(g), hipMemcpyHostToDevice, s));
+        PCPX_HIP(hipMemsetAsync(ix.d_scalars + 6, 0, sizeof(u32), s));
+        PCPX_HIP(hipStreamSynchronize(s));  // g is a stack temporary
+    } else {
+        int st = device_bbox(ix.d_xyz, n, s, ix.d_scalars, d_box);
+        if (st != PCPX_OK) return st;
+    }
+    u32 nvalid = 0;
+    if (n > 0) {
+        unsigned blocks = static_cast<unsigned>((n + 255) / 256);
+        k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.d_codes[0], ix.d_vals[0], ix.d_scalars + 6);
+        PCPX_HIP(hipGetLastError());
+        size_t tb = ix.sort_tmp_bytes;
+        int st = sort_pairs_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], n, s);
+        if (st != PCPX_OK) return st;
+    }
+    float hb[8];
+    PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, 8 * sizeof(u32), hipMemcpyDeviceToHost, s));
+    PCPX_HIP(hipStreamSynchronize(s));
+    std::memcpy(&nvalid, &hb[0], sizeof(u32));
+    std::memcpy(ix.bbox, &hb[2], 6 * sizeof(float));
+    ix.n = nvalid;
+
+    // levels
+    u32 nleaves = (nvalid + LEAF - 1) / LEAF;
+    ix.nleaves = nleaves;
+    u32 off = 0, cnt = nleaves;
+    int lvl = 0;
+    std::memset(ix.h_lvl, 0, sizeof(ix.h_lvl));
+    for (;; ++lvl) {
+        if (lvl >= MAXLVL) {
+            set_error("pcpx: tree deeper than %d levels", MAXLVL);
+            return PCPX_ERR_UNSUPPORTED;
+        }
+        ix.h_lvl[lvl] = off;
+        ix.h_lvl[MAXLVL + lvl] = cnt;
+        off += round_up(cnt < 1 ? 1 : cnt, W);
+        if (cnt <= 1) break;
+        cnt = (cnt + W - 1) / W;
+    }
+    ix.top = lvl;
+    PCPX_HIP(hipMemcpyAsync(ix.d_lvl, ix.h_lvl, sizeof(ix.h_lvl), hipMemcpyHostToDevice, s));
+    if (nleaves > 0) {
+        u32 nslots = nleaves * LEAF;
+        k_fill_leaves<<<(nslots + 255) / 256, 256, 0, s>>>(ix.d_xyz, ix.perm(), nvalid, nslots, ix.d_leaves);
+        u32 npad = round_up(nleaves, W);
+        k_leaf_boxes<<<(npad + 255) / 256, 256, 0, s>>>(ix.d_leaves, nleaves, npad, ix.d_boxes);
+        for (int l = 1; l <= ix.top; ++l) {
+            u32 nc = ix.h_lvl[MAXLVL + l - 1], np = ix.h_lvl[MAXLVL + l];
+            u32 npp = round_up(np, W);
+            k_upper_boxes<<<(npp + 255) / 256, 256, 0, s>>>(ix.d_boxes + 6ull * ix.h_lvl[l - 1], nc,
+                                                              ix.d_boxes + 6ull * ix.h_lvl[l], np, npp);
+        }
+        PCPX_HIP(hipGetLastError());
+    }
+    return PCPX_OK;
+}
+
+}  // namespace pcpx

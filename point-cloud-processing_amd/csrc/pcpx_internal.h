@@ -1,0 +1,128 @@
+// pcpx_internal.h -- shared between the build, query and API translation units of libpcpx.so.
+//
+// Index layout in HBM (see DESIGN.md "Data layout"):
+//   * points are sorted by a 63-bit Morton code (21 bits/axis, x most significant like the
+//     reference's octant bits, include/pcp/octree/linked_octree_node.hpp:258-265);
+//   * the sorted order is cut into LEAVES of LEAF consecutive points, stored SoA per leaf
+//     {x[LEAF], y[LEAF], z[LEAF], id[LEAF]} so that one leaf is one contiguous 16*LEAF-byte record
+//     that a wavefront fetches with scalar (SMEM) loads and broadcasts to its 64 lanes;
+//   * above the leaves sits an IMPLICIT W-ary tree of tight AABBs: node i of level l covers
+//     children [i*W, i*W+W) of level l-1.  No pointers, no parent links: built by a bottom-up sweep.
+#ifndef PCPX_INTERNAL_H
+#define PCPX_INTERNAL_H
+
+#include <cstring>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "pcpx.h"
+
+namespace pcpx {
+
+using u32 = std::uint32_t;
+using u64 = std::uint64_t;
+
+constexpr int LEAF = 8;    // points per leaf
+constexpr int LOGW = 2;    // log2 of the tree arity
+constexpr int W = 1 << LOGW;
+constexpr int GROUP = 64;  // queries per wavefront
+constexpr int LEAVES_PER_GROUP = GROUP / LEAF;
+constexpr int MAXLVL = 16;
+constexpr u32 INVALID_ID = 0xFFFFFFFFu;
+constexpr u64 PAD_CODE = ~0ull;
+
+struct Leaf {
+    float x[LEAF];
+    float y[LEAF];
+    float z[LEAF];
+    u32 id[LEAF];
+};
+static_assert(sizeof(Leaf) == 16 * LEAF, "leaf record must be dense");
+
+struct TreeView {
+    const Leaf* leaves;  // nleaves records
+    const float* boxes;  // 6 floats per node, levels concatenated (level 0 = leaves), each level padded to W
+    const u32* lvl;      // [0,MAXLVL): node offset of level l; [MAXLVL,2*MAXLVL): node count of level l
+    u32 nleaves;
+    u32 n;               // indexed points
+    int top;             // index of the root level (its count is 1)
+};
+
+// Queries of a batch, in Morton-sorted order.  For self queries qx == nullptr and the query of
+// sorted position p is point p of the leaves.
+struct QueryView {
+    const float* qx;
+    const float* qy;
+    const float* qz;
+    const u32* row;   // output row of sorted query p
+    const u32* seed;  // first leaf of the seed range of group g
+    u32 nq;
+};
+
+struct Index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    u64 n_in = 0;     // input points
+    u64 n = 0;        // inserted points
+    u64 cap = 0;      // capacity (points) of the device buffers
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+
+    float* d_xyz = nullptr;      // n_in x 3, input order
+    u64* d_codes[2] = {nullptr, nullptr};
+    u32* d_vals[2] = {nullptr, nullptr};
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    Leaf* d_leaves = nullptr;
+    float* d_boxes = nullptr;
+    u64 boxes_cap = 0;           // nodes
+    u32* d_lvl = nullptr;        // 2*MAXLVL
+    u32* d_scalars = nullptr;    // [0..6) encoded bbox, [6] valid count, 6 floats decoded bbox at [8..14)
+    u32 h_lvl[2 * MAXLVL] = {};
+    u32 nleaves = 0;
+    int top = 0;
+
+    // scratch for batch queries (grown on demand)
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    u64* sorted_codes() const { return d_codes[1]; }
+    u32* perm() const { return d_vals[1]; }
+    TreeView view() const { return TreeView{d_leaves, d_boxes, d_lvl, nleaves, static_cast<u32>(n), top}; }
+};
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what, const char* file, int line);
+#define PCPX_HIP(expr)                                                       \
+    do {                                                                     \
+        int _s = ::pcpx::check_hip((expr), #expr, __FILE__, __LINE__);       \
+        if (_s != PCPX_OK) return _s;                                        \
+    } while (0)
+
+// build.hip
+int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
+int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6);
+int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n,
+                   hipStream_t s);
+int ensure_scratch(Index& ix, size_t bytes);
+
+// query.hip
+int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
+               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2);
+int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
+                       const float* d_radii, u32* d_out_cnt);
+int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,
+                      u32* d_out_idx);
+int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt);
+int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx);
+int launch_normals(const float* d_xyz, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first,
+                   u64 count, u32 k, float* d_out, float* d_evals, hipStream_t s);
+int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
+int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
+
+}  // namespace pcpx
+
+#endif

@@ -1,0 +1,864 @@
+// pcpx_query.hip -- batched kNN / radius search / PCA-normal kernels for gfx950 (wave64).
+//
+// Execution model (DESIGN.md "Kernels"):
+//   * ONE WAVEFRONT = 64 Morton-consecutive queries, one query per lane.
+//   * Tree traversal is WAVE-UNIFORM: node indices, the pending-children bit stack and all control
+//     flow live in SGPRs; node boxes and whole leaf records are fetched with scalar (SMEM) loads and
+//     broadcast to the 64 lanes as SGPR operands of the per-lane VALU distance code.  A subtree is
+//     entered when ANY lane still needs it (ballot), so the wave walks the union of its lanes' search
+//     regions -- small, because the lanes are neighbours on the Morton curve.
+//   * kNN selection: per lane a SORTED best-list of KCAP 64-bit keys (d2 bits << 32 | index) in VGPRs
+//     plus an UNSORTED append buffer in LDS (column per lane, conflict free).  A candidate with
+//     d2 <= tau is appended with one ds_write_b64; when any lane's column is full the whole wave runs a
+//     register bitonic sort of the new keys and a bitonic merge with the best-list, which also
+//     tightens tau = d2 of the k-th best.
+//   * The search is seeded with the 64 points of the query group itself (for arbitrary queries: the
+//     64-point chunk at the group's Morton position), so tau is tight before the traversal starts.
+//
+// Arithmetic follows the reference exactly: d = p - q, dx*dx + dy*dy + dz*dz in float32 without
+// FMA contraction (include/pcp/common/norm.hpp:102-112), eps-box exclusion
+// (include/pcp/common/vector3d_queries.hpp:47-64).  The box lower bound is monotone in float, so
+// pruning never changes the result: rows equal the exact (d2, index)-sorted k nearest.
+#include "pcpx_internal.h"
+
+#include <cmath>
+#include <limits>
+
+#pragma clang fp contract(off)
+
+namespace pcpx {
+
+namespace {
+
+constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID_ID): larger than every real key
+constexpr int WAVES_PER_BLOCK = 4;
+
+__device__ __forceinline__ u32 wave_in_block() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give XCD x the
+// contiguous range of virtual blocks [x*per, (x+1)*per): Morton neighbours then share one L2.
+__device__ __forceinline__ u32 virtual_block()
+{
+    u32 per = gridDim.x >> 3;  // grid is a multiple of 8
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
+
+// squared distance from q to the box; equals d2(q, clamp(q, box)) of
+// include/pcp/common/axis_aligned_bounding_box.hpp:138-148 and is a lower bound, in float
+// arithmetic, of sq3(p - q) for every p inside the box.
+__device__ __forceinline__ float box_d2(const float* __restrict__ b, float qx, float qy, float qz)
+{
+    float dx = fmaxf(fmaxf(b[0] - qx, qx - b[3]), 0.f);
+    float dy = fmaxf(fmaxf(b[1] - qy, qy - b[4]), 0.f);
+    float dz = fmaxf(fmaxf(b[2] - qz, qz - b[5]), 0.f);
+    return sq3(dx, dy, dz);
+}
+
+__device__ __forceinline__ void ce(u64& a, u64& b)
+{
+    u64 lo = a < b ? a : b;
+    u64 hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+
+template <int N>
+__device__ __forceinline__ void bitonic_sort(u64 (&a)[N])
+{
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                int l = i ^ j;
+                if (l > i) {
+                    if ((i & k) == 0) ce(a[i], a[l]);
+                    else ce(a[l], a[i]);
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
+{
+#pragma unroll
+    for (int j = N >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            int l = i ^ j;
+            if (l > i) ce(a[i], a[l]);
+        }
+    }
+}
+
+// Fold the first KCAP buffered keys of this lane into its sorted best-list; leftovers move down.
+template <int KCAP, int BUF>
+__device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
+{
+    u64 nw[KCAP];
+#pragma unroll
+    for (int j = 0; j < KCAP; ++j) nw[j] = j < cnt ? col[j * 64] : PAD_KEY;
+#pragma unroll
+    for (int j = 0; j < BUF - KCAP; ++j)
+        if (KCAP + j < cnt) col[j * 64] = col[(KCAP + j) * 64];
+    cnt = cnt > KCAP ? cnt - KCAP : 0;
+    bitonic_sort<KCAP>(nw);
+#pragma unroll
+    for (int j = 0; j < KCAP; ++j) {
+        u64 o = nw[KCAP - 1 - j];
+        best[j] = best[j] < o ? best[j] : o;
+    }
+    bitonic_merge<KCAP>(best);
+}
+
+struct Traversal {
+    // wave-uniform DFS over the implicit W-ary tree with a bit stack of pending children
+    u64 pend;
+    int l;       // level whose pending nibble is being consumed
+    u32 parent;  // index (at level l+1) of the node whose children are pending
+};
+
+// ------------------------------------------------------------------------------------------------
+// kNN
+// ------------------------------------------------------------------------------------------------
+template <int KCAP, bool SELF>
+__global__ __launch_bounds__(256) void k_knn(TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k,
+                                             float eps, u32* __restrict__ out_idx, u32* __restrict__ out_cnt,
+                                             float* __restrict__ out_d2)
+{
+    constexpr int BUF = KCAP + LEAF;
+    extern __shared__ u64 lds[];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wib = wave_in_block();
+    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wib;
+    if (g >= group_end) return;
+    u64* col = lds + static_cast<size_t>(wib) * BUF * 64 + lane;
+
+    // ---- my query ----
+    const u32 p = g * GROUP + lane;
+    const u32 nq = SELF ? t.n : qv.nq;
+    const bool valid = p < nq;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    u32 row = 0;
+    if (valid) {
+        if (SELF) {
+            const Leaf& lf = t.leaves[p / LEAF];
+            qx = lf.x[p % LEAF];
+            qy = lf.y[p % LEAF];
+            qz = lf.z[p % LEAF];
+            row = lf.id[p % LEAF];
+        } else {
+            qx = qv.qx[p];
+            qy = qv.qy[p];
+            qz = qv.qz[p];
+            row = qv.row[p];
+        }
+    }
+    // best-list: KCAP-k leading zero keys act as -inf sentinels so that tau is always best[KCAP-1]
+    u64 best[KCAP];
+#pragma unroll
+    for (int j = 0; j < KCAP; ++j) best[j] = (j < KCAP - static_cast<int>(k)) ? 0ull : PAD_KEY;
+    float tau = valid ? std::numeric_limits<float>::infinity() : -1.f;
+    int cnt = 0;
+
+    auto leaf_candidates = [&](u32 leaf) {
+        if (__ballot(cnt > KCAP) != 0ull) {
+            compact<KCAP, BUF>(best, col, cnt);
+            if (valid) tau = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+        }
+        const Leaf lf = t.leaves[leaf];  // wave-uniform address: SMEM loads into SGPRs
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+            float d2 = sq3(dx, dy, dz);
+            if (d2 <= tau) {
+                bool same = fabsf(dx) < eps && fabsf(dy) < eps && fabsf(dz) < eps;
+                if (!same) {
+                    col[cnt * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | lf.id[j];
+                    ++cnt;
+                }
+            }
+        }
+    };
+
+    // ---- seed: the 64-point chunk at the group's own Morton position ----
+    u32 s0, s1;
+    if (SELF) s0 = g * LEAVES_PER_GROUP;
+    else s0 = qv.seed[g];
+    s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
+    for (u32 lf = s0; lf < s1; ++lf) leaf_candidates(lf);
+    while (__ballot(cnt > 0) != 0ull) compact<KCAP, BUF>(best, col, cnt);
+    if (valid) tau = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+
+    // ---- traversal ----
+    if (t.top > 0) {
+        const float* rootbox = t.boxes + 6ull * t.lvl[t.top];
+        bool go = __ballot(valid && box_d2(rootbox, qx, qy, qz) <= tau) != 0ull;
+        int lev = t.top;  // node being expanded: (lev, node)
+        u32 node = 0;
+        u64 pend = 0;
+        while (go) {
+            // expand (lev, node): test its W children, all lanes against each child box
+            const int cl = lev - 1;
+            const u32 base = node << LOGW;
+            const u32 ccount = t.lvl[MAXLVL + cl];
+            const float* cb = t.boxes + 6ull * (t.lvl[cl] + base);
+            u32 m = 0;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                bool need = valid && box_d2(cb + 6 * c, qx, qy, qz) <= tau;
+                if (base + c < ccount && __ballot(need) != 0ull) m |= 1u << c;
+            }
+            pend |= static_cast<u64>(m) << (W * cl);
+            int l = cl;
+            u32 parent = node;
+            go = false;
+            for (;;) {
+                u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
+                if (mm) {
+                    int b = __builtin_ctz(mm);
+                    pend &= ~(1ull << (W * l + b));
+                    u32 child = (parent << LOGW) + b;
+                    if (l == 0) {
+                        if (child < s0 || child >= s1) leaf_candidates(child);
+                    } else {
+                        lev = l;
+                        node = child;
+                        go = true;
+                        break;
+                    }
+                } else {
+                    ++l;
+                    if (l >= t.top) break;
+                    parent >>= LOGW;
+                }
+            }
+        }
+    }
+    while (__ballot(cnt > 0) != 0ull) compact<KCAP, BUF>(best, col, cnt);
+
+    // ---- write the row ----
+    if (valid) {
+        u32 found = 0;
+        const u64 ob = static_cast<u64>(row) * k;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            int j = s - (KCAP - static_cast<int>(k));
+            if (j >= 0) {
+                u64 key = best[s];
+                bool ok = key != PAD_KEY;
+                out_idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
+                if (out_d2) out_d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
+                found += ok ? 1u : 0u;
+            }
+        }
+        out_cnt[row] = found;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
+// every point with d2 <= r*r, query included)
+// ------------------------------------------------------------------------------------------------
+template <bool SELF, bool FILL>
+__global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
+                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
+                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
+    if (g >= group_end) return;
+    const u32 p = g * GROUP + lane;
+    const u32 nq = SELF ? t.n : qv.nq;
+    const bool valid = p < nq;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    u32 row = 0;
+    if (valid) {
+        if (SELF) {
+            const Leaf& lf = t.leaves[p / LEAF];
+            qx = lf.x[p % LEAF];
+            qy = lf.y[p % LEAF];
+            qz = lf.z[p % LEAF];
+            row = lf.id[p % LEAF];
+        } else {
+            qx = qv.qx[p];
+            qy = qv.qy[p];
+            qz = qv.qz[p];
+            row = qv.row[p];
+        }
+    }
+    float r = radius;
+    if (radii && valid) r = radii[row];
+    const float r2 = valid ? r * r : -1.f;  // sphere.hpp:34 radius * radius in float
+    u32 cnt = 0;
+    u64 wpos = (FILL && valid) ? offsets[row] : 0;
+
+    auto leaf_candidates = [&](u32 leaf) {
+        const Leaf lf = t.leaves[leaf];
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+            if (sq3(dx, dy, dz) <= r2) {
+                if (FILL) out_idx[wpos + cnt] = lf.id[j];
+                ++cnt;
+            }
+        }
+    };
+
+    if (t.nleaves > 0) {
+        const float* rootbox = t.boxes + 6ull * t.lvl[t.top];
+        bool go = __ballot(valid && box_d2(rootbox, qx, qy, qz) <= r2) != 0ull;
+        if (t.top == 0) {
+            if (go) leaf_candidates(0);
+            go = false;
+        }
+        int lev = t.top;
+        u32 node = 0;
+        u64 pend = 0;
+        while (go) {
+            const int cl = lev - 1;
+            const u32 base = node << LOGW;
+            const u32 ccount = t.lvl[MAXLVL + cl];
+            const float* cb = t.boxes + 6ull * (t.lvl[cl] + base);
+            u32 m = 0;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                bool need = valid && box_d2(cb + 6 * c, qx, qy, qz) <= r2;
+                if (base + c < ccount && __ballot(need) != 0ull) m |= 1u << c;
+            }
+            pend |= static_cast<u64>(m) << (W * cl);
+            int l = cl;
+            u32 parent = node;
+            go = false;
+            for (;;) {
+                u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
+                if (mm) {
+                    int b = __builtin_ctz(mm);
+                    pend &= ~(1ull << (W * l + b));
+                    u32 child = (parent << LOGW) + b;
+                    if (l == 0) {
+                        leaf_candidates(child);
+                    } else {
+                        lev = l;
+                        node = child;
+                        go = true;
+                        break;
+                    }
+                } else {
+                    ++l;
+                    if (l >= t.top) break;
+                    parent >>= LOGW;
+                }
+            }
+        }
+    }
+    if (valid && !FILL) out_cnt[row] = cnt;
+}
+
+// AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:
+// test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
+// (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
+                                                    u32* __restrict__ out_cnt, const u64* __restrict__ offsets,
+                                                    u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const u32 p = g * GROUP + lane;
+    const bool valid = p < nb;
+    float b[6] = {0, 0, 0, 0, 0, 0};
+    if (valid)
+        for (int a = 0; a < 6; ++a) b[a] = boxes6[6ull * p + a];
+    u32 cnt = 0;
+    u64 wpos = (FILL && valid) ? offsets[p] : 0;
+    auto overlaps = [&](const float* nb6) {
+        return valid && (nb6[3] >= b[0] && nb6[4] >= b[1] && nb6[5] >= b[2]) &&
+               (nb6[0] <= b[3] && nb6[1] <= b[4] && nb6[2] <= b[5]);
+    };
+    auto leaf_candidates = [&](u32 leaf) {
+        const Leaf lf = t.leaves[leaf];
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float x = lf.x[j], y = lf.y[j], z = lf.z[j];
+            bool in = valid && (x >= b[0] && y >= b[1] && z >= b[2]) && (x <= b[3] && y <= b[4] && z <= b[5]);
+            if (in) {
+                if (FILL) out_idx[wpos + cnt] = lf.id[j];
+                ++cnt;
+            }
+        }
+    };
+    if (t.nleaves > 0 && __ballot(valid) != 0ull) {
+        const float* rootbox = t.boxes + 6ull * t.lvl[t.top];
+        bool go = __ballot(overlaps(rootbox)) != 0ull;
+        if (t.top == 0) {
+            if (go) leaf_candidates(0);
+            go = false;
+        }
+        int lev = t.top;
+        u32 node = 0;
+        u64 pend = 0;
+        while (go) {
+            const int cl = lev - 1;
+            const u32 base = node << LOGW;
+            const u32 ccount = t.lvl[MAXLVL + cl];
+            const float* cb = t.boxes + 6ull * (t.lvl[cl] + base);
+            u32 m = 0;
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (base + c < ccount && __ballot(overlaps(cb + 6 * c)) != 0ull) m |= 1u << c;
+            pend |= static_cast<u64>(m) << (W * cl);
+            int l = cl;
+            u32 parent = node;
+            go = false;
+            for (;;) {
+                u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
+                if (mm) {
+                    int bb = __builtin_ctz(mm);
+                    pend &= ~(1ull << (W * l + bb));
+                    u32 child = (parent << LOGW) + bb;
+                    if (l == 0) {
+                        leaf_candidates(child);
+                    } else {
+                        lev = l;
+                        node = child;
+                        go = true;
+                        break;
+                    }
+                } else {
+                    ++l;
+                    if (l >= t.top) break;
+                    parent >>= LOGW;
+                }
+            }
+        }
+    }
+    if (valid && !FILL) out_cnt[p] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCA normal of one neighbourhood per thread.
+// Restates pcp::estimate_normal (include/pcp/common/normals/normal_estimation.hpp:41-77): row mean,
+// centred scatter matrix V'V'^T (not divided by n), Eigen 3.3.8 SelfAdjointEigenSolver<Matrix3f>
+// ::compute (scale, closed-form 3x3 tridiagonalisation, implicit-shift QL, ascending sort), column of
+// the smallest eigenvalue with the reference's "last tie wins" ifs.  All in float32 without FMA, in
+// the same operation order as the CPU restatement used by the tests, so results are bit-comparable with it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void make_givens(float p, float q, float& c, float& s)
+{
+    if (q == 0.f) {
+        c = p < 0.f ? -1.f : 1.f;
+        s = 0.f;
+    } else if (p == 0.f) {
+        c = 0.f;
+        s = q < 0.f ? 1.f : -1.f;
+    } else if (fabsf(p) > fabsf(q)) {
+        float t = q / p;
+        float u = sqrtf(1.f + t * t);
+        if (p < 0.f) u = -u;
+        c = 1.f / u;
+        s = -t * c;
+    } else {
+        float t = p / q;
+        float u = sqrtf(1.f + t * t);
+        if (q < 0.f) u = -u;
+        s = -1.f / u;
+        c = -t * s;
+    }
+}
+
+__device__ __forceinline__ float eig_hypot(float x, float y)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float p, qp;
+    if (ax > ay) {
+        p = ax;
+        qp = ay / p;
+    } else {
+        p = ay;
+        qp = ax / p;
+    }
+    if (p == 0.f) return 0.f;
+    return p * sqrtf(1.f + qp * qp);
+}
+
+__device__ void eig3_smallest(float a00, float a10, float a20, float a11, float a21, float a22, float normal[3],
+                              float evals[3])
+{
+    float scale = fmaxf(fmaxf(fmaxf(fabsf(a00), fabsf(a10)), fmaxf(fabsf(a20), fabsf(a11))),
+                        fmaxf(fabsf(a21), fabsf(a22)));
+    if (scale == 0.f) scale = 1.f;
+    a00 /= scale; a10 /= scale; a20 /= scale; a11 /= scale; a21 /= scale; a22 /= scale;
+    float d0, d1, d2, e0, e1;
+    float q00 = 1.f, q10 = 0.f, q20 = 0.f, q01 = 0.f, q11 = 1.f, q21 = 0.f, q02 = 0.f, q12 = 0.f, q22 = 1.f;
+    const float tiny = std::numeric_limits<float>::min();
+    d0 = a00;
+    float v1norm2 = a20 * a20;
+    if (v1norm2 <= tiny) {
+        d1 = a11; d2 = a22; e0 = a10; e1 = a21;
+    } else {
+        float beta = sqrtf(a10 * a10 + v1norm2);
+        float inv_beta = 1.f / beta;
+        float m01 = a10 * inv_beta, m02 = a20 * inv_beta;
+        float q = 2.f * m01 * a21 + m02 * (a22 - a11);
+        d1 = a11 + m02 * q;
+        d2 = a22 - m02 * q;
+        e0 = beta;
+        e1 = a21 - m01 * q;
+        q11 = m01; q21 = m02; q12 = m02; q22 = -m01;
+    }
+    // registers instead of arrays: diag = {d0,d1,d2}, sub = {e0,e1}, Q columns {q?0,q?1,q?2}
+    const float precision = 2.f * std::numeric_limits<float>::epsilon();
+    int end = 2, start = 0, iter = 0;
+    bool converged = true;
+    auto rot_cols01 = [&](float c, float s) {
+        float x, y;
+        x = q00; y = q01; q00 = c * x - s * y; q01 = s * x + c * y;
+        x = q10; y = q11; q10 = c * x - s * y; q11 = s * x + c * y;
+        x = q20; y = q21; q20 = c * x - s * y; q21 = s * x + c * y;
+    };
+    auto rot_cols12 = [&](float c, float s) {
+        float x, y;
+        x = q01; y = q02; q01 = c * x - s * y; q02 = s * x + c * y;
+        x = q11; y = q12; q11 = c * x - s * y; q12 = s * x + c * y;
+        x = q21; y = q22; q21 = c * x - s * y; q22 = s * x + c * y;
+    };
+    while (end > 0) {
+        if (start <= 0 && 0 < end)
+            if (fabsf(e0) <= (fabsf(d0) + fabsf(d1)) * precision || fabsf(e0) <= tiny) e0 = 0.f;
+        if (start <= 1 && 1 < end)
+            if (fabsf(e1) <= (fabsf(d1) + fabsf(d2)) * precision || fabsf(e1) <= tiny) e1 = 0.f;
+        while (end > 0 && (end == 2 ? e1 : e0) == 0.f) end--;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 90) { converged = false; break; }
+        start = end - 1;
+        while (start > 0 && (start == 1 ? e0 : 0.f) != 0.f) start--;
+        // tridiagonal_qr_step(start, end)
+        float dem1 = end == 2 ? d1 : d0, de = end == 2 ? d2 : d1, ee = end == 2 ? e1 : e0;
+        float td = (dem1 - de) * 0.5f;
+        float mu = de;
+        if (td == 0.f) {
+            mu -= fabsf(ee);
+        } else {
+            float e2 = ee * ee;
+            float h = eig_hypot(td, ee);
+            if (e2 == 0.f) mu -= (ee / (td + (td > 0.f ? 1.f : -1.f))) * (ee / h);
+            else mu -= e2 / (td + (td > 0.f ? h : -h));
+        }
+        float x = (start == 0 ? d0 : d1) - mu;
+        float z = start == 0 ? e0 : e1;
+        for (int k = start; k < end; ++k) {
+            float c, s;
+            make_givens(x, z, c, s);
+            float dk = k == 0 ? d0 : d1, dk1 = k == 0 ? d1 : d2, sk = k == 0 ? e0 : e1;
+            float sdk = s * dk + c * sk;
+            float dkp1 = s * sk + c * dk1;
+            float ndk = c * (c * dk - s * sk) - s * (c * sk - s * dk1);
+            float ndk1 = s * sdk + c * dkp1;
+            float nsk = c * sdk - s * dkp1;
+            if (k == 0) { d0 = ndk; d1 = ndk1; e0 = nsk; }
+            else { d1 = ndk; d2 = ndk1; e1 = nsk; }
+            if (k > start) e0 = c * e0 - s * z;  // k == 1, start == 0: sub[k-1] = sub[0]
+            x = nsk;
+            if (k < end - 1) {  // k == 0, end == 2
+                z = -s * e1;
+                e1 = c * e1;
+            }
+            if (k == 0) rot_cols01(c, s);
+            else rot_cols12(c, s);
+        }
+    }
+    if (converged) {
+        // ascending selection sort (first minimum wins), swapping eigenvector columns
+        auto swap01 = [&]() {
+            float t;
+            t = d0; d0 = d1; d1 = t;
+            t = q00; q00 = q01; q01 = t; t = q10; q10 = q11; q11 = t; t = q20; q20 = q21; q21 = t;
+        };
+        auto swap02 = [&]() {
+            float t;
+            t = d0; d0 = d2; d2 = t;
+            t = q00; q00 = q02; q02 = t; t = q10; q10 = q12; q12 = t; t = q20; q20 = q22; q22 = t;
+        };
+        auto swap12 = [&]() {
+            float t;
+            t = d1; d1 = d2; d2 = t;
+            t = q01; q01 = q02; q02 = t; t = q11; q11 = q12; q12 = t; t = q21; q21 = q22; q22 = t;
+        };
+        int kmin = 0;
+        float mv = d0;
+        if (d1 < mv) { mv = d1; kmin = 1; }
+        if (d2 < mv) { mv = d2; kmin = 2; }
+        if (kmin == 1) swap01();
+        else if (kmin == 2) swap02();
+        if (d2 < d1) swap12();
+    }
+    float l0 = d0 * scale, l1 = d1 * scale, l2 = d2 * scale;
+    evals[0] = l0; evals[1] = l1; evals[2] = l2;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (l0 <= l1 && l0 <= l2) { nx = q00; ny = q10; nz = q20; }
+    if (l1 <= l0 && l1 <= l2) { nx = q01; ny = q11; nz = q21; }
+    if (l2 <= l0 && l2 <= l1) { nx = q02; ny = q12; nz = q22; }
+    normal[0] = nx; normal[1] = ny; normal[2] = nz;
+}
+
+// thread i handles neighbourhood row = rowmap ? rowmap[first+i] : first+i
+__global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, const u32* __restrict__ nbr,
+                                                 const u32* __restrict__ cnt, const u32* __restrict__ rowmap, u64 first,
+                                                 u64 count, u32 k, float* __restrict__ out, float* __restrict__ evals)
+{
+    u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    u64 row = rowmap ? rowmap[first + i] : first + i;
+    u32 n = cnt ? cnt[row] : k;
+    const u32* nb = nbr + row * k;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u32 j = 0; j < n; ++j) {
+        u64 id = nb[j];
+        float x = xyz[3 * id], y = xyz[3 * id + 1], z = xyz[3 * id + 2];
+        if (j == 0) { sx = x; sy = y; sz = z; }
+        else { sx += x; sy += y; sz += z; }
+    }
+    float fn = static_cast<float>(n);
+    float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    for (u32 j = 0; j < n; ++j) {
+        u64 id = nb[j];
+        float vx = xyz[3 * id] - mx, vy = xyz[3 * id + 1] - my, vz = xyz[3 * id + 2] - mz;
+        c00 += vx * vx;
+        c10 += vy * vx;
+        c11 += vy * vy;
+        c20 += vz * vx;
+        c21 += vz * vy;
+        c22 += vz * vz;
+    }
+    float nrm[3], ev[3];
+    eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
+    out[3 * row] = nrm[0];
+    out[3 * row + 1] = nrm[1];
+    out[3 * row + 2] = nrm[2];
+    if (evals) {
+        evals[3 * row] = ev[0];
+        evals[3 * row + 1] = ev[1];
+        evals[3 * row + 2] = ev[2];
+    }
+}
+
+// estimate_normal over an explicit point set (m x 3): a single thread, the set is tiny in practice
+__global__ void k_normal_single(const float* __restrict__ xyz, u64 m, float* __restrict__ out3)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u64 j = 0; j < m; ++j) {
+        float x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
+        if (j == 0) { sx = x; sy = y; sz = z; }
+        else { sx += x; sy += y; sz += z; }
+    }
+    float fn = static_cast<float>(m);
+    float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    for (u64 j = 0; j < m; ++j) {
+        float vx = xyz[3 * j] - mx, vy = xyz[3 * j + 1] - my, vz = xyz[3 * j + 2] - mz;
+        c00 += vx * vx; c10 += vy * vx; c11 += vy * vy; c20 += vz * vx; c21 += vz * vy; c22 += vz * vz;
+    }
+    float ev[3];
+    eig3_smallest(c00, c10, c20, c11, c21, c22, out3, ev);
+}
+
+// ------------------------------------------------------------------------------------------------
+// arbitrary query batches: Morton-sort the queries on the index's grid, seed each group at the
+// 64-point chunk where its first query would sit in the sorted cloud
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 spread21(u32 v)
+{
+    u64 x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__device__ __forceinline__ u32 quant21(float v, float lo, float hi)
+{
+    float ext = hi - lo;
+    float t = ext > 0.f ? (v - lo) / ext : 0.f;
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    u32 q = static_cast<u32>(t * 2097152.f);
+    return q > 2097151u ? 2097151u : q;
+}
+
+__global__ __launch_bounds__(256) void k_query_codes(const float* __restrict__ q, u32 nq, const float* __restrict__ box6,
+                                                     u64* __restrict__ codes, u32* __restrict__ vals)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    float x = q[3ull * i], y = q[3ull * i + 1], z = q[3ull * i + 2];
+    codes[i] = (spread21(quant21(x, box6[0], box6[3])) << 2) | (spread21(quant21(y, box6[1], box6[4])) << 1) |
+               spread21(quant21(z, box6[2], box6[5]));
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_query_gather(const float* __restrict__ q, const u32* __restrict__ order, u32 nq,
+                                                      float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    u64 o = order[i];
+    qx[i] = q[3 * o];
+    qy[i] = q[3 * o + 1];
+    qz[i] = q[3 * o + 2];
+}
+
+__global__ __launch_bounds__(256) void k_query_seeds(const u64* __restrict__ qcodes, u32 nq, const u64* __restrict__ pcodes,
+                                                     u32 n, u32 nleaves, u32* __restrict__ seed, u32 ngroups)
+{
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    u32 mid = g * GROUP + GROUP / 2;
+    if (mid >= nq) mid = nq - 1;
+    u64 c = qcodes[mid];
+    u32 lo = 0, hi = n;  // lower_bound over the sorted point codes
+    while (lo < hi) {
+        u32 m = lo + ((hi - lo) >> 1);
+        if (pcodes[m] < c) lo = m + 1;
+        else hi = m;
+    }
+    u32 chunk = lo / GROUP;
+    u32 s0 = chunk * LEAVES_PER_GROUP;
+    if (s0 >= nleaves) s0 = nleaves > LEAVES_PER_GROUP ? ((nleaves - 1) / LEAVES_PER_GROUP) * LEAVES_PER_GROUP : 0;
+    seed[g] = s0;
+}
+
+inline u32 grid_for_groups(u64 groups)
+{
+    u64 blocks = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    blocks = (blocks + 7) / 8 * 8;
+    return static_cast<u32>(blocks);
+}
+
+}  // namespace
+
+int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
+{
+    if (nq >= 0xFFFFFFFEull) {
+        set_error("pcpx: nq = %llu does not fit 32-bit rows", static_cast<unsigned long long>(nq));
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = ix.stream;
+    u32 n32 = static_cast<u32>(nq);
+    u64 ngroups = (nq + GROUP - 1) / GROUP;
+    size_t tb = 0;
+    int st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, nq, s);
+    if (st != PCPX_OK) return st;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t o_codes0 = 0, o_codes1 = o_codes0 + al(nq * 8), o_vals0 = o_codes1 + al(nq * 8), o_vals1 = o_vals0 + al(nq * 4),
+           o_qx = o_vals1 + al(nq * 4), o_qy = o_qx + al(nq * 4), o_qz = o_qy + al(nq * 4), o_seed = o_qz + al(nq * 4),
+           o_tmp = o_seed + al(ngroups * 4), total = o_tmp + al(tb);
+    if ((st = ensure_scratch(ix, total)) != PCPX_OK) return st;
+    char* base = static_cast<char*>(ix.d_scratch);
+    u64* codes0 = reinterpret_cast<u64*>(base + o_codes0);
+    u64* codes1 = reinterpret_cast<u64*>(base + o_codes1);
+    u32* vals0 = reinterpret_cast<u32*>(base + o_vals0);
+    u32* vals1 = reinterpret_cast<u32*>(base + o_vals1);
+    float* qx = reinterpret_cast<float*>(base + o_qx);
+    float* qy = reinterpret_cast<float*>(base + o_qy);
+    float* qz = reinterpret_cast<float*>(base + o_qz);
+    u32* seed = reinterpret_cast<u32*>(base + o_seed);
+    if (nq > 0) {
+        const float* d_box = reinterpret_cast<const float*>(ix.d_scalars + 8);
+        k_query_codes<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, n32, d_box, codes0, vals0);
+        if ((st = sort_pairs_u64(base + o_tmp, tb, codes0, codes1, vals0, vals1, nq, s)) != PCPX_OK) return st;
+        k_query_gather<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, vals1, n32, qx, qy, qz);
+        k_query_seeds<<<static_cast<u32>((ngroups + 255) / 256), 256, 0, s>>>(
+            codes1, n32, ix.sorted_codes(), static_cast<u32>(ix.n), ix.nleaves, seed, static_cast<u32>(ngroups));
+        PCPX_HIP(hipGetLastError());
+    }
+    qv = QueryView{qx, qy, qz, vals1, seed, n32};
+    return PCPX_OK;
+}
+
+template <int KCAP>
+static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, u32* oi,
+                        u32* oc, float* od)
+{
+    constexpr int BUF = KCAP + LEAF;
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * BUF * 64 * sizeof(u64);
+    u32 grid = grid_for_groups(gcount);
+    u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
+    if (self) k_knn<KCAP, true><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od);
+    else k_knn<KCAP, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od);
+    return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
+}
+
+int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
+               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2)
+{
+    if (group_count == 0) return PCPX_OK;
+    if (k <= 16) return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2);
+    if (k <= 32) return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2);
+    set_error("pcpx: k = %u > 32 is not supported yet", k);
+    return PCPX_ERR_UNSUPPORTED;
+}
+
+int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
+                       const float* d_radii, u32* d_out_cnt)
+{
+    if (group_count == 0) return PCPX_OK;
+    u32 grid = grid_for_groups(group_count);
+    u32 gf = static_cast<u32>(group_first), ge = static_cast<u32>(group_first + group_count);
+    if (self)
+        k_range<true, false><<<grid, 256, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
+    else
+        k_range<false, false><<<grid, 256, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
+    return check_hip(hipGetLastError(), "k_range launch", __FILE__, __LINE__);
+}
+
+int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,
+                      u32* d_out_idx)
+{
+    u64 groups = (static_cast<u64>(qv.nq) + GROUP - 1) / GROUP;
+    if (groups == 0) return PCPX_OK;
+    k_range<false, true><<<grid_for_groups(groups), 256, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
+                                                                           d_radii, nullptr, d_offsets, d_out_idx);
+    return check_hip(hipGetLastError(), "k_range fill launch", __FILE__, __LINE__);
+}
+
+int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt)
+{
+    if (nb == 0) return PCPX_OK;
+    u32 grid = static_cast<u32>((nb + 255) / 256);
+    k_range_aabb<false><<<grid, 256, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), d_out_cnt, nullptr, nullptr);
+    return check_hip(hipGetLastError(), "k_range_aabb launch", __FILE__, __LINE__);
+}
+
+int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx)
+{
+    if (nb == 0) return PCPX_OK;
+    u32 grid = static_cast<u32>((nb + 255) / 256);
+    k_range_aabb<true><<<grid, 256, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), nullptr, d_offsets, d_out_idx);
+    return check_hip(hipGetLastError(), "k_range_aabb fill launch", __FILE__, __LINE__);
+}
+
+int launch_normals(const float* d_xyz, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count,
+                   u32 k, float* d_out, float* d_evals, hipStream_t s)
+{
+    if (count == 0) return PCPX_OK;
+    k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
+                                                                     d_evals);
+    return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);
+}
+
+int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s)
+{
+    k_normal_single<<<1, 64, 0, s>>>(d_xyz, m, d_out3);
+    return check_hip(hipGetLastError(), "k_normal_single launch", __FILE__, __LINE__);
+}
+
+}  // namespace pcpx

@@ -1,0 +1,261 @@
+"""Host-side mirror (Python) of the reference's spatial containers and normal estimation, in batched
+form, over the C ABI of libpcpx.so.  The C++17 drop-in headers live in include/pcp/; this module
+exists so that tests and bench.py can drive the same entry points from Python.
+
+Names follow the reference: LinkedOctree ~ pcp::basic_linked_octree_t
+(include/pcp/octree/linked_octree.hpp:40-41), LinkedKdTree ~ pcp::basic_linked_kdtree_t
+(include/pcp/kdtree/linked_kdtree.hpp:64-65), estimate_normals ~ pcp::algorithm::estimate_normals
+(include/pcp/algorithm/estimate_normals.hpp:58-65).  Elements are indices into the input array.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import BuildParams, PcpxError, check  # noqa: F401
+
+INVALID = np.uint32(0xFFFFFFFF)
+
+
+def _f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    n = C.c_int(0)
+    check(_capi.load().pcpx_device_count(C.byref(n)))
+    return n.value
+
+
+def bounding_box(xyz, device=0):
+    """pcp::bounding_box (include/pcp/common/axis_aligned_bounding_box.hpp:214-251) on the GPU."""
+    xyz = _f32(xyz, 3)
+    out = np.zeros(6, np.float32)
+    check(_capi.load().pcpx_bounding_box(_vp(xyz), len(xyz), device, out.ctypes.data_as(_capi.f32p)))
+    return out
+
+
+def shard_range(n, rank, world):
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(_capi.load().pcpx_shard_range(n, rank, world, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def estimate_normal(points, device=0):
+    """pcp::estimate_normal (include/pcp/common/normals/normal_estimation.hpp:32-78)."""
+    pts = _f32(points, 3)
+    out = np.zeros(3, np.float32)
+    check(_capi.load().pcpx_estimate_normal(_vp(pts), len(pts), device, out.ctypes.data_as(_capi.f32p)))
+    return out
+
+
+class Index:
+    """Owns a pcpx_index handle: the device-resident Morton-sorted implicit AABB tree."""
+
+    def __init__(self, xyz, voxel_grid=None, device=0):
+        self._lib = _capi.load()
+        self._h = C.c_void_p(None)
+        self.device = device
+        xyz = _f32(xyz, 3)
+        self.n_in = len(xyz)
+        p = self._params(voxel_grid)
+        check(self._lib.pcpx_index_create(_vp(xyz), len(xyz), p, device, C.byref(self._h)))
+
+    @staticmethod
+    def _params(voxel_grid):
+        if voxel_grid is None:
+            return None
+        g = np.asarray(voxel_grid, np.float32).reshape(6)
+        p = BuildParams()
+        p.struct_size = C.sizeof(BuildParams)
+        p.flags = _capi.PCPX_BUILD_USE_GRID
+        for a in range(3):
+            p.grid_min[a] = float(g[a])
+            p.grid_max[a] = float(g[3 + a])
+        return C.pointer(p)
+
+    def rebuild(self, xyz, voxel_grid=None):
+        xyz = _f32(xyz, 3)
+        check(self._lib.pcpx_index_rebuild(self._h, _vp(xyz), len(xyz), self._params(voxel_grid)))
+        self.n_in = len(xyz)
+
+    def close(self):
+        if self._h:
+            self._lib.pcpx_index_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- container queries ----
+    def size(self):
+        n = C.c_uint64(0)
+        check(self._lib.pcpx_index_size(self._h, C.byref(n)))
+        return n.value
+
+    def empty(self):
+        return self.size() == 0
+
+    def bbox(self):
+        out = np.zeros(6, np.float32)
+        check(self._lib.pcpx_index_bbox(self._h, out.ctypes.data_as(_capi.f32p)))
+        return out
+
+    # ---- kNN ----
+    def knn_self(self, k, eps=1e-5, want_d2=False):
+        idx = np.empty((self.n_in, k), np.uint32)
+        cnt = np.empty(self.n_in, np.uint32)
+        d2 = np.empty((self.n_in, k), np.float32) if want_d2 else None
+        check(self._lib.pcpx_knn_self(self._h, k, eps, _vp(idx), _vp(cnt), _vp(d2)))
+        return (idx, cnt, d2) if want_d2 else (idx, cnt)
+
+    def knn(self, queries, k, eps=1e-5, want_d2=False):
+        q = _f32(queries, 3)
+        idx = np.empty((len(q), k), np.uint32)
+        cnt = np.empty(len(q), np.uint32)
+        d2 = np.empty((len(q), k), np.float32) if want_d2 else None
+        check(self._lib.pcpx_knn_batch(self._h, _vp(q), len(q), k, eps, _vp(idx), _vp(cnt), _vp(d2)))
+        return (idx, cnt, d2) if want_d2 else (idx, cnt)
+
+    # ---- radius search ----
+    def range_count_self(self, radius):
+        cnt = np.empty(self.n_in, np.uint32)
+        check(self._lib.pcpx_range_count_self(self._h, radius, _vp(cnt)))
+        return cnt
+
+    def range_count(self, queries, radius):
+        q = _f32(queries, 3)
+        cnt = np.empty(len(q), np.uint32)
+        check(self._lib.pcpx_range_count_batch(self._h, _vp(q), len(q), radius, _vp(cnt)))
+        return cnt
+
+    def range_sphere(self, centers, radius):
+        """CSR (offsets, indices) of the points inside each sphere; radius scalar or per-sphere."""
+        q = _f32(centers, 3)
+        radii = None
+        r = 0.0
+        if np.ndim(radius) == 0:
+            r = float(radius)
+        else:
+            radii = _f32(radius).reshape(-1)
+            assert len(radii) == len(q)
+        off = np.zeros(len(q) + 1, np.uint64)
+        st = self._lib.pcpx_range_sphere_batch(self._h, _vp(q), _vp(radii), r, len(q), _vp(off), None, 0)
+        if st == _capi.PCPX_OK:
+            return off, np.empty(0, np.uint32)
+        if st != _capi.PCPX_ERR_CAPACITY:
+            check(st)
+        out = np.empty(int(off[-1]), np.uint32)
+        check(self._lib.pcpx_range_sphere_batch(self._h, _vp(q), _vp(radii), r, len(q), _vp(off), _vp(out), len(out)))
+        return off, out
+
+    def range_aabb(self, boxes):
+        b = _f32(boxes, 6)
+        off = np.zeros(len(b) + 1, np.uint64)
+        st = self._lib.pcpx_range_aabb_batch(self._h, _vp(b), len(b), _vp(off), None, 0)
+        if st == _capi.PCPX_OK:
+            return off, np.empty(0, np.uint32)
+        if st != _capi.PCPX_ERR_CAPACITY:
+            check(st)
+        out = np.empty(int(off[-1]), np.uint32)
+        check(self._lib.pcpx_range_aabb_batch(self._h, _vp(b), len(b), _vp(off), _vp(out), len(out)))
+        return off, out
+
+    # ---- normals ----
+    def normals_knn_self(self, k, eps=1e-5, want_knn=False):
+        nrm = np.empty((self.n_in, 3), np.float32)
+        idx = np.empty((self.n_in, k), np.uint32) if want_knn else None
+        cnt = np.empty(self.n_in, np.uint32) if want_knn else None
+        check(self._lib.pcpx_normals_knn_self(self._h, k, eps, _vp(nrm), _vp(idx), _vp(cnt)))
+        return (nrm, idx, cnt) if want_knn else nrm
+
+    def normals_from_knn(self, nbr, cnt, want_evals=False):
+        nbr = np.ascontiguousarray(nbr, np.uint32)
+        cnt = np.ascontiguousarray(cnt, np.uint32)
+        nq, k = nbr.shape
+        nrm = np.empty((nq, 3), np.float32)
+        ev = np.empty((nq, 3), np.float32) if want_evals else None
+        check(self._lib.pcpx_normals_from_knn(self._h, _vp(nbr), _vp(cnt), nq, k, _vp(nrm), _vp(ev)))
+        return (nrm, ev) if want_evals else nrm
+
+    # ---- device-pointer forms (torch tensors / raw pointers), used by bench.py ----
+    @classmethod
+    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None):
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        self._h = C.c_void_p(None)
+        self.device = device
+        self.n_in = n
+        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid), device,
+                                              C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        return self
+
+    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None):
+        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid)))
+        self.n_in = n
+
+    def knn_self_dev(self, k, eps, d_idx, d_cnt, d_d2=None, first=0, count=_capi.UINT64_MAX):
+        check(self._lib.pcpx_knn_self_dev(self._h, k, eps, first, count, C.c_void_p(d_idx), C.c_void_p(d_cnt),
+                                          C.c_void_p(d_d2) if d_d2 else None))
+
+    def normals_knn_self_dev(self, k, eps, d_normals, d_idx=None, d_cnt=None, first=0, count=_capi.UINT64_MAX):
+        check(self._lib.pcpx_normals_knn_self_dev(self._h, k, eps, first, count, C.c_void_p(d_normals),
+                                                  C.c_void_p(d_idx) if d_idx else None,
+                                                  C.c_void_p(d_cnt) if d_cnt else None))
+
+    def range_count_self_dev(self, radius, d_cnt, first=0, count=_capi.UINT64_MAX):
+        check(self._lib.pcpx_range_count_self_dev(self._h, radius, first, count, C.c_void_p(d_cnt)))
+
+    def synchronize(self):
+        check(self._lib.pcpx_index_synchronize(self._h))
+
+
+class LinkedOctree(Index):
+    """pcp::basic_linked_octree_t over index elements.  node_capacity / max_depth are accepted for
+    signature parity (include/pcp/octree/linked_octree_node.hpp:31-40) but do not shape the GPU
+    structure: only query results are observable."""
+
+    def __init__(self, xyz, node_capacity=32, max_depth=21, voxel_grid=None, device=0):
+        assert node_capacity > 0 and max_depth > 0  # linked_octree_node.hpp:87-88
+        super().__init__(xyz, voxel_grid=voxel_grid, device=device)
+
+    def voxel_grid(self):
+        return self.bbox()
+
+    def nearest_neighbours(self, targets, k, eps=1e-5):
+        return self.knn(targets, k, eps)
+
+    def range_search(self, centers, radius):
+        return self.range_sphere(centers, radius)
+
+
+class LinkedKdTree(Index):
+    """pcp::basic_linked_kdtree_t over index elements (construction_params_t accepted, unused)."""
+
+    def __init__(self, xyz, max_depth=12, compute_max_depth=False, max_elements_per_leaf=64, device=0):
+        super().__init__(xyz, voxel_grid=None, device=device)
+
+    def aabb(self):
+        return self.bbox()
+
+    def nearest_neighbours(self, targets, k, eps=1e-5):
+        return self.knn(targets, k, eps)
+
+    def range_search(self, centers, radius):
+        return self.range_sphere(centers, radius)
+
+
+def estimate_normals(tree, k, eps=1e-5):
+    """pcp::algorithm::estimate_normals with knn_map = tree.nearest_neighbours(point, k): one normal
+    per indexed point (examples/simple_example.cpp:83-99)."""
+    return tree.normals_knn_self(k, eps)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.
+
+1. reference_kats.json -- the known-answer tests of the reference's own test suite for the hot path,
+   transcribed as DATA (inputs + expected outputs), each with the reference file:line it comes from.
+2. stanford_bunny.ply  -- copy of the reference's example DATA file examples/data/stanford_bunny.ply
+   (BASELINE config 1 input; a data file, not source).
+3. bunny_k15.npz       -- oracle outputs on the bunny: (d2,index)-sorted 15-NN rows and PCA normals of
+   512 evenly spaced query points, plus sphere-range counts, produced by oracle/pcp_oracle.cpp after
+   it has been checked against (1) (tests/test_oracle.py does that check on every run).
+
+Run from the repo root in the build container: python tests/golden/make_golden.py
+(step 2 needs /root/reference; steps 1 and 3 do not).
+"""
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def kats():
+    octants8 = [[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5],
+                [-.5, -.5, .5], [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5]]
+    seven = [[-.5, -.5, -.5], [.5, -.5, -.5], [-.5, .5, -.5], [-.5, -.5, .5], [.5, -.5, .5], [.5, .5, .5],
+             [-.5, .5, .5]]
+    four = [[.51, .51, -.51], [.61, .51, -.51], [.41, .31, -.51], [.71, .21, -.51]]
+    sixteen = octants8 + [[-.4, -.3, -.6], [.4, -.3, -.6], [.4, .3, -.6], [-.4, .3, -.6],
+                          [-.4, -.3, .6], [.4, -.3, .6], [.4, .3, .6], [-.4, .3, .6]]
+    grid1 = [-1, -1, -1, 1, 1, 1]
+    return {
+        "_comment": "Known-answer tests transcribed from the reference's Catch2 suite (data only).",
+        "octree_param_sweep": {"node_capacity": [1, 2, 3, 4], "max_depth": [1, 3, 21],
+                               "source": "test/octree/octree_knn.cpp:6-7, test/octree/octree_range_search.cpp:6-7"},
+        "kdtree_param_sweep": {"max_depth_knn": [1, 2, 4, 12], "max_depth_range": [1, 2, 4, 8, 12],
+                               "source": "test/kdtree/knn.cpp:12, test/kdtree/kdtree_range_search.cpp:14"},
+        "knn": [
+            {"name": "k1_each_octant", "source": "test/octree/octree_knn.cpp:13-60, test/kdtree/knn.cpp:14-56",
+             "voxel_grid": grid1, "points": octants8,
+             "queries": [[.51, .51, .51], [-.51, -.51, -.51], [.51, .51, -.51], [-.51, .51, .51]], "k": 1,
+             "expected_counts": [1, 1, 1, 1], "expected_points": [[[.5, .5, .5]], [[-.5, -.5, -.5]], [[.5, .5, -.5]],
+                                                                  [[-.5, .5, .5]]]},
+            {"name": "coincident_only_point", "source": "test/octree/octree_knn.cpp:61-88, test/kdtree/knn.cpp:58-83",
+             "voxel_grid": grid1, "points": [[-.5, -.5, -.5]], "queries": [[-.5, -.5, -.5]], "k": 1,
+             "expected_counts": [0], "expected_points": [[]]},
+            {"name": "coincident_plus_one", "source": "test/octree/octree_knn.cpp:89-121, test/kdtree/knn.cpp:84-116",
+             "voxel_grid": grid1, "points": [[-.5, -.5, -.5], [-1., -1., -1.]], "queries": [[-.5, -.5, -.5]], "k": 2,
+             "expected_counts": [1], "expected_points": [[[-1., -1., -1.]]]},
+            {"name": "ordered_4nn", "source": "test/octree/octree_knn.cpp:123-169, test/kdtree/knn.cpp:118-160",
+             "voxel_grid": grid1, "points": seven + four, "queries": [[.5, .5, -.5]], "k": 4,
+             "expected_counts": [4], "expected_points": [four]},
+            {"name": "ordered_3nn", "source": "test/octree/octree_knn.cpp:170-182, test/kdtree/knn.cpp:161-175",
+             "voxel_grid": grid1, "points": seven + four, "queries": [[.5, .5, -.5]], "k": 3,
+             "expected_counts": [3], "expected_points": [four[:3]]},
+        ],
+        "planted_knn": {"source": "test/octree/octree_knn.cpp:184-254, test/kdtree/knn.cpp:177-245",
+                        "voxel_grid": [-2, -2, -2, 2, 2, 2], "background_range": [-0.95, 0.95],
+                        "near_range": [-0.99, -0.96], "far_range": [0.96, 0.99], "size_range": [1000, 100000],
+                        "k_range": [1, 10], "reference_point": [-1., 1., 1.]},
+        "range": {
+            "source": "test/octree/octree_range_search.cpp:13-118, test/kdtree/kdtree_range_search.cpp:16-121",
+            "voxel_grid": grid1, "points": sixteen,
+            "spheres": [{"center": [0, 0, 0], "radius": 0.1, "expected_points": []},
+                        {"center": [.9, .9, .9], "radius": 1.0, "expected_points": [[.5, .5, .5], [.4, .3, .6]]}],
+            "aabbs": [{"min": [1.05, 1.05, 1.05], "max": [2, 2, 2], "expected_points": []},
+                      {"min": [-2, -2, -2], "max": [0, 0, 0], "expected_points": [[-.5, -.5, -.5], [-.4, -.3, -.6]]},
+                      {"min": [.5, .5, .5], "max": [.5, .5, .5], "expected_points": [[.5, .5, .5]]}]},
+        "octree_insertion": {"source": "test/octree/octree_insertion.cpp:21-41", "voxel_grid": grid1,
+                             "inside": octants8,
+                             "outside": [[-2, 0, 0], [0, -2, 0], [0, 0, -2], [2, 0, 0], [0, 2, 0], [0, 0, 2]],
+                             "expected_size": 8},
+        "normal": {"source": "test/common/normal_estimation.cpp:11-38, test/common/plane3d.cpp:33-69",
+                   "points": [[0, 0, 0], [-2, 0, 0], [2, 0, 0], [0, -2, 0], [0, 2, 0], [0, 0, -1], [0, 0, 1]],
+                   "expected_normal_up_to_sign": [0, 0, 1], "component_tolerance": 1e-5},
+        "eps": 1e-5,
+    }
+
+
+def main():
+    with open(os.path.join(HERE, "reference_kats.json"), "w") as f:
+        json.dump(kats(), f, indent=1)
+    src = "/root/reference/examples/data/stanford_bunny.ply"
+    dst = os.path.join(HERE, "stanford_bunny.ply")
+    if os.path.exists(src):
+        shutil.copyfile(src, dst)
+
+    import importlib
+    pkg = importlib.import_module("point-cloud-processing_amd")
+    from oracle import pcp_oracle as O
+    pts, _ = pkg.ply.read_ply(dst)
+    assert pts.shape == (35947, 3)
+    qsel = np.linspace(0, len(pts) - 1, 512).astype(np.int64)
+    idx, cnt, d2 = O.knn_bruteforce(pts, pts[qsel], 15, eps=1e-5, nthreads=8, want_d2=True)
+    nrm, ev = O.normals_from_knn(pts, idx, cnt, want_evals=True)
+    rc = O.range_count_bruteforce(pts, pts[qsel], 0.01, nthreads=8)
+    # the restated octree/kd-tree must agree with brute force here (also asserted in tests/test_oracle.py)
+    oi, oc = O.Octree(pts).knn(pts[qsel], 15)
+    ki, kc = O.KdTree(pts, compute_max_depth=True).knn(pts[qsel], 15)
+    assert (oi == idx).all() and (ki == idx).all()
+    np.savez_compressed(os.path.join(HERE, "bunny_k15.npz"), query_index=qsel, knn_idx=idx, knn_cnt=cnt, knn_d2=d2,
+                        normals=nrm, evals=ev, range_count_r001=rc)
+    print("wrote fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()

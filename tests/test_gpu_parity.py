@@ -1,0 +1,354 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI of
+libpcpx.so; the oracle (oracle/pcp_oracle.cpp) is only the checker.
+
+Bars: kNN rows are bit-exact against the (d2, index)-sorted brute-force oracle -- indices, counts and
+float32 squared distances; range results are exact sets; normals are bit-comparable with the oracle's
+Eigen restatement and within 1e-4 cosine (the tolerance BASELINE.json's north_star states)."""
+import numpy as np
+import pytest
+
+from conftest import knn_rows_equivalent, points_match, same_point_set
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-4  # north_star: "normals within 1e-4 cosine of reference"
+
+
+def _cos_err(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    num = np.abs((a * b).sum(1))
+    den = np.sqrt((a * a).sum(1) * (b * b).sum(1))
+    return 1.0 - num / np.maximum(den, 1e-300)
+
+
+def _check_knn_exact(pkg, oracle, pts, queries, k, eps=1e-5, self_query=False, ix=None):
+    ix = ix or pkg.Index(pts)
+    if self_query:
+        gi, gc, gd = ix.knn_self(k, eps, want_d2=True)
+        queries = pts
+    else:
+        gi, gc, gd = ix.knn(queries, k, eps, want_d2=True)
+    oi, oc, od = oracle.knn_bruteforce(pts, queries, k, eps, nthreads=8, want_d2=True)
+    assert np.array_equal(gc, oc)
+    assert np.array_equal(gi, oi)
+    valid = np.arange(k)[None, :] < oc[:, None]
+    assert np.array_equal(gd[valid], od[valid])
+    return ix
+
+
+# ---- the reference's own known-answer tests, through the GPU path ------------------------------------
+def test_reference_knn_kats(pkg, kats):
+    for case in kats["knn"]:
+        pts = np.array(case["points"], np.float32)
+        for tree in (pkg.LinkedOctree(pts, voxel_grid=case["voxel_grid"]), pkg.LinkedKdTree(pts)):
+            idx, cnt = tree.nearest_neighbours(case["queries"], case["k"], eps=kats["eps"])
+            assert list(cnt) == case["expected_counts"], case["name"]
+            for q, exp in enumerate(case["expected_points"]):
+                assert points_match(pts[idx[q, : cnt[q]]], exp), case["name"]
+                assert np.all(idx[q, cnt[q]:] == 0xFFFFFFFF)
+
+
+def test_reference_range_kats(pkg, kats):
+    r = kats["range"]
+    pts = np.array(r["points"], np.float32)
+    for tree in (pkg.LinkedOctree(pts, voxel_grid=r["voxel_grid"]), pkg.LinkedKdTree(pts)):
+        centers = [s["center"] for s in r["spheres"]]
+        radii = np.array([s["radius"] for s in r["spheres"]], np.float32)
+        off, idx = tree.range_sphere(centers, radii)
+        for i, s in enumerate(r["spheres"]):
+            assert same_point_set(pts[idx[off[i]:off[i + 1]]], s["expected_points"])
+            o1, i1 = tree.range_search([s["center"]], s["radius"])
+            assert same_point_set(pts[i1], s["expected_points"])
+        boxes = [b["min"] + b["max"] for b in r["aabbs"]]
+        off, idx = tree.range_aabb(boxes)
+        for i, b in enumerate(r["aabbs"]):
+            assert same_point_set(pts[idx[off[i]:off[i + 1]]], b["expected_points"])
+
+
+def test_reference_insertion_kat(pkg, kats):
+    c = kats["octree_insertion"]
+    pts = np.array(c["inside"] + c["outside"], np.float32)
+    t = pkg.LinkedOctree(pts, voxel_grid=c["voxel_grid"])
+    assert t.size() == c["expected_size"]
+    assert np.array_equal(t.voxel_grid(), np.array(c["voxel_grid"], np.float32))
+    # dropped points are never returned, and their own rows are empty
+    idx, cnt = t.knn_self(3)
+    assert np.all(cnt[len(c["inside"]):] == 0) and np.all(cnt[: len(c["inside"])] == 3)
+    assert idx[: len(c["inside"])].max() < len(c["inside"])
+
+
+def test_reference_normal_kat(pkg, kats):
+    c = kats["normal"]
+    n = pkg.estimate_normal(c["points"])
+    exp = np.array(c["expected_normal_up_to_sign"], np.float32)
+    tol = c["component_tolerance"]
+    assert np.all(np.abs(n - exp) < tol) or np.all(np.abs(n + exp) < tol)
+    assert abs(float(np.sqrt((n.astype(np.float64) ** 2).sum())) - 1.0) < tol
+
+
+def test_planted_neighbours(pkg, kats):
+    p = kats["planted_knn"]
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        n = int(rng.integers(*p["size_range"]))
+        k = int(rng.integers(p["k_range"][0], p["k_range"][1] + 1))
+        bg = rng.uniform(*p["background_range"], (n, 3)).astype(np.float32)
+        planted = np.stack([rng.uniform(*p["near_range"], k), rng.uniform(*p["far_range"], k),
+                            rng.uniform(*p["far_range"], k)], axis=1).astype(np.float32)
+        pts = np.concatenate([bg, planted])
+        t = pkg.LinkedOctree(pts, voxel_grid=p["voxel_grid"])
+        assert t.size() == n + k
+        idx, cnt = t.nearest_neighbours([p["reference_point"]], k)
+        assert cnt[0] == k and set(idx[0].tolist()) == set(range(n, n + k))
+
+
+# ---- golden fixtures ----------------------------------------------------------------------------------
+def test_bunny_golden(pkg, bunny, bunny_golden):
+    g = bunny_golden
+    qi = g["query_index"]
+    ix = pkg.LinkedOctree(bunny)
+    assert ix.size() == len(bunny)
+    nrm, idx, cnt = ix.normals_knn_self(15, want_knn=True)
+    assert np.array_equal(idx[qi], g["knn_idx"]) and np.array_equal(cnt[qi], g["knn_cnt"])
+    _, _, d2 = ix.knn_self(15, want_d2=True)
+    assert np.array_equal(d2[qi], g["knn_d2"])
+    assert _cos_err(nrm[qi], g["normals"]).max() <= COS_TOL
+    assert np.array_equal(nrm[qi], g["normals"])  # same arithmetic, same order: bit-identical in practice
+    assert np.array_equal(ix.range_count_self(0.01)[qi], g["range_count_r001"])
+    assert np.array_equal(ix.range_count(bunny[qi], 0.01), g["range_count_r001"])
+
+
+def test_bunny_full_against_oracle_trees(pkg, oracle, bunny):
+    """BASELINE config 1: every bunny point, k=15, against the restated octree and kd-tree (tie-aware)."""
+    ix = pkg.Index(bunny)
+    gi, gc = ix.knn_self(15)
+    for tree in (oracle.Octree(bunny), oracle.KdTree(bunny, compute_max_depth=True)):
+        oi, oc = tree.knn(bunny, 15, nthreads=8)
+        ok, why = knn_rows_equivalent(bunny, bunny, gi, gc, oi, oc)
+        assert ok, why
+    on = oracle.normals_from_knn(bunny, gi, gc, nthreads=8)
+    gn = ix.normals_knn_self(15)
+    assert _cos_err(gn, on).max() <= COS_TOL
+
+
+# ---- seeded random clouds against the brute-force oracle --------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 257, 1000, 4099])
+@pytest.mark.parametrize("k", [1, 15, 16, 17, 32])
+def test_knn_self_small(pkg, oracle, n, k):
+    rng = np.random.default_rng(1000 * n + k)
+    pts = rng.random((n, 3), dtype=np.float32)
+    _check_knn_exact(pkg, oracle, pts, None, k, self_query=True)
+
+
+@pytest.mark.parametrize("n,nq,k", [(1, 5, 3), (50, 1, 15), (1000, 777, 15), (20000, 3000, 10), (20000, 130, 32)])
+def test_knn_batch_arbitrary_queries(pkg, oracle, n, nq, k):
+    rng = np.random.default_rng(n + nq + k)
+    pts = rng.random((n, 3), dtype=np.float32)
+    q = (rng.random((nq, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)  # some outside the cloud's box
+    _check_knn_exact(pkg, oracle, pts, q, k)
+
+
+def test_knn_empty_and_k0(pkg):
+    ix = pkg.Index(np.empty((0, 3), np.float32))
+    assert ix.size() == 0 and ix.empty()
+    idx, cnt = ix.knn([[0, 0, 0], [1, 1, 1]], 4)
+    assert np.all(cnt == 0) and np.all(idx == 0xFFFFFFFF)
+    ix = pkg.Index(np.random.default_rng(0).random((100, 3), dtype=np.float32))
+    idx, cnt = ix.knn([[0.5, 0.5, 0.5]], 0)
+    assert idx.shape == (1, 0) and cnt[0] == 0
+    with pytest.raises(pkg.PcpxError):
+        ix.knn([[0.5, 0.5, 0.5]], 33)  # k > 32 not built yet: must fail loudly, not silently truncate
+
+
+def test_knn_coincident_points_and_eps(pkg, oracle):
+    """eps-box exclusion removes EVERY point inside the box, not 'the query index'
+    (include/pcp/octree/linked_octree_node.hpp:540)."""
+    rng = np.random.default_rng(3)
+    base = rng.random((500, 3), dtype=np.float32)
+    dup = base[:100] + np.float32(3e-6)  # inside the 1e-5 box of their twins
+    pts = np.concatenate([base, dup, base[:50]])  # and exact duplicates
+    _check_knn_exact(pkg, oracle, pts, None, 8, self_query=True)
+    _check_knn_exact(pkg, oracle, pts, None, 8, eps=1e-7, self_query=True)  # duplicates at d2 == 0 stay excluded
+    _check_knn_exact(pkg, oracle, pts, None, 8, eps=0.0, self_query=True)   # nothing excluded: self is neighbour 0
+    _check_knn_exact(pkg, oracle, pts, base[:64] + np.float32(1e-3), 8, eps=2e-3)
+
+
+def test_knn_lattice_ties(pkg, oracle):
+    """A lattice makes exact distance ties the norm; (d2, index) ordering must still match exactly, and
+    the reference trees must agree up to ties."""
+    g = np.arange(12, dtype=np.float32) / np.float32(8)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(0)
+    pts = pts[rng.permutation(len(pts))]
+    ix = _check_knn_exact(pkg, oracle, pts, None, 15, self_query=True)
+    gi, gc = ix.knn_self(15)
+    oi, oc = oracle.Octree(pts).knn(pts, 15, nthreads=8)
+    ok, why = knn_rows_equivalent(pts, pts, gi, gc, oi, oc)
+    assert ok, why
+
+
+def test_knn_clustered_and_degenerate(pkg, oracle):
+    c = pkg.synthetic.clustered_cloud(30000, seed=44)
+    _check_knn_exact(pkg, oracle, c, c[::37], 15)
+    rng = np.random.default_rng(9)
+    plane = rng.random((3000, 3), dtype=np.float32)
+    plane[:, 2] = 0.25  # zero extent on one axis
+    _check_knn_exact(pkg, oracle, plane, None, 15, self_query=True)
+    line = np.zeros((2000, 3), np.float32)
+    line[:, 0] = rng.random(2000, dtype=np.float32) * 100 - 50
+    _check_knn_exact(pkg, oracle, line, None, 5, self_query=True)
+    big = (rng.random((3000, 3), dtype=np.float32) * 200 - 100).astype(np.float32)  # benchmark range U(-100,100)
+    _check_knn_exact(pkg, oracle, big, None, 10, self_query=True)
+
+
+def test_rebuild_reuses_handle(pkg, oracle):
+    rng = np.random.default_rng(21)
+    a = rng.random((5000, 3), dtype=np.float32)
+    ix = pkg.Index(a)
+    _check_knn_exact(pkg, oracle, a, None, 15, self_query=True, ix=ix)
+    b = pkg.synthetic.jitter(a, seed=46)
+    ix.rebuild(b)
+    _check_knn_exact(pkg, oracle, b, None, 15, self_query=True, ix=ix)
+    c = rng.random((9000, 3), dtype=np.float32)  # grows past the first capacity
+    ix.rebuild(c)
+    _check_knn_exact(pkg, oracle, c, None, 15, self_query=True, ix=ix)
+
+
+# ---- radius search -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,r", [(1, 0.5), (100, 0.3), (5000, 0.05), (50000, 0.03), (5000, 1.0)])
+def test_range_count_and_lists(pkg, oracle, n, r):
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3), dtype=np.float32)
+    ix = pkg.Index(pts)
+    exp = oracle.range_count_bruteforce(pts, pts, r, nthreads=8)
+    assert np.array_equal(ix.range_count_self(r), exp)
+    q = (rng.random((300, 3), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)
+    expq = oracle.range_count_bruteforce(pts, q, r, nthreads=8)
+    assert np.array_equal(ix.range_count(q, r), expq)
+    off, idx = ix.range_sphere(q, r)
+    assert np.array_equal(np.diff(off).astype(np.uint32), expq)
+    tree = oracle.Octree(pts)
+    for i in range(0, 300, 29):
+        assert sorted(idx[off[i]:off[i + 1]].tolist()) == sorted(tree.range_sphere(q[i], r).tolist())
+
+
+def test_range_aabb_against_oracle(pkg, oracle):
+    rng = np.random.default_rng(4)
+    pts = rng.random((20000, 3), dtype=np.float32)
+    lo = rng.random((50, 3), dtype=np.float32) * 0.9
+    hi = lo + rng.random((50, 3), dtype=np.float32) * 0.2
+    ix = pkg.Index(pts)
+    off, idx = ix.range_aabb(np.concatenate([lo, hi], 1))
+    tree = oracle.KdTree(pts)
+    for i in range(50):
+        assert sorted(idx[off[i]:off[i + 1]].tolist()) == sorted(tree.range_aabb(lo[i], hi[i]).tolist())
+
+
+# ---- normals -------------------------------------------------------------------------------------------
+def test_normals_match_oracle_bitwise_on_random_cloud(pkg, oracle):
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(-10, 10, (20000, 3)).astype(np.float32)
+    ix = pkg.Index(pts)
+    nrm, idx, cnt = ix.normals_knn_self(15, want_knn=True)
+    on, oev = oracle.normals_from_knn(pts, idx, cnt, nthreads=8, want_evals=True)
+    assert _cos_err(nrm, on).max() <= COS_TOL
+    assert np.mean(np.all(nrm == on, axis=1)) > 0.999
+    n2, ev = ix.normals_from_knn(idx, cnt, want_evals=True)
+    assert np.array_equal(n2, nrm)
+    assert np.allclose(ev, oev, rtol=1e-5, atol=1e-6)
+    assert np.all(np.abs(np.sqrt((nrm.astype(np.float64) ** 2).sum(1)) - 1) < 1e-5)
+
+
+def test_normals_of_a_plane_and_short_neighbourhoods(pkg):
+    rng = np.random.default_rng(2)
+    pts = rng.random((4000, 3), dtype=np.float32)
+    pts[:, 2] = 0.5 + 0.25 * pts[:, 0]  # plane z = 0.5 + x/4, normal ~ (-0.25, 0, 1)/|.|
+    nrm = pkg.Index(pts).normals_knn_self(15)
+    exp = np.array([-0.25, 0, 1.0]) / np.sqrt(1 + 0.0625)
+    assert (1 - np.abs(nrm.astype(np.float64) @ exp)).max() < 1e-4
+    few = rng.random((3, 3), dtype=np.float32)  # k > n - 1: rows are short, normals still finite
+    n3, idx, cnt = pkg.Index(few).normals_knn_self(15, want_knn=True)
+    assert list(cnt) == [2, 2, 2] and np.isfinite(n3).all()
+
+
+# ---- BASELINE-size runs: size-independent properties + sampled oracle checks ------------------------
+def _properties(pts, idx, cnt, d2, k):
+    assert np.all(cnt == k)
+    assert np.all(np.diff(d2.astype(np.float64), axis=1) >= 0)  # ascending
+    assert not np.any(idx == np.arange(len(pts), dtype=np.uint32)[:, None])  # the query itself is excluded
+    assert idx.max() < len(pts)
+    # d2 really is the reference's float expression for the returned index
+    sel = np.random.default_rng(0).integers(0, len(pts), 2000)
+    for j in (0, k - 1):
+        d = pts[idx[sel, j]] - pts[sel]
+        ref = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert np.array_equal(ref.astype(np.float32), d2[sel, j])
+
+
+def test_config2_uniform_1m(pkg, oracle):
+    """BASELINE configs[1]: 1 M uniform points, k=15 kNN + normals."""
+    pts = pkg.synthetic.uniform_cloud(1_000_000, 42)
+    ix = pkg.Index(pts)
+    nrm, idx, cnt = ix.normals_knn_self(15, want_knn=True)
+    _, _, d2 = ix.knn_self(15, want_d2=True)
+    _properties(pts, idx, cnt, d2, 15)
+    sel = np.random.default_rng(1).integers(0, len(pts), 3000)
+    tree = oracle.Octree(pts)  # reference defaults: capacity 32, depth 21, auto bbox
+    oi, oc = tree.knn(pts[sel], 15, nthreads=8)
+    ok, why = knn_rows_equivalent(pts, pts[sel], idx[sel], cnt[sel], oi, oc)
+    assert ok, why
+    on, oev = oracle.normals_from_knn(pts, idx[sel], cnt[sel], nthreads=8, want_evals=True)
+    err = _cos_err(nrm[sel], on)
+    assert err.max() <= COS_TOL
+    # symmetric check of a neighbour relation through range counts: |ball(r_k)| >= k + 1
+    rk = np.sqrt(d2[sel, -1].astype(np.float64)).astype(np.float32)
+    off, _ = ix.range_sphere(pts[sel[:200]], rk[:200] * np.float32(1.0001))
+    assert np.all(np.diff(off) >= 16)
+
+
+def test_config3_range_10m_and_knn_10m_properties(pkg, oracle):
+    """BASELINE configs[2] (10 M points, r = 0.01 counts) and the 10 M kNN target config: properties at
+    full size plus brute-force checks on sampled queries."""
+    pts = pkg.synthetic.uniform_cloud(10_000_000, 43)
+    ix = pkg.Index(pts)
+    assert ix.size() == len(pts)
+    cnt = ix.range_count_self(0.01)
+    assert cnt.min() >= 1  # the query point itself is inside its sphere
+    assert abs(cnt.mean() - 1e7 * 4 / 3 * np.pi * 1e-6) < 2.5  # E ~ 41.9 minus boundary effects
+    sel = np.random.default_rng(2).integers(0, len(pts), 48)
+    assert np.array_equal(cnt[sel], oracle.range_count_bruteforce(pts, pts[sel], 0.01, nthreads=8))
+    idx, kc, d2 = ix.knn_self(15, want_d2=True)
+    _properties(pts, idx, kc, d2, 15)
+    oi, oc, od = oracle.knn_bruteforce(pts, pts[sel], 15, nthreads=8, want_d2=True)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(d2[sel], od)
+
+
+def test_sorted_shards_cover_the_cloud(pkg):
+    """The per-rank query shards of the multi-GPU path (pcpx_shard_range + *_dev sorted slices): the union
+    of the shards' rows equals the single-call result."""
+    import torch
+    pts = pkg.synthetic.clustered_cloud(200_000, seed=44)
+    dev = torch.device("cuda:0")
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), len(pts))
+    k = 15
+    full_idx = torch.full((len(pts), k), -1, dtype=torch.int32, device=dev)
+    full_cnt = torch.zeros(len(pts), dtype=torch.int32, device=dev)
+    full_n = torch.zeros((len(pts), 3), dtype=torch.float32, device=dev)
+    ix.normals_knn_self_dev(k, 1e-5, full_n.data_ptr(), full_idx.data_ptr(), full_cnt.data_ptr())
+    ix.synchronize()
+    sh_idx = torch.full_like(full_idx, -1)
+    sh_cnt = torch.zeros_like(full_cnt)
+    sh_n = torch.zeros_like(full_n)
+    covered = 0
+    for rank in range(8):
+        first, count = pkg.shard_range(ix.size(), rank, 8)
+        assert first % 64 == 0
+        ix.normals_knn_self_dev(k, 1e-5, sh_n.data_ptr(), sh_idx.data_ptr(), sh_cnt.data_ptr(), first, count)
+        covered += count
+    ix.synchronize()
+    assert covered == len(pts)
+    assert torch.equal(full_idx, sh_idx) and torch.equal(full_cnt, sh_cnt) and torch.equal(full_n, sh_n)
+    host_idx, host_cnt = pkg.Index(pts).knn_self(k)
+    assert np.array_equal(full_idx.cpu().numpy().view(np.uint32), host_idx)

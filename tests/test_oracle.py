@@ -1,0 +1,145 @@
+"""CPU tests: the oracle against the reference's own known-answer tests (tests/golden/reference_kats.json,
+transcribed from the reference's Catch2 suite) and against the committed bunny goldens."""
+import numpy as np
+import pytest
+
+from conftest import knn_rows_equivalent, points_match, same_point_set
+
+
+def _octree_sweep(kats):
+    s = kats["octree_param_sweep"]
+    return [(c, d) for c in s["node_capacity"] for d in s["max_depth"]]
+
+
+def test_octree_knn_kats(oracle, kats):
+    for case in kats["knn"]:
+        pts = np.array(case["points"], np.float32)
+        for cap, depth in _octree_sweep(kats):
+            t = oracle.Octree(pts, cap, depth, case["voxel_grid"])
+            assert t.size() == len(pts)
+            idx, cnt = t.knn(case["queries"], case["k"], eps=kats["eps"])
+            assert list(cnt) == case["expected_counts"], (case["name"], cap, depth)
+            for q, exp in enumerate(case["expected_points"]):
+                assert points_match(pts[idx[q, : cnt[q]]], exp), (case["name"], cap, depth)
+
+
+def test_kdtree_knn_kats(oracle, kats):
+    for case in kats["knn"]:
+        pts = np.array(case["points"], np.float32)
+        for depth in kats["kdtree_param_sweep"]["max_depth_knn"]:
+            t = oracle.KdTree(pts, max_depth=depth)
+            idx, cnt = t.knn(case["queries"], case["k"], eps=kats["eps"])
+            assert list(cnt) == case["expected_counts"], (case["name"], depth)
+            for q, exp in enumerate(case["expected_points"]):
+                assert points_match(pts[idx[q, : cnt[q]]], exp), (case["name"], depth)
+
+
+def test_bruteforce_knn_kats(oracle, kats):
+    for case in kats["knn"]:
+        pts = np.array(case["points"], np.float32)
+        idx, cnt = oracle.knn_bruteforce(pts, case["queries"], case["k"], eps=kats["eps"])
+        assert list(cnt) == case["expected_counts"]
+        for q, exp in enumerate(case["expected_points"]):
+            assert points_match(pts[idx[q, : cnt[q]]], exp)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_planted_neighbours(oracle, kats, seed):
+    """test/octree/octree_knn.cpp:184-254 / test/kdtree/knn.cpp:177-245 with a fixed seed."""
+    p = kats["planted_knn"]
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(p["size_range"][0], 20000))
+    k = int(rng.integers(p["k_range"][0], p["k_range"][1] + 1))
+    bg = rng.uniform(p["background_range"][0], p["background_range"][1], (n, 3)).astype(np.float32)
+    planted = np.stack([rng.uniform(*p["near_range"], k), rng.uniform(*p["far_range"], k),
+                        rng.uniform(*p["far_range"], k)], axis=1).astype(np.float32)
+    pts = np.concatenate([bg, planted])
+    ref = [p["reference_point"]]
+    for tree in (oracle.Octree(pts, 4, 21, p["voxel_grid"]), oracle.KdTree(pts, max_depth=12)):
+        idx, cnt = tree.knn(ref, k)
+        assert cnt[0] == k
+        assert set(idx[0].tolist()) == set(range(n, n + k))
+    idx, cnt = oracle.knn_bruteforce(pts, ref, k)
+    assert set(idx[0].tolist()) == set(range(n, n + k))
+
+
+def test_range_kats(oracle, kats):
+    r = kats["range"]
+    pts = np.array(r["points"], np.float32)
+    trees = [oracle.Octree(pts, c, d, r["voxel_grid"]) for c, d in _octree_sweep(kats)]
+    trees += [oracle.KdTree(pts, max_depth=d) for d in kats["kdtree_param_sweep"]["max_depth_range"]]
+    for t in trees:
+        for s in r["spheres"]:
+            got = t.range_sphere(s["center"], s["radius"])
+            assert same_point_set(pts[got], s["expected_points"])
+        for b in r["aabbs"]:
+            got = t.range_aabb(b["min"], b["max"])
+            assert same_point_set(pts[got], b["expected_points"])
+
+
+def test_octree_drops_points_outside_grid(oracle, kats):
+    c = kats["octree_insertion"]
+    pts = np.array(c["inside"] + c["outside"], np.float32)
+    for cap, depth in _octree_sweep(kats):
+        assert oracle.Octree(pts, cap, depth, c["voxel_grid"]).size() == c["expected_size"]
+
+
+def test_normal_kat(oracle, kats):
+    c = kats["normal"]
+    n = oracle.estimate_normal(c["points"])
+    exp = np.array(c["expected_normal_up_to_sign"], np.float32)
+    tol = c["component_tolerance"]
+    assert np.all(np.abs(n - exp) < tol) or np.all(np.abs(n + exp) < tol)
+    assert abs(float(np.sqrt((n.astype(np.float64) ** 2).sum())) - 1.0) < tol
+
+
+def test_bbox_matches_numpy(oracle):
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(1000, 3)).astype(np.float32)
+    b = oracle.bbox(x)
+    assert np.array_equal(b[:3], x.min(0)) and np.array_equal(b[3:], x.max(0))
+
+
+def test_trees_agree_with_bruteforce_on_bunny(oracle, bunny, bunny_golden):
+    g = bunny_golden
+    q = bunny[g["query_index"]]
+    idx, cnt, d2 = oracle.knn_bruteforce(bunny, q, 15, nthreads=8, want_d2=True)
+    assert np.array_equal(idx, g["knn_idx"]) and np.array_equal(cnt, g["knn_cnt"])
+    assert np.array_equal(d2, g["knn_d2"])
+    for tree in (oracle.Octree(bunny), oracle.KdTree(bunny, compute_max_depth=True)):
+        ti, tc = tree.knn(q, 15, nthreads=8)
+        ok, why = knn_rows_equivalent(bunny, q, ti, tc, idx, cnt)
+        assert ok, why
+    assert np.array_equal(oracle.Octree(bunny).range_count(q, 0.01, nthreads=8), g["range_count_r001"])
+    assert np.array_equal(oracle.range_count_bruteforce(bunny, q, 0.01, nthreads=8), g["range_count_r001"])
+    nrm = oracle.normals_from_knn(bunny, idx, cnt)
+    assert np.array_equal(nrm, g["normals"])
+
+
+def test_oracle_normals_close_to_float64_eigh(oracle, bunny, bunny_golden):
+    """The float32 Eigen restatement against numpy's float64 symmetric solver: |cos| within 1e-4 wherever
+    the smallest eigenvalue is well separated (relative gap >= 1e-3)."""
+    g = bunny_golden
+    bad = 0
+    for r in range(len(g["query_index"])):
+        nb = bunny[g["knn_idx"][r, : g["knn_cnt"][r]]].astype(np.float64)
+        c = nb - nb.mean(0)
+        w, v = np.linalg.eigh(c.T @ c)
+        if (w[1] - w[0]) / max(w[2], 1e-300) < 1e-3:
+            continue
+        cosang = abs(float(v[:, 0] @ g["normals"][r].astype(np.float64)))
+        bad += (1.0 - cosang) > 1e-4
+    assert bad == 0
+
+
+def test_estimate_normals_driver_consistent(oracle):
+    """test/algorithm/estimate_normals.cpp:13-66: estimate_normals == per-point estimate_normal(knn(p))."""
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-10, 10, (1000, 3)).astype(np.float32)
+    t = oracle.Octree(pts, voxel_grid=[-10, -10, -10, 10, 10, 10])
+    nrm, idx = t.estimate_normals(5, want_idx=True)
+    ki, kc = t.knn(pts, 5)
+    assert np.array_equal(ki, idx)
+    for i in range(0, 1000, 37):
+        e = oracle.estimate_normal(pts[ki[i, : kc[i]]])
+        assert np.all(np.abs(nrm[i] - e) < 1e-5) or np.all(np.abs(nrm[i] + e) < 1e-5)
