@@ -150,6 +150,24 @@ int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_fi
 /* Block until everything enqueued on the index's stream has finished. */
 int pcpx_index_synchronize(pcpx_index* idx);
 
+/* ---- measurement --------------------------------------------------------------------------- */
+/* Per-kernel device time, measured with hipEvents recorded on the index's stream around every kernel
+ * family launched between pcpx_profile_begin and pcpx_profile_end (which synchronises the stream). */
+typedef enum pcpx_kernel_family {
+    PCPX_K_BUILD = 0,   /* bbox + Morton codes + sort + leaves + boxes (one interval per build) */
+    PCPX_K_KNN = 1,     /* k_knn */
+    PCPX_K_NORMALS = 2, /* k_normals */
+    PCPX_K_RANGE = 3,   /* k_range / k_range_aabb */
+    PCPX_K_QUERY_PREP = 4, /* query Morton sort + seeds of *_batch calls */
+    PCPX_K_FAMILIES = 5
+} pcpx_kernel_family;
+typedef struct pcpx_profile {
+    uint32_t launches[PCPX_K_FAMILIES];
+    float total_ms[PCPX_K_FAMILIES];
+} pcpx_profile;
+int pcpx_profile_begin(pcpx_index* idx);
+int pcpx_profile_end(pcpx_index* idx, pcpx_profile* out);
+
 #ifdef __cplusplus
 }
 #endif

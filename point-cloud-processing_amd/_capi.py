@@ -25,6 +25,13 @@ class BuildParams(C.Structure):
                 ("grid_max", C.c_float * 3)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint32 * 5), ("total_ms", C.c_float * 5)]
+
+
+K_BUILD, K_KNN, K_NORMALS, K_RANGE, K_QUERY_PREP = range(5)
+
+
 class PcpxError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("pcpx status %d: %s" % (status, message))
@@ -67,6 +74,8 @@ SIGNATURES = {
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),
     "pcpx_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
     "pcpx_index_synchronize": (C.c_int, [C.c_void_p]),
+    "pcpx_profile_begin": (C.c_int, [C.c_void_p]),
+    "pcpx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
 }
 
 _lib = None

@@ -96,6 +96,10 @@ void free_index(Index* ix)
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    for (auto& iv : ix->intervals) {
+        (void)hipEventDestroy(iv.a);
+        (void)hipEventDestroy(iv.b);
+    }
     (void)hipFree(ix->d_xyz);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(ix->d_codes[b]);
@@ -521,7 +525,7 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     u64 n = ix->n;
     u64 first = sorted_first > n ? n : sorted_first;
     u64 count = (sorted_count > n - first) ? n - first : sorted_count;
-    return launch_normals(ix->d_xyz, d_idx, d_cnt, ix->perm(), first, count, k, d_out_normals, nullptr, ix->stream);
+    return launch_normals(*ix, d_idx, d_cnt, ix->perm(), first, count, k, d_out_normals, nullptr);
 }
 
 int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
@@ -574,8 +578,8 @@ int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t
     if (opt_out_evals && (st = de.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(di.p, nbr_idx, nq * k * sizeof(u32), hipMemcpyHostToDevice, ix->stream));
     PCPX_HIP(hipMemcpyAsync(dc.p, count, nq * sizeof(u32), hipMemcpyHostToDevice, ix->stream));
-    st = launch_normals(ix->d_xyz, di.as<u32>(), dc.as<u32>(), nullptr, 0, nq, k, dn.as<float>(),
-                        opt_out_evals ? de.as<float>() : nullptr, ix->stream);
+    st = launch_normals(*ix, di.as<u32>(), dc.as<u32>(), nullptr, 0, nq, k, dn.as<float>(),
+                        opt_out_evals ? de.as<float>() : nullptr);
     if (st != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, nq * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     if (opt_out_evals) PCPX_HIP(hipMemcpyAsync(opt_out_evals, de.p, nq * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
@@ -594,6 +598,42 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
     if (m > 0) PCPX_HIP(hipMemcpy(dp.p, xyz, m * 3 * sizeof(float), hipMemcpyHostToDevice));
     if ((st = launch_normal_single(dp.as<float>(), m, dn.as<float>(), nullptr)) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpy(out_normal, dn.p, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PCPX_OK;
+}
+
+int pcpx_profile_begin(pcpx_index* h)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    for (auto& iv : ix->intervals) {
+        (void)hipEventDestroy(iv.a);
+        (void)hipEventDestroy(iv.b);
+    }
+    ix->intervals.clear();
+    ix->profiling = true;
+    return PCPX_OK;
+}
+
+int pcpx_profile_end(pcpx_index* h, pcpx_profile* out)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out) return PCPX_ERR_INVALID;
+    ix->profiling = false;
+    std::memset(out, 0, sizeof(*out));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    for (auto& iv : ix->intervals) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, iv.a, iv.b) == hipSuccess && iv.family >= 0 && iv.family < PCPX_K_FAMILIES) {
+            out->launches[iv.family] += 1;
+            out->total_ms[iv.family] += ms;
+        }
+        (void)hipEventDestroy(iv.a);
+        (void)hipEventDestroy(iv.b);
+    }
+    ix->intervals.clear();
     return PCPX_OK;
 }
 

@@ -261,6 +261,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
             }
     }
     hipStream_t s = ix.stream;
+    ProfileScope prof(ix, PCPX_K_BUILD);
     if (n > ix.cap || !ix.d_xyz) {
         PCPX_HIP(hipStreamSynchronize(s));
         u64 cap = n < 64 ? 64 : n;

@@ -16,6 +16,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "pcpx.h"
 
@@ -85,6 +86,14 @@ struct Index {
     u32 nleaves = 0;
     int top = 0;
 
+    // profiling (pcpx_profile_begin/end): one event pair per kernel-family interval
+    struct Interval {
+        int family;
+        hipEvent_t a, b;
+    };
+    bool profiling = false;
+    std::vector<Interval> intervals;
+
     // scratch for batch queries (grown on demand)
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -92,6 +101,28 @@ struct Index {
     u64* sorted_codes() const { return d_codes[1]; }
     u32* perm() const { return d_vals[1]; }
     TreeView view() const { return TreeView{d_leaves, d_boxes, d_lvl, nleaves, static_cast<u32>(n), top}; }
+};
+
+// RAII: records an event pair around a kernel family on the index's stream while profiling is on
+struct ProfileScope {
+    Index& ix;
+    int family;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfileScope(Index& i, int fam) : ix(i), family(fam)
+    {
+        if (!ix.profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            a = b = nullptr;
+            return;
+        }
+        (void)hipEventRecord(a, ix.stream);
+    }
+    ~ProfileScope()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, ix.stream);
+        ix.intervals.push_back(Index::Interval{family, a, b});
+    }
 };
 
 void set_error(const char* fmt, ...);
@@ -118,8 +149,8 @@ int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float*
                       u32* d_out_idx);
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt);
 int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx);
-int launch_normals(const float* d_xyz, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first,
-                   u64 count, u32 k, float* d_out, float* d_evals, hipStream_t s);
+int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
+                   float* d_out, float* d_evals);
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
 

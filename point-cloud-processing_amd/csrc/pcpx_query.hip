@@ -116,13 +116,6 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
     bitonic_merge<KCAP>(best);
 }
 
-struct Traversal {
-    // wave-uniform DFS over the implicit W-ary tree with a bit stack of pending children
-    u64 pend;
-    int l;       // level whose pending nibble is being consumed
-    u32 parent;  // index (at level l+1) of the node whose children are pending
-};
-
 // ------------------------------------------------------------------------------------------------
 // kNN
 // ------------------------------------------------------------------------------------------------
@@ -752,6 +745,7 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
         return PCPX_ERR_UNSUPPORTED;
     }
     hipStream_t s = ix.stream;
+    ProfileScope prof(ix, PCPX_K_QUERY_PREP);
     u32 n32 = static_cast<u32>(nq);
     u64 ngroups = (nq + GROUP - 1) / GROUP;
     size_t tb = 0;
@@ -792,6 +786,7 @@ static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * BUF * 64 * sizeof(u64);
     u32 grid = grid_for_groups(gcount);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
+    ProfileScope prof(ix, PCPX_K_KNN);
     if (self) k_knn<KCAP, true><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od);
     else k_knn<KCAP, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
@@ -813,6 +808,7 @@ int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_firs
     if (group_count == 0) return PCPX_OK;
     u32 grid = grid_for_groups(group_count);
     u32 gf = static_cast<u32>(group_first), ge = static_cast<u32>(group_first + group_count);
+    ProfileScope prof(ix, PCPX_K_RANGE);
     if (self)
         k_range<true, false><<<grid, 256, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
     else
@@ -825,6 +821,7 @@ int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float*
 {
     u64 groups = (static_cast<u64>(qv.nq) + GROUP - 1) / GROUP;
     if (groups == 0) return PCPX_OK;
+    ProfileScope prof(ix, PCPX_K_RANGE);
     k_range<false, true><<<grid_for_groups(groups), 256, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
                                                                            d_radii, nullptr, d_offsets, d_out_idx);
     return check_hip(hipGetLastError(), "k_range fill launch", __FILE__, __LINE__);
@@ -834,6 +831,7 @@ int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt)
 {
     if (nb == 0) return PCPX_OK;
     u32 grid = static_cast<u32>((nb + 255) / 256);
+    ProfileScope prof(ix, PCPX_K_RANGE);
     k_range_aabb<false><<<grid, 256, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), d_out_cnt, nullptr, nullptr);
     return check_hip(hipGetLastError(), "k_range_aabb launch", __FILE__, __LINE__);
 }
@@ -842,14 +840,18 @@ int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offs
 {
     if (nb == 0) return PCPX_OK;
     u32 grid = static_cast<u32>((nb + 255) / 256);
+    ProfileScope prof(ix, PCPX_K_RANGE);
     k_range_aabb<true><<<grid, 256, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), nullptr, d_offsets, d_out_idx);
     return check_hip(hipGetLastError(), "k_range_aabb fill launch", __FILE__, __LINE__);
 }
 
-int launch_normals(const float* d_xyz, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count,
-                   u32 k, float* d_out, float* d_evals, hipStream_t s)
+int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
+                   float* d_out, float* d_evals)
 {
     if (count == 0) return PCPX_OK;
+    ProfileScope prof(ix, PCPX_K_NORMALS);
+    hipStream_t s = ix.stream;
+    const float* d_xyz = ix.d_xyz;
     k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
                                                                      d_evals);
     return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);

@@ -219,6 +219,16 @@ class Index:
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 
+    def profile_begin(self):
+        check(self._lib.pcpx_profile_begin(self._h))
+
+    def profile_end(self):
+        """{family: (launches, total_ms)} from hipEvents recorded on the index's stream."""
+        p = _capi.Profile()
+        check(self._lib.pcpx_profile_end(self._h, C.byref(p)))
+        names = ["build", "knn", "normals", "range", "query_prep"]
+        return {n: (int(p.launches[i]), float(p.total_ms[i])) for i, n in enumerate(names)}
+
 
 class LinkedOctree(Index):
     """pcp::basic_linked_octree_t over index elements.  node_capacity / max_depth are accepted for
