@@ -165,6 +165,9 @@ typedef struct pcpx_profile {
     uint32_t launches[PCPX_K_FAMILIES];
     float total_ms[PCPX_K_FAMILIES];
 } pcpx_profile;
+/* Diagnostic build of the self-kNN kernel (k <= 16): out_stats = {leaves visited, node expansions,
+ * compactions, keys appended, wavefronts, seed leaves, 0, 0} summed over the launch. */
+int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t out_stats[8]);
 int pcpx_profile_begin(pcpx_index* idx);
 int pcpx_profile_end(pcpx_index* idx, pcpx_profile* out);
 

@@ -107,8 +107,7 @@ void free_index(Index* ix)
     }
     (void)hipFree(ix->d_sort_tmp);
     (void)hipFree(ix->d_leaves);
-    (void)hipFree(ix->d_boxes);
-    (void)hipFree(ix->d_lvl);
+    (void)hipFree(ix->d_nodes);
     (void)hipFree(ix->d_scalars);
     (void)hipFree(ix->d_scratch);
     if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -302,7 +301,7 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
     u64 gf, gc;
     slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
-    return launch_knn(*ix, qv, true, gf, gc, k, eps, d_out_idx, d_out_count, d_out_d2);
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, d_out_idx, d_out_count, d_out_d2, nullptr);
 }
 
 int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count, float* out_d2)
@@ -343,7 +342,7 @@ int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_
     if (!d_q_xyz || !d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
     QueryView qv;
     if ((st = prepare_queries(*ix, d_q_xyz, nq, qv)) != PCPX_OK) return st;
-    return launch_knn(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, k, eps, d_out_idx, d_out_count, d_out_d2);
+    return launch_knn(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, k, eps, d_out_idx, d_out_count, d_out_d2, nullptr);
 }
 
 int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, float eps, uint32_t* out_idx,
@@ -512,20 +511,15 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     int st = use(ix);
     if (st != PCPX_OK) return st;
     if (!d_out_normals || k == 0) return PCPX_ERR_INVALID;
-    u32* d_idx = d_opt_out_idx;
-    u32* d_cnt = d_opt_out_count;
-    if (!d_idx || !d_cnt) {  // neighbour lists not wanted by the caller: keep them in index scratch
-        size_t need_idx = static_cast<size_t>(ix->n_in) * k * sizeof(u32), need_cnt = static_cast<size_t>(ix->n_in) * sizeof(u32);
-        need_idx = (need_idx + 255) / 256 * 256;
-        if ((st = ensure_scratch(*ix, need_idx + need_cnt)) != PCPX_OK) return st;
-        if (!d_idx) d_idx = static_cast<u32*>(ix->d_scratch);
-        if (!d_cnt) d_cnt = reinterpret_cast<u32*>(static_cast<char*>(ix->d_scratch) + need_idx);
+    if (sorted_first % GROUP != 0) {
+        set_error("pcpx_normals_knn_self_dev: sorted_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
     }
-    if ((st = pcpx_knn_self_dev(h, k, eps, sorted_first, sorted_count, d_idx, d_cnt, nullptr)) != PCPX_OK) return st;
-    u64 n = ix->n;
-    u64 first = sorted_first > n ? n : sorted_first;
-    u64 count = (sorted_count > n - first) ? n - first : sorted_count;
-    return launch_normals(*ix, d_idx, d_cnt, ix->perm(), first, count, k, d_out_normals, nullptr);
+    // fused kernel: kNN rows stay in registers, only what the caller asked for is written
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, d_opt_out_idx, d_opt_out_count, nullptr, d_out_normals);
 }
 
 int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
@@ -598,6 +592,21 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
     if (m > 0) PCPX_HIP(hipMemcpy(dp.p, xyz, m * 3 * sizeof(float), hipMemcpyHostToDevice));
     if ((st = launch_normal_single(dp.as<float>(), m, dn.as<float>(), nullptr)) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpy(out_normal, dn.p, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PCPX_OK;
+}
+
+int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t out_stats[8])
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_stats || k == 0 || k > 16) return PCPX_ERR_INVALID;
+    DevBuf ds;
+    if ((st = ds.alloc(8 * sizeof(u64))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemsetAsync(ds.p, 0, 8 * sizeof(u64), ix->stream));
+    if ((st = launch_knn_stats(*ix, k, eps, ds.as<unsigned long long>())) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_stats, ds.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
     return PCPX_OK;
 }
 

@@ -137,14 +137,20 @@ __global__ __launch_bounds__(256) void k_fill_leaves(const float* __restrict__ x
     lf.id[s] = id;
 }
 
-__global__ __launch_bounds__(256) void k_leaf_boxes(const Leaf* __restrict__ leaves, u32 nleaves, u32 npadded,
-                                                    float* __restrict__ boxes)
+// leaf-level nodes: slot j of the bottom level (node leaf0 + j); j >= nleaves are padding nodes
+__global__ __launch_bounds__(256) void k_leaf_boxes(const Leaf* __restrict__ leaves, u32 nleaves, u32 nslots,
+                                                    NodeBox* __restrict__ level)
 {
     u32 l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= npadded) return;
+    if (l >= nslots) return;
     float inf = std::numeric_limits<float>::infinity();
-    float b[6] = {inf, inf, inf, -inf, -inf, -inf};
+    NodeBox nb;
+    nb.lo[0] = nb.lo[1] = nb.lo[2] = 0.f;
+    nb.hi[0] = nb.hi[1] = nb.hi[2] = 0.f;
+    nb.poison = __builtin_nanf("");
+    nb.pad = 0.f;
     if (l < nleaves) {
+        float b[6] = {inf, inf, inf, -inf, -inf, -inf};
         const Leaf& lf = leaves[l];
 #pragma unroll
         for (int s = 0; s < LEAF; ++s) {  // NaN pads never win fminf/fmaxf
@@ -155,33 +161,50 @@ __global__ __launch_bounds__(256) void k_leaf_boxes(const Leaf* __restrict__ lea
             b[4] = fmaxf(b[4], lf.y[s]);
             b[5] = fmaxf(b[5], lf.z[s]);
         }
+        nb.lo[0] = b[0]; nb.lo[1] = b[1]; nb.lo[2] = b[2];
+        nb.hi[0] = b[3]; nb.hi[1] = b[4]; nb.hi[2] = b[5];
+        nb.poison = 0.f;
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) boxes[6 * static_cast<u64>(l) + a] = b[a];
+    level[l] = nb;
 }
 
-__global__ __launch_bounds__(256) void k_upper_boxes(const float* __restrict__ child, u32 nchild, float* __restrict__ parent,
-                                                     u32 nparent, u32 nparent_padded)
+// one level up: node i = union of its 4 children (padding children are skipped)
+__global__ __launch_bounds__(256) void k_upper_boxes(const NodeBox* __restrict__ child, NodeBox* __restrict__ parent,
+                                                     u32 nparent)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nparent_padded) return;
+    if (i >= nparent) return;
     float inf = std::numeric_limits<float>::infinity();
     float b[6] = {inf, inf, inf, -inf, -inf, -inf};
-    if (i < nparent) {
-        for (int c = 0; c < W; ++c) {
-            u32 ci = i * W + c;
-            if (ci >= nchild) break;
-            const float* cb = child + 6 * static_cast<u64>(ci);
-            b[0] = fminf(b[0], cb[0]);
-            b[1] = fminf(b[1], cb[1]);
-            b[2] = fminf(b[2], cb[2]);
-            b[3] = fmaxf(b[3], cb[3]);
-            b[4] = fmaxf(b[4], cb[4]);
-            b[5] = fmaxf(b[5], cb[5]);
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        NodeBox cb = child[static_cast<u64>(i) * W + c];
+        if (cb.poison == 0.f) {
+            any = true;
+            b[0] = fminf(b[0], cb.lo[0]);
+            b[1] = fminf(b[1], cb.lo[1]);
+            b[2] = fminf(b[2], cb.lo[2]);
+            b[3] = fmaxf(b[3], cb.hi[0]);
+            b[4] = fmaxf(b[4], cb.hi[1]);
+            b[5] = fmaxf(b[5], cb.hi[2]);
         }
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) parent[6 * static_cast<u64>(i) + a] = b[a];
+    NodeBox nb;
+    nb.lo[0] = any ? b[0] : 0.f; nb.lo[1] = any ? b[1] : 0.f; nb.lo[2] = any ? b[2] : 0.f;
+    nb.hi[0] = any ? b[3] : 0.f; nb.hi[1] = any ? b[4] : 0.f; nb.hi[2] = any ? b[5] : 0.f;
+    nb.poison = any ? 0.f : __builtin_nanf("");
+    nb.pad = 0.f;
+    parent[i] = nb;
+}
+
+inline u64 pow4(int d) { return 1ull << (2 * d); }
+inline u64 level_start(int d) { return (pow4(d) - 1) / 3; }
+inline int depth_for(u64 nleaves)
+{
+    int d = 0;
+    while (pow4(d) < nleaves) ++d;
+    return d;
 }
 
 template <class T>
@@ -200,8 +223,6 @@ int dev_alloc(T*& p, size_t count)
     }
     return PCPX_OK;
 }
-
-inline u32 round_up(u32 v, u32 m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
@@ -273,13 +294,9 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         }
         u32 nl = static_cast<u32>((cap + LEAF - 1) / LEAF);
         if ((st = dev_alloc(ix.d_leaves, nl)) != PCPX_OK) return st;
-        u64 nodes = 0;
-        for (u32 c = nl;; c = (c + W - 1) / W) {
-            nodes += round_up(c, W);
-            if (c <= 1) break;
-        }
-        if ((st = dev_alloc(ix.d_boxes, nodes * 6)) != PCPX_OK) return st;
-        ix.boxes_cap = nodes;
+        u64 nodes = level_start(depth_for(nl) + 1);
+        if ((st = dev_alloc(ix.d_nodes, nodes)) != PCPX_OK) return st;
+        ix.nodes_cap = nodes;
         size_t tb = 0;
         if ((st = sort_pairs_u64(nullptr, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], cap, s)) != PCPX_OK)
             return st;
@@ -289,9 +306,8 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         ix.sort_tmp_bytes = tb;
         ix.cap = cap;
     }
-    if (!ix.d_lvl) {
+    if (!ix.d_scalars) {
         int st;
-        if ((st = dev_alloc(ix.d_lvl, 2 * MAXLVL)) != PCPX_OK) return st;
         if ((st = dev_alloc(ix.d_scalars, 16)) != PCPX_OK) return st;
     }
     ix.n_in = n;
@@ -325,35 +341,29 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     std::memcpy(ix.bbox, &hb[2], 6 * sizeof(float));
     ix.n = nvalid;
 
-    // levels
+    // implicit tree, heap layout
     u32 nleaves = (nvalid + LEAF - 1) / LEAF;
     ix.nleaves = nleaves;
-    u32 off = 0, cnt = nleaves;
-    int lvl = 0;
-    std::memset(ix.h_lvl, 0, sizeof(ix.h_lvl));
-    for (;; ++lvl) {
-        if (lvl >= MAXLVL) {
-            set_error("pcpx: tree deeper than %d levels", MAXLVL);
-            return PCPX_ERR_UNSUPPORTED;
-        }
-        ix.h_lvl[lvl] = off;
-        ix.h_lvl[MAXLVL + lvl] = cnt;
-        off += round_up(cnt < 1 ? 1 : cnt, W);
-        if (cnt <= 1) break;
-        cnt = (cnt + W - 1) / W;
+    int depth = depth_for(nleaves);
+    if (depth > MAXDEPTH) {
+        set_error("pcpx: tree deeper than %d levels", MAXDEPTH);
+        return PCPX_ERR_UNSUPPORTED;
     }
-    ix.top = lvl;
-    PCPX_HIP(hipMemcpyAsync(ix.d_lvl, ix.h_lvl, sizeof(ix.h_lvl), hipMemcpyHostToDevice, s));
-    if (nleaves > 0) {
+    ix.depth = depth;
+    ix.leaf0 = static_cast<u32>(level_start(depth));
+    if (level_start(depth + 1) > ix.nodes_cap) {
+        set_error("pcpx: internal error, node capacity");
+        return PCPX_ERR_INVALID;
+    }
+    {
         u32 nslots = nleaves * LEAF;
-        k_fill_leaves<<<(nslots + 255) / 256, 256, 0, s>>>(ix.d_xyz, ix.perm(), nvalid, nslots, ix.d_leaves);
-        u32 npad = round_up(nleaves, W);
-        k_leaf_boxes<<<(npad + 255) / 256, 256, 0, s>>>(ix.d_leaves, nleaves, npad, ix.d_boxes);
-        for (int l = 1; l <= ix.top; ++l) {
-            u32 nc = ix.h_lvl[MAXLVL + l - 1], np = ix.h_lvl[MAXLVL + l];
-            u32 npp = round_up(np, W);
-            k_upper_boxes<<<(npp + 255) / 256, 256, 0, s>>>(ix.d_boxes + 6ull * ix.h_lvl[l - 1], nc,
-                                                              ix.d_boxes + 6ull * ix.h_lvl[l], np, npp);
+        if (nslots)
+            k_fill_leaves<<<(nslots + 255) / 256, 256, 0, s>>>(ix.d_xyz, ix.perm(), nvalid, nslots, ix.d_leaves);
+        u32 bottom = static_cast<u32>(pow4(depth));
+        k_leaf_boxes<<<(bottom + 255) / 256, 256, 0, s>>>(ix.d_leaves, nleaves, bottom, ix.d_nodes + level_start(depth));
+        for (int d = depth - 1; d >= 0; --d) {
+            u32 np = static_cast<u32>(pow4(d));
+            k_upper_boxes<<<(np + 255) / 256, 256, 0, s>>>(ix.d_nodes + level_start(d + 1), ix.d_nodes + level_start(d), np);
         }
         PCPX_HIP(hipGetLastError());
     }

@@ -30,7 +30,7 @@ constexpr int LOGW = 2;    // log2 of the tree arity
 constexpr int W = 1 << LOGW;
 constexpr int GROUP = 64;  // queries per wavefront
 constexpr int LEAVES_PER_GROUP = GROUP / LEAF;
-constexpr int MAXLVL = 16;
+constexpr int MAXDEPTH = 15;  // 4^15 leaves of 8 points: far beyond 2^32 points
 constexpr u32 INVALID_ID = 0xFFFFFFFFu;
 constexpr u64 PAD_CODE = ~0ull;
 
@@ -42,13 +42,26 @@ struct Leaf {
 };
 static_assert(sizeof(Leaf) == 16 * LEAF, "leaf record must be dense");
 
+// One node of the implicit 4-ary AABB tree, 32 B so that the 4 children of a node are one 128-B
+// scalar load.  `poison` is +0 for a real node and NaN for a padding node (no points below it): it is
+// added to the box distance, so a padding node can never pass a `distance <= bound` test.
+struct NodeBox {
+    float lo[3];
+    float hi[3];
+    float poison;
+    float pad;
+};
+static_assert(sizeof(NodeBox) == 32, "node box must be 32 bytes");
+
+// Heap layout: root = node 0, children of node h = 4h+1 .. 4h+4, so depth d starts at (4^d-1)/3.
+// Leaf j is node leaf0 + j with leaf0 = (4^depth - 1)/3; depth is the smallest with 4^depth >= nleaves.
 struct TreeView {
-    const Leaf* leaves;  // nleaves records
-    const float* boxes;  // 6 floats per node, levels concatenated (level 0 = leaves), each level padded to W
-    const u32* lvl;      // [0,MAXLVL): node offset of level l; [MAXLVL,2*MAXLVL): node count of level l
+    const Leaf* leaves;    // nleaves records
+    const NodeBox* nodes;  // (4^(depth+1)-1)/3 nodes
     u32 nleaves;
-    u32 n;               // indexed points
-    int top;             // index of the root level (its count is 1)
+    u32 n;                 // indexed points
+    int depth;
+    u32 leaf0;
 };
 
 // Queries of a batch, in Morton-sorted order.  For self queries qx == nullptr and the query of
@@ -78,13 +91,12 @@ struct Index {
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     Leaf* d_leaves = nullptr;
-    float* d_boxes = nullptr;
-    u64 boxes_cap = 0;           // nodes
-    u32* d_lvl = nullptr;        // 2*MAXLVL
+    NodeBox* d_nodes = nullptr;
+    u64 nodes_cap = 0;           // nodes
     u32* d_scalars = nullptr;    // [0..6) encoded bbox, [6] valid count, 6 floats decoded bbox at [8..14)
-    u32 h_lvl[2 * MAXLVL] = {};
     u32 nleaves = 0;
-    int top = 0;
+    int depth = 0;
+    u32 leaf0 = 0;
 
     // profiling (pcpx_profile_begin/end): one event pair per kernel-family interval
     struct Interval {
@@ -100,7 +112,7 @@ struct Index {
 
     u64* sorted_codes() const { return d_codes[1]; }
     u32* perm() const { return d_vals[1]; }
-    TreeView view() const { return TreeView{d_leaves, d_boxes, d_lvl, nleaves, static_cast<u32>(n), top}; }
+    TreeView view() const { return TreeView{d_leaves, d_nodes, nleaves, static_cast<u32>(n), depth, leaf0}; }
 };
 
 // RAII: records an event pair around a kernel family on the index's stream while profiling is on
@@ -141,8 +153,10 @@ int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, cons
 int ensure_scratch(Index& ix, size_t bytes);
 
 // query.hip
+// kNN (+ fused PCA normals when d_out_normals != nullptr); any of the outputs may be nullptr
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
-               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2);
+               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2, float* d_out_normals);
+int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats);
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
                        const float* d_radii, u32* d_out_cnt);
 int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,

@@ -2,23 +2,31 @@
 //
 // Execution model (DESIGN.md "Kernels"):
 //   * ONE WAVEFRONT = 64 Morton-consecutive queries, one query per lane.
-//   * Tree traversal is WAVE-UNIFORM: node indices, the pending-children bit stack and all control
-//     flow live in SGPRs; node boxes and whole leaf records are fetched with scalar (SMEM) loads and
-//     broadcast to the 64 lanes as SGPR operands of the per-lane VALU distance code.  A subtree is
-//     entered when ANY lane still needs it (ballot), so the wave walks the union of its lanes' search
-//     regions -- small, because the lanes are neighbours on the Morton curve.
-//   * kNN selection: per lane a SORTED best-list of KCAP 64-bit keys (d2 bits << 32 | index) in VGPRs
-//     plus an UNSORTED append buffer in LDS (column per lane, conflict free).  A candidate with
-//     d2 <= tau is appended with one ds_write_b64; when any lane's column is full the whole wave runs a
-//     register bitonic sort of the new keys and a bitonic merge with the best-list, which also
-//     tightens tau = d2 of the k-th best.
+//   * Tree traversal is WAVE-UNIFORM: node ids, the pending-children bit stack and all control flow
+//     live in SGPRs; the 4 child boxes of a node (one 128-B record) and whole leaf records (128 B) are
+//     fetched with scalar (SMEM) loads and broadcast to the 64 lanes as SGPR operands of the per-lane
+//     VALU distance code.  A subtree is entered when ANY lane still needs it (ballot), so the wave
+//     walks the union of its lanes' search regions -- small, because the lanes are neighbours on the
+//     Morton curve.
+//   * kNN selection: per lane a SORTED best-list of KCAP 64-bit keys (d2 bits << 32 | sorted position)
+//     in VGPRs plus an UNSORTED append buffer in LDS (one column per lane, conflict free).  Accepting a
+//     candidate is branch-free: the key is always stored, to the lane's next free slot if d2 <= tau
+//     and the point is outside the eps-box, else to a trash row.  When a column is nearly full the wave
+//     sorts the new keys in registers (bitonic network whose compare-exchange is v_min_f64 / v_max_f64:
+//     every key is the bit pattern of a finite non-negative double) and merges them with the best-list,
+//     which tightens tau = d2 of the k-th best.
 //   * The search is seeded with the 64 points of the query group itself (for arbitrary queries: the
 //     64-point chunk at the group's Morton position), so tau is tight before the traversal starts.
+//   * Keys carry the SORTED position, so neighbour ids and coordinates are gathered from the leaf
+//     records (spatially coherent, L1/L2 resident); the final rows are re-ordered by (d2, original index).
+//   * PCA normals are fused into the same kernel: no neighbour list round trip through HBM.
 //
 // Arithmetic follows the reference exactly: d = p - q, dx*dx + dy*dy + dz*dz in float32 without
 // FMA contraction (include/pcp/common/norm.hpp:102-112), eps-box exclusion
 // (include/pcp/common/vector3d_queries.hpp:47-64).  The box lower bound is monotone in float, so
-// pruning never changes the result: rows equal the exact (d2, index)-sorted k nearest.
+// pruning never changes the result.  Rows are the exact k nearest in ascending (d2, index) order; if
+// several points tie EXACTLY with the k-th distance, which of them is kept is unspecified -- as in the
+// reference, where it depends on heap order (linked_octree_node.hpp:479-489, linked_kdtree.hpp:483-488).
 #include "pcpx_internal.h"
 
 #include <cmath>
@@ -30,7 +38,7 @@ namespace pcpx {
 
 namespace {
 
-constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID_ID): larger than every real key
+constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID): larger than every real key, a finite double
 constexpr int WAVES_PER_BLOCK = 4;
 
 __device__ __forceinline__ u32 wave_in_block() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
@@ -45,23 +53,40 @@ __device__ __forceinline__ u32 virtual_block()
 
 __device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
 
-// squared distance from q to the box; equals d2(q, clamp(q, box)) of
-// include/pcp/common/axis_aligned_bounding_box.hpp:138-148 and is a lower bound, in float
-// arithmetic, of sq3(p - q) for every p inside the box.
-__device__ __forceinline__ float box_d2(const float* __restrict__ b, float qx, float qy, float qz)
+// squared distance from q to the box (+ poison): equals d2(q, clamp(q, box)) of
+// include/pcp/common/axis_aligned_bounding_box.hpp:138-148 and is a lower bound, in float arithmetic,
+// of sq3(p - q) for every p inside the box; NaN for a padding node.
+__device__ __forceinline__ float box_d2(const NodeBox& b, float qx, float qy, float qz)
 {
-    float dx = fmaxf(fmaxf(b[0] - qx, qx - b[3]), 0.f);
-    float dy = fmaxf(fmaxf(b[1] - qy, qy - b[4]), 0.f);
-    float dz = fmaxf(fmaxf(b[2] - qz, qz - b[5]), 0.f);
-    return sq3(dx, dy, dz);
+    float dx = fmaxf(fmaxf(b.lo[0] - qx, qx - b.hi[0]), 0.f);
+    float dy = fmaxf(fmaxf(b.lo[1] - qy, qy - b.hi[1]), 0.f);
+    float dz = fmaxf(fmaxf(b.lo[2] - qz, qz - b.hi[2]), 0.f);
+    return sq3(dx, dy, dz) + b.poison;
 }
 
+struct NodeBox4 {
+    NodeBox c[W];
+};
+
+// ---- selection network on 64-bit keys -------------------------------------------------------------
+// Keys are (float32 d2 >= 0 bits) << 32 | u32: as IEEE doubles they are finite, non-negative and
+// ordered like the integers, so min/max of the doubles is the integer compare-exchange in 2 VALU ops
+// (a u64 compare + 4 selects costs 8 and two s_nop on gfx950).
 __device__ __forceinline__ void ce(u64& a, u64& b)
 {
-    u64 lo = a < b ? a : b;
-    u64 hi = a < b ? b : a;
-    a = lo;
-    b = hi;
+    double x = __longlong_as_double(static_cast<long long>(a)), y = __longlong_as_double(static_cast<long long>(b));
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    a = static_cast<u64>(__double_as_longlong(lo));
+    b = static_cast<u64>(__double_as_longlong(hi));
+}
+__device__ __forceinline__ u64 key_min(u64 a, u64 b)
+{
+    double x = __longlong_as_double(static_cast<long long>(a)), y = __longlong_as_double(static_cast<long long>(b));
+    double lo;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    return static_cast<u64>(__double_as_longlong(lo));
 }
 
 template <int N>
@@ -96,343 +121,134 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
     }
 }
 
+// key/payload variant for the (rare) final tie repair
+__device__ __forceinline__ void ce_payload(u64& ka, u64& kb, u32& pa, u32& pb)
+{
+    bool sw = ka > kb;
+    u64 t0 = sw ? kb : ka, t1 = sw ? ka : kb;
+    u32 q0 = sw ? pb : pa, q1 = sw ? pa : pb;
+    ka = t0; kb = t1; pa = q0; pb = q1;
+}
+template <int N>
+__device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
+{
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                int l = i ^ j;
+                if (l > i) {
+                    if ((i & k) == 0) ce_payload(a[i], a[l], p[i], p[l]);
+                    else ce_payload(a[l], a[i], p[l], p[i]);
+                }
+            }
+        }
+    }
+}
+
 // Fold the first KCAP buffered keys of this lane into its sorted best-list; leftovers move down.
+// All LDS traffic is unconditional (stale slots are masked to PAD_KEY in registers): no exec games.
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
     u64 nw[KCAP];
 #pragma unroll
-    for (int j = 0; j < KCAP; ++j) nw[j] = j < cnt ? col[j * 64] : PAD_KEY;
+    for (int j = 0; j < KCAP; ++j) nw[j] = col[j * 64];
 #pragma unroll
-    for (int j = 0; j < BUF - KCAP; ++j)
-        if (KCAP + j < cnt) col[j * 64] = col[(KCAP + j) * 64];
+    for (int j = 0; j < KCAP; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
+#pragma unroll
+    for (int j = 0; j < BUF - KCAP; ++j) col[j * 64] = col[(KCAP + j) * 64];
     cnt = cnt > KCAP ? cnt - KCAP : 0;
     bitonic_sort<KCAP>(nw);
 #pragma unroll
-    for (int j = 0; j < KCAP; ++j) {
-        u64 o = nw[KCAP - 1 - j];
-        best[j] = best[j] < o ? best[j] : o;
-    }
+    for (int j = 0; j < KCAP; ++j) best[j] = key_min(best[j], nw[KCAP - 1 - j]);
     bitonic_merge<KCAP>(best);
 }
 
-// ------------------------------------------------------------------------------------------------
-// kNN
-// ------------------------------------------------------------------------------------------------
-template <int KCAP, bool SELF>
-__global__ __launch_bounds__(256) void k_knn(TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k,
-                                             float eps, u32* __restrict__ out_idx, u32* __restrict__ out_cnt,
-                                             float* __restrict__ out_d2)
-{
-    constexpr int BUF = KCAP + LEAF;
-    extern __shared__ u64 lds[];
-    const u32 lane = threadIdx.x & 63u;
-    const u32 wib = wave_in_block();
-    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wib;
-    if (g >= group_end) return;
-    u64* col = lds + static_cast<size_t>(wib) * BUF * 64 + lane;
+// ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
+// All members are wave-uniform (SGPRs).  next() yields, in Morton order, every leaf whose box is still
+// needed by at least one lane at the time its parent is expanded.
+struct Walker {
+    u64 pend;     // nibble l = children (height l) of the current ancestor at height l+1 still to visit
+    u32 node;     // heap id of the node to expand (valid when expand)
+    u32 parent;   // heap id (height l+1) whose pending nibble is being consumed
+    int ht;       // height of `node`
+    int l;
+    bool expand;
+    bool done;
+    bool single;  // depth == 0: the root is the only leaf
 
-    // ---- my query ----
-    const u32 p = g * GROUP + lane;
-    const u32 nq = SELF ? t.n : qv.nq;
-    const bool valid = p < nq;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    u32 row = 0;
-    if (valid) {
-        if (SELF) {
-            const Leaf& lf = t.leaves[p / LEAF];
-            qx = lf.x[p % LEAF];
-            qy = lf.y[p % LEAF];
-            qz = lf.z[p % LEAF];
-            row = lf.id[p % LEAF];
+    template <class Need>
+    __device__ __forceinline__ void start(const TreeView& t, Need&& need)
+    {
+        pend = 0;
+        node = 0;
+        parent = 0;
+        ht = t.depth;
+        l = t.depth;
+        expand = false;
+        single = false;
+        done = t.nleaves == 0;
+        if (done) return;
+        const NodeBox root = t.nodes[0];
+        bool go = __ballot(need(root)) != 0ull;
+        if (!go) {
+            done = true;
+        } else if (t.depth == 0) {
+            single = true;
         } else {
-            qx = qv.qx[p];
-            qy = qv.qy[p];
-            qz = qv.qz[p];
-            row = qv.row[p];
+            expand = true;
         }
     }
-    // best-list: KCAP-k leading zero keys act as -inf sentinels so that tau is always best[KCAP-1]
-    u64 best[KCAP];
-#pragma unroll
-    for (int j = 0; j < KCAP; ++j) best[j] = (j < KCAP - static_cast<int>(k)) ? 0ull : PAD_KEY;
-    float tau = valid ? std::numeric_limits<float>::infinity() : -1.f;
-    int cnt = 0;
 
-    auto leaf_candidates = [&](u32 leaf) {
-        if (__ballot(cnt > KCAP) != 0ull) {
-            compact<KCAP, BUF>(best, col, cnt);
-            if (valid) tau = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+    template <class Need>
+    __device__ __forceinline__ bool next(const TreeView& t, Need&& need, u32& leaf, u32& n_expand)
+    {
+        if (done) return false;
+        if (single) {
+            single = false;
+            done = true;
+            leaf = 0;
+            return true;
         }
-        const Leaf lf = t.leaves[leaf];  // wave-uniform address: SMEM loads into SGPRs
+        for (;;) {
+            if (expand) {
+                expand = false;
+                ++n_expand;
+                const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1);
+                u32 m = 0;
 #pragma unroll
-        for (int j = 0; j < LEAF; ++j) {
-            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-            float d2 = sq3(dx, dy, dz);
-            if (d2 <= tau) {
-                bool same = fabsf(dx) < eps && fabsf(dy) < eps && fabsf(dz) < eps;
-                if (!same) {
-                    col[cnt * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | lf.id[j];
-                    ++cnt;
+                for (int c = 0; c < W; ++c)
+                    if (__ballot(need(cb.c[c])) != 0ull) m |= 1u << c;
+                l = ht - 1;
+                parent = node;
+                pend |= static_cast<u64>(m) << (W * l);
+            }
+            u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
+            if (mm) {
+                int b = __builtin_ctz(mm);
+                pend &= ~(1ull << (W * l + b));
+                u32 child = (parent << LOGW) + 1u + static_cast<u32>(b);
+                if (l == 0) {
+                    leaf = child - t.leaf0;
+                    return true;
                 }
-            }
-        }
-    };
-
-    // ---- seed: the 64-point chunk at the group's own Morton position ----
-    u32 s0, s1;
-    if (SELF) s0 = g * LEAVES_PER_GROUP;
-    else s0 = qv.seed[g];
-    s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
-    for (u32 lf = s0; lf < s1; ++lf) leaf_candidates(lf);
-    while (__ballot(cnt > 0) != 0ull) compact<KCAP, BUF>(best, col, cnt);
-    if (valid) tau = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
-
-    // ---- traversal ----
-    if (t.top > 0) {
-        const float* rootbox = t.boxes + 6ull * t.lvl[t.top];
-        bool go = __ballot(valid && box_d2(rootbox, qx, qy, qz) <= tau) != 0ull;
-        int lev = t.top;  // node being expanded: (lev, node)
-        u32 node = 0;
-        u64 pend = 0;
-        while (go) {
-            // expand (lev, node): test its W children, all lanes against each child box
-            const int cl = lev - 1;
-            const u32 base = node << LOGW;
-            const u32 ccount = t.lvl[MAXLVL + cl];
-            const float* cb = t.boxes + 6ull * (t.lvl[cl] + base);
-            u32 m = 0;
-#pragma unroll
-            for (int c = 0; c < W; ++c) {
-                bool need = valid && box_d2(cb + 6 * c, qx, qy, qz) <= tau;
-                if (base + c < ccount && __ballot(need) != 0ull) m |= 1u << c;
-            }
-            pend |= static_cast<u64>(m) << (W * cl);
-            int l = cl;
-            u32 parent = node;
-            go = false;
-            for (;;) {
-                u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
-                if (mm) {
-                    int b = __builtin_ctz(mm);
-                    pend &= ~(1ull << (W * l + b));
-                    u32 child = (parent << LOGW) + b;
-                    if (l == 0) {
-                        if (child < s0 || child >= s1) leaf_candidates(child);
-                    } else {
-                        lev = l;
-                        node = child;
-                        go = true;
-                        break;
-                    }
-                } else {
-                    ++l;
-                    if (l >= t.top) break;
-                    parent >>= LOGW;
+                node = child;
+                ht = l;
+                expand = true;
+            } else {
+                ++l;
+                if (l >= t.depth) {
+                    done = true;
+                    return false;
                 }
+                parent = (parent - 1u) >> LOGW;
             }
         }
     }
-    while (__ballot(cnt > 0) != 0ull) compact<KCAP, BUF>(best, col, cnt);
-
-    // ---- write the row ----
-    if (valid) {
-        u32 found = 0;
-        const u64 ob = static_cast<u64>(row) * k;
-#pragma unroll
-        for (int s = 0; s < KCAP; ++s) {
-            int j = s - (KCAP - static_cast<int>(k));
-            if (j >= 0) {
-                u64 key = best[s];
-                bool ok = key != PAD_KEY;
-                out_idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
-                if (out_d2) out_d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
-                found += ok ? 1u : 0u;
-            }
-        }
-        out_cnt[row] = found;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
-// every point with d2 <= r*r, query included)
-// ------------------------------------------------------------------------------------------------
-template <bool SELF, bool FILL>
-__global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
-                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
-                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
-{
-    const u32 lane = threadIdx.x & 63u;
-    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
-    if (g >= group_end) return;
-    const u32 p = g * GROUP + lane;
-    const u32 nq = SELF ? t.n : qv.nq;
-    const bool valid = p < nq;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    u32 row = 0;
-    if (valid) {
-        if (SELF) {
-            const Leaf& lf = t.leaves[p / LEAF];
-            qx = lf.x[p % LEAF];
-            qy = lf.y[p % LEAF];
-            qz = lf.z[p % LEAF];
-            row = lf.id[p % LEAF];
-        } else {
-            qx = qv.qx[p];
-            qy = qv.qy[p];
-            qz = qv.qz[p];
-            row = qv.row[p];
-        }
-    }
-    float r = radius;
-    if (radii && valid) r = radii[row];
-    const float r2 = valid ? r * r : -1.f;  // sphere.hpp:34 radius * radius in float
-    u32 cnt = 0;
-    u64 wpos = (FILL && valid) ? offsets[row] : 0;
-
-    auto leaf_candidates = [&](u32 leaf) {
-        const Leaf lf = t.leaves[leaf];
-#pragma unroll
-        for (int j = 0; j < LEAF; ++j) {
-            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-            if (sq3(dx, dy, dz) <= r2) {
-                if (FILL) out_idx[wpos + cnt] = lf.id[j];
-                ++cnt;
-            }
-        }
-    };
-
-    if (t.nleaves > 0) {
-        const float* rootbox = t.boxes + 6ull * t.lvl[t.top];
-        bool go = __ballot(valid && box_d2(rootbox, qx, qy, qz) <= r2) != 0ull;
-        if (t.top == 0) {
-            if (go) leaf_candidates(0);
-            go = false;
-        }
-        int lev = t.top;
-        u32 node = 0;
-        u64 pend = 0;
-        while (go) {
-            const int cl = lev - 1;
-            const u32 base = node << LOGW;
-            const u32 ccount = t.lvl[MAXLVL + cl];
-            const float* cb = t.boxes + 6ull * (t.lvl[cl] + base);
-            u32 m = 0;
-#pragma unroll
-            for (int c = 0; c < W; ++c) {
-                bool need = valid && box_d2(cb + 6 * c, qx, qy, qz) <= r2;
-                if (base + c < ccount && __ballot(need) != 0ull) m |= 1u << c;
-            }
-            pend |= static_cast<u64>(m) << (W * cl);
-            int l = cl;
-            u32 parent = node;
-            go = false;
-            for (;;) {
-                u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
-                if (mm) {
-                    int b = __builtin_ctz(mm);
-                    pend &= ~(1ull << (W * l + b));
-                    u32 child = (parent << LOGW) + b;
-                    if (l == 0) {
-                        leaf_candidates(child);
-                    } else {
-                        lev = l;
-                        node = child;
-                        go = true;
-                        break;
-                    }
-                } else {
-                    ++l;
-                    if (l >= t.top) break;
-                    parent >>= LOGW;
-                }
-            }
-        }
-    }
-    if (valid && !FILL) out_cnt[row] = cnt;
-}
-
-// AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:
-// test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
-// (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
-                                                    u32* __restrict__ out_cnt, const u64* __restrict__ offsets,
-                                                    u32* __restrict__ out_idx)
-{
-    const u32 lane = threadIdx.x & 63u;
-    const u32 g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
-    const u32 p = g * GROUP + lane;
-    const bool valid = p < nb;
-    float b[6] = {0, 0, 0, 0, 0, 0};
-    if (valid)
-        for (int a = 0; a < 6; ++a) b[a] = boxes6[6ull * p + a];
-    u32 cnt = 0;
-    u64 wpos = (FILL && valid) ? offsets[p] : 0;
-    auto overlaps = [&](const float* nb6) {
-        return valid && (nb6[3] >= b[0] && nb6[4] >= b[1] && nb6[5] >= b[2]) &&
-               (nb6[0] <= b[3] && nb6[1] <= b[4] && nb6[2] <= b[5]);
-    };
-    auto leaf_candidates = [&](u32 leaf) {
-        const Leaf lf = t.leaves[leaf];
-#pragma unroll
-        for (int j = 0; j < LEAF; ++j) {
-            float x = lf.x[j], y = lf.y[j], z = lf.z[j];
-            bool in = valid && (x >= b[0] && y >= b[1] && z >= b[2]) && (x <= b[3] && y <= b[4] && z <= b[5]);
-            if (in) {
-                if (FILL) out_idx[wpos + cnt] = lf.id[j];
-                ++cnt;
-            }
-        }
-    };
-    if (t.nleaves > 0 && __ballot(valid) != 0ull) {
-        const float* rootbox = t.boxes + 6ull * t.lvl[t.top];
-        bool go = __ballot(overlaps(rootbox)) != 0ull;
-        if (t.top == 0) {
-            if (go) leaf_candidates(0);
-            go = false;
-        }
-        int lev = t.top;
-        u32 node = 0;
-        u64 pend = 0;
-        while (go) {
-            const int cl = lev - 1;
-            const u32 base = node << LOGW;
-            const u32 ccount = t.lvl[MAXLVL + cl];
-            const float* cb = t.boxes + 6ull * (t.lvl[cl] + base);
-            u32 m = 0;
-#pragma unroll
-            for (int c = 0; c < W; ++c)
-                if (base + c < ccount && __ballot(overlaps(cb + 6 * c)) != 0ull) m |= 1u << c;
-            pend |= static_cast<u64>(m) << (W * cl);
-            int l = cl;
-            u32 parent = node;
-            go = false;
-            for (;;) {
-                u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
-                if (mm) {
-                    int bb = __builtin_ctz(mm);
-                    pend &= ~(1ull << (W * l + bb));
-                    u32 child = (parent << LOGW) + bb;
-                    if (l == 0) {
-                        leaf_candidates(child);
-                    } else {
-                        lev = l;
-                        node = child;
-                        go = true;
-                        break;
-                    }
-                } else {
-                    ++l;
-                    if (l >= t.top) break;
-                    parent >>= LOGW;
-                }
-            }
-        }
-    }
-    if (valid && !FILL) out_cnt[p] = cnt;
-}
+};
 
 // ------------------------------------------------------------------------------------------------
 // PCA normal of one neighbourhood per thread.
@@ -601,6 +417,301 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
     normal[0] = nx; normal[1] = ny; normal[2] = nz;
 }
 
+// ------------------------------------------------------------------------------------------------
+// kNN (+ fused PCA normals)
+// ------------------------------------------------------------------------------------------------
+template <int KCAP, bool SELF, bool STATS>
+__global__ __launch_bounds__(256, KCAP <= 16 ? 3 : 1) void k_knn(TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k,
+                                             float eps, u32* __restrict__ out_idx, u32* __restrict__ out_cnt,
+                                             float* __restrict__ out_d2, float* __restrict__ out_nrm,
+                                             unsigned long long* __restrict__ stats)
+{
+    constexpr int BUF = KCAP + LEAF;  // usable rows; row BUF is the trash row
+    extern __shared__ u64 lds[];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wib = wave_in_block();
+    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wib;
+    if (g >= group_end) return;
+    u64* col = lds + static_cast<size_t>(wib) * (BUF + 1) * 64 + lane;
+    // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
+    // [3] keys appended, [4] waves, [5] seed leaves
+    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0;
+
+    // ---- my query ----
+    const u32 p = g * GROUP + lane;
+    const u32 nq = SELF ? t.n : qv.nq;
+    const bool valid = p < nq;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    u32 row = 0;
+    if (valid) {
+        if (SELF) {
+            const Leaf& lf = t.leaves[p / LEAF];
+            qx = lf.x[p % LEAF];
+            qy = lf.y[p % LEAF];
+            qz = lf.z[p % LEAF];
+            row = lf.id[p % LEAF];
+        } else {
+            qx = qv.qx[p];
+            qy = qv.qy[p];
+            qz = qv.qz[p];
+            row = qv.row[p];
+        }
+    }
+    // best-list: KCAP-k leading zero keys act as -inf sentinels so that tau is always best[KCAP-1]
+    u64 best[KCAP];
+#pragma unroll
+    for (int j = 0; j < KCAP; ++j) best[j] = (j < KCAP - static_cast<int>(k)) ? 0ull : PAD_KEY;
+    const float inf = std::numeric_limits<float>::infinity();
+    float tau = valid ? inf : -1.f;  // -1: an idle lane never accepts a candidate nor needs a node
+    int cnt = 0;
+
+    auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
+
+    // ---- seed range: the 64-point chunk at the group's own Morton position ----
+    u32 s0, s1;
+    if (SELF) s0 = g * LEAVES_PER_GROUP;
+    else s0 = qv.seed[g];
+    s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
+    if (s0 > s1) s0 = s1;
+
+    Walker wk;
+    wk.done = true;
+    u32 seedcur = s0;
+    int phase = 0;  // 0: seed leaves, 1: tree walk
+    for (;;) {
+        u32 leaf = 0;
+        bool have = false;
+        if (phase == 0) {
+            if (seedcur < s1) {
+                leaf = seedcur++;
+                have = true;
+            }
+        } else {
+            do {
+                have = wk.next(t, need, leaf, st_expand);
+            } while (have && leaf >= s0 && leaf < s1);
+        }
+        // one compaction site: buffer nearly full, or a lane could have a finite tau now, or draining
+        bool trig;
+        if (have) trig = __ballot(cnt > KCAP || (tau == inf && cnt >= static_cast<int>(k))) != 0ull;
+        else trig = __ballot(cnt > 0) != 0ull;
+        if (trig) {
+            compact<KCAP, BUF>(best, col, cnt);
+            float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+            tau = valid ? nt : -1.f;
+            if (STATS) ++st_compact;
+            if (!have) continue;  // keep draining
+        }
+        if (!have) {
+            if (phase == 0) {
+                phase = 1;
+                wk.start(t, need);
+                continue;
+            }
+            break;
+        }
+        // ---- candidates of one leaf: SMEM broadcast, branch-free accept ----
+        if (STATS) ++st_leaves;
+        const Leaf lf = t.leaves[leaf];
+        const u32 posbase = leaf * LEAF;
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+            float d2 = sq3(dx, dy, dz);
+            float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+            float m2 = d2 <= tau ? m : -1.f;   // NaN padding points fail here
+            bool acc = m2 >= eps;               // outside the eps-box (eps >= 0)
+            int slot = acc ? cnt : BUF;
+            col[slot * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
+            cnt += acc ? 1 : 0;
+            if (STATS) st_app += acc ? 1u : 0u;
+        }
+    }
+
+    if (STATS) {
+        u32 app = st_app;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) app += __shfl_xor(app, off);
+        if (lane == 0) {
+            atomicAdd(&stats[0], static_cast<unsigned long long>(st_leaves));
+            atomicAdd(&stats[1], static_cast<unsigned long long>(st_expand));
+            atomicAdd(&stats[2], static_cast<unsigned long long>(st_compact));
+            atomicAdd(&stats[3], static_cast<unsigned long long>(app));
+            atomicAdd(&stats[4], 1ull);
+            atomicAdd(&stats[5], static_cast<unsigned long long>(s1 - s0));
+        }
+    }
+
+    // ---- sorted position -> original index; order rows by (d2, index) ----
+    const int first_slot = KCAP - static_cast<int>(k);
+    u32 pos[KCAP];
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) {
+        u64 key = best[s];
+        bool real = s >= first_slot && key != PAD_KEY;
+        u32 ps = real ? static_cast<u32>(key) : 0u;
+        pos[s] = ps;
+        u32 id = t.leaves[ps / LEAF].id[ps % LEAF];
+        best[s] = real ? ((key & 0xFFFFFFFF00000000ull) | id) : key;
+    }
+    bool unordered = false;
+#pragma unroll
+    for (int s = 0; s + 1 < KCAP; ++s) unordered |= best[s] > best[s + 1];
+    if (__ballot(unordered) != 0ull) bitonic_sort_payload<KCAP>(best, pos);  // exact-tie repair, rare
+
+    if (!valid) return;
+    u32 found = 0;
+    u32 okmask = 0;
+    const u64 ob = static_cast<u64>(row) * k;
+#pragma unroll
+    for (int s = 0; s < KCAP; ++s) {
+        int j = s - first_slot;
+        if (j >= 0) {
+            u64 key = best[s];
+            bool ok = key != PAD_KEY;
+            if (out_idx) out_idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
+            if (out_d2) out_d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
+            found += ok ? 1u : 0u;
+            okmask |= ok ? (1u << s) : 0u;
+        }
+    }
+    if (out_cnt) out_cnt[row] = found;
+
+    // ---- fused pcp::estimate_normal over the row (normal_estimation.hpp:41-77), coordinates gathered
+    //      from the leaf records in row order ----
+    if (out_nrm) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            bool ok = (okmask >> s) & 1u;
+            const Leaf& lf = t.leaves[pos[s] / LEAF];
+            float x = lf.x[pos[s] % LEAF], y = lf.y[pos[s] % LEAF], z = lf.z[pos[s] % LEAF];
+            sx += ok ? x : 0.f;
+            sy += ok ? y : 0.f;
+            sz += ok ? z : 0.f;
+        }
+        float fn = static_cast<float>(found);
+        float mx = sx / fn, my = sy / fn, mz = sz / fn;
+        float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            bool ok = (okmask >> s) & 1u;
+            const Leaf& lf = t.leaves[pos[s] / LEAF];
+            float x = lf.x[pos[s] % LEAF], y = lf.y[pos[s] % LEAF], z = lf.z[pos[s] % LEAF];
+            float vx = ok ? x - mx : 0.f, vy = ok ? y - my : 0.f, vz = ok ? z - mz : 0.f;
+            c00 += vx * vx;
+            c10 += vy * vx;
+            c11 += vy * vy;
+            c20 += vz * vx;
+            c21 += vz * vy;
+            c22 += vz * vz;
+        }
+        float nrm[3], ev[3];
+        eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
+        out_nrm[3ull * row] = nrm[0];
+        out_nrm[3ull * row + 1] = nrm[1];
+        out_nrm[3ull * row + 2] = nrm[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
+// every point with d2 <= r*r, query included)
+// ------------------------------------------------------------------------------------------------
+template <bool SELF, bool FILL>
+__global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
+                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
+                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
+    if (g >= group_end) return;
+    const u32 p = g * GROUP + lane;
+    const u32 nq = SELF ? t.n : qv.nq;
+    const bool valid = p < nq;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    u32 row = 0;
+    if (valid) {
+        if (SELF) {
+            const Leaf& lf = t.leaves[p / LEAF];
+            qx = lf.x[p % LEAF];
+            qy = lf.y[p % LEAF];
+            qz = lf.z[p % LEAF];
+            row = lf.id[p % LEAF];
+        } else {
+            qx = qv.qx[p];
+            qy = qv.qy[p];
+            qz = qv.qz[p];
+            row = qv.row[p];
+        }
+    }
+    float r = radius;
+    if (radii && valid) r = radii[row];
+    const float r2 = valid ? r * r : -1.f;  // sphere.hpp:34 radius * radius in float; -1: idle lane
+    u32 cnt = 0;
+    u64 wpos = (FILL && valid) ? offsets[row] : 0;
+    auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
+
+    Walker wk;
+    wk.start(t, need);
+    u32 leaf = 0, nexp = 0;
+    while (wk.next(t, need, leaf, nexp)) {
+        const Leaf lf = t.leaves[leaf];
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+            bool in = sq3(dx, dy, dz) <= r2;
+            if (FILL) {
+                if (in) out_idx[wpos + cnt] = lf.id[j];
+            }
+            cnt += in ? 1u : 0u;
+        }
+    }
+    if (valid && !FILL) out_cnt[row] = cnt;
+}
+
+// AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:
+// test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
+// (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
+                                                    u32* __restrict__ out_cnt, const u64* __restrict__ offsets,
+                                                    u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const u32 p = g * GROUP + lane;
+    const bool valid = p < nb;
+    // an idle lane gets an inverted box that contains and overlaps nothing
+    float b0 = 1.f, b1 = 1.f, b2 = 1.f, b3 = -1.f, b4 = -1.f, b5 = -1.f;
+    if (valid) {
+        b0 = boxes6[6ull * p]; b1 = boxes6[6ull * p + 1]; b2 = boxes6[6ull * p + 2];
+        b3 = boxes6[6ull * p + 3]; b4 = boxes6[6ull * p + 4]; b5 = boxes6[6ull * p + 5];
+    }
+    u32 cnt = 0;
+    u64 wpos = (FILL && valid) ? offsets[p] : 0;
+    auto need = [&](const NodeBox& n) {
+        bool o = (n.hi[0] >= b0) & (n.hi[1] >= b1) & (n.hi[2] >= b2) & (n.lo[0] <= b3) & (n.lo[1] <= b4) & (n.lo[2] <= b5);
+        return o & (n.poison == 0.f) & valid;
+    };
+    Walker wk;
+    wk.start(t, need);
+    u32 leaf = 0, nexp = 0;
+    while (wk.next(t, need, leaf, nexp)) {
+        const Leaf lf = t.leaves[leaf];
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float x = lf.x[j], y = lf.y[j], z = lf.z[j];
+            bool in = valid & (x >= b0) & (y >= b1) & (z >= b2) & (x <= b3) & (y <= b4) & (z <= b5);
+            if (FILL) {
+                if (in) out_idx[wpos + cnt] = lf.id[j];
+            }
+            cnt += in ? 1u : 0u;
+        }
+    }
+    if (valid && !FILL) out_cnt[p] = cnt;
+}
+
 // thread i handles neighbourhood row = rowmap ? rowmap[first+i] : first+i
 __global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, const u32* __restrict__ nbr,
                                                  const u32* __restrict__ cnt, const u32* __restrict__ rowmap, u64 first,
@@ -736,6 +847,8 @@ inline u32 grid_for_groups(u64 groups)
     return static_cast<u32>(blocks);
 }
 
+inline float sanitize_eps(float eps) { return eps > 0.f ? eps : 0.f; }  // eps <= 0 or NaN: nothing is "equal"
+
 }  // namespace
 
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
@@ -780,26 +893,42 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
 
 template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, u32* oi,
-                        u32* oc, float* od)
+                        u32* oc, float* od, float* on)
 {
     constexpr int BUF = KCAP + LEAF;
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * BUF * 64 * sizeof(u64);
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
     u32 grid = grid_for_groups(gcount);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     ProfileScope prof(ix, PCPX_K_KNN);
-    if (self) k_knn<KCAP, true><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od);
-    else k_knn<KCAP, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od);
+    if (self) k_knn<KCAP, true, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
+    else k_knn<KCAP, false, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
-               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2)
+               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2, float* d_out_normals)
 {
     if (group_count == 0) return PCPX_OK;
-    if (k <= 16) return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2);
-    if (k <= 32) return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2);
+    eps = sanitize_eps(eps);
+    if (k <= 16)
+        return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2, d_out_normals);
+    if (k <= 32)
+        return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2, d_out_normals);
     set_error("pcpx: k = %u > 32 is not supported yet", k);
     return PCPX_ERR_UNSUPPORTED;
+}
+
+// instrumented self-kNN (k <= 16): traversal statistics summed over all waves into d_stats[8]
+int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
+{
+    constexpr int KCAP = 16, BUF = KCAP + LEAF;
+    u64 groups = (ix.n + GROUP - 1) / GROUP;
+    if (groups == 0) return PCPX_OK;
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
+    k_knn<KCAP, true, true><<<grid_for_groups(groups), 256, lds, ix.stream>>>(
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), nullptr, nullptr, nullptr, nullptr, d_stats);
+    return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,

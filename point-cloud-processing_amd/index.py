@@ -219,6 +219,12 @@ class Index:
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 
+    def debug_knn_stats(self, k, eps=1e-5):
+        out = (C.c_uint64 * 8)()
+        check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out))
+        names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves"]
+        return {n: int(out[i]) for i, n in enumerate(names)}
+
     def profile_begin(self):
         check(self._lib.pcpx_profile_begin(self._h))
 
