@@ -168,85 +168,71 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
 }
 
 // ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
+__device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
 // All members are wave-uniform (SGPRs).  next() yields, in Morton order, every leaf whose box is still
-// needed by at least one lane at the time its parent is expanded.
+// needed by at least one lane at the time its parent is expanded.  State: `pend` holds one nibble per
+// height l = the children (height l) of the current ancestor at height l+1 that are still to visit;
+// `parent` is that ancestor's heap id.
 struct Walker {
-    u64 pend;     // nibble l = children (height l) of the current ancestor at height l+1 still to visit
-    u32 node;     // heap id of the node to expand (valid when expand)
-    u32 parent;   // heap id (height l+1) whose pending nibble is being consumed
-    int ht;       // height of `node`
+    u64 pend;
+    u32 parent;
     int l;
-    bool expand;
     bool done;
-    bool single;  // depth == 0: the root is the only leaf
 
     template <class Need>
-    __device__ __forceinline__ void start(const TreeView& t, Need&& need)
+    __device__ __forceinline__ u32 child_mask(const TreeView& t, u32 node, Need&& need)
+    {
+        const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1);
+        u32 m = 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
+        return m;
+    }
+
+    // returns true if the root itself is the single leaf (depth 0) and is needed
+    template <class Need>
+    __device__ __forceinline__ bool start(const TreeView& t, Need&& need, u32& n_expand)
     {
         pend = 0;
-        node = 0;
         parent = 0;
-        ht = t.depth;
-        l = t.depth;
-        expand = false;
-        single = false;
-        done = t.nleaves == 0;
-        if (done) return;
+        l = 0;
+        done = true;
+        if (t.nleaves == 0) return false;
         const NodeBox root = t.nodes[0];
-        bool go = __ballot(need(root)) != 0ull;
-        if (!go) {
-            done = true;
-        } else if (t.depth == 0) {
-            single = true;
-        } else {
-            expand = true;
-        }
+        if (!any_lane(need(root))) return false;
+        if (t.depth == 0) return true;
+        ++n_expand;
+        l = t.depth - 1;
+        pend = static_cast<u64>(child_mask(t, 0u, need)) << (W * l);
+        done = false;
+        return false;
     }
 
     template <class Need>
     __device__ __forceinline__ bool next(const TreeView& t, Need&& need, u32& leaf, u32& n_expand)
     {
-        if (done) return false;
-        if (single) {
-            single = false;
-            done = true;
-            leaf = 0;
-            return true;
-        }
-        for (;;) {
-            if (expand) {
-                expand = false;
-                ++n_expand;
-                const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1);
-                u32 m = 0;
-#pragma unroll
-                for (int c = 0; c < W; ++c)
-                    if (__ballot(need(cb.c[c])) != 0ull) m |= 1u << c;
-                l = ht - 1;
-                parent = node;
-                pend |= static_cast<u64>(m) << (W * l);
-            }
+        while (!done) {
             u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
-            if (mm) {
-                int b = __builtin_ctz(mm);
-                pend &= ~(1ull << (W * l + b));
-                u32 child = (parent << LOGW) + 1u + static_cast<u32>(b);
-                if (l == 0) {
-                    leaf = child - t.leaf0;
-                    return true;
-                }
-                node = child;
-                ht = l;
-                expand = true;
-            } else {
+            if (mm == 0) {
                 ++l;
-                if (l >= t.depth) {
-                    done = true;
-                    return false;
-                }
+                if (l >= t.depth) done = true;
                 parent = (parent - 1u) >> LOGW;
+                continue;
             }
+            u32 b = static_cast<u32>(__builtin_ctz(mm));
+            pend &= ~(1ull << (W * l + b));
+            u32 child = (parent << LOGW) + 1u + b;
+            if (l == 0) {
+                leaf = child - t.leaf0;
+                return true;
+            }
+            ++n_expand;
+            --l;
+            parent = child;
+            pend |= static_cast<u64>(child_mask(t, child, need)) << (W * l);
         }
+        return false;
     }
 };
 
@@ -474,57 +460,62 @@ __global__ __launch_bounds__(256, KCAP <= 16 ? 3 : 1) void k_knn(TreeView t, Que
     s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
     if (s0 > s1) s0 = s1;
 
+    // Single loop, single back-edge: each iteration fetches the next leaf (seed chunk first, then the
+    // tree walk), runs the one compaction site if needed, then the one candidate site.
     Walker wk;
+    wk.pend = 0;
+    wk.parent = 0;
+    wk.l = 0;
     wk.done = true;
     u32 seedcur = s0;
-    int phase = 0;  // 0: seed leaves, 1: tree walk
-    for (;;) {
+    bool walking = false;
+    bool running = true;
+    while (running) {
         u32 leaf = 0;
         bool have = false;
-        if (phase == 0) {
-            if (seedcur < s1) {
-                leaf = seedcur++;
-                have = true;
-            }
+        if (!walking) {
+            have = seedcur < s1;
+            leaf = seedcur;
+            seedcur += have ? 1u : 0u;
         } else {
             do {
                 have = wk.next(t, need, leaf, st_expand);
             } while (have && leaf >= s0 && leaf < s1);
         }
-        // one compaction site: buffer nearly full, or a lane could have a finite tau now, or draining
-        bool trig;
-        if (have) trig = __ballot(cnt > KCAP || (tau == inf && cnt >= static_cast<int>(k))) != 0ull;
-        else trig = __ballot(cnt > 0) != 0ull;
+        // compaction: buffer nearly full, or a lane could get a finite tau now, or draining at a phase end
+        bool trig = have ? any_lane(cnt > KCAP || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
             compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = valid ? nt : -1.f;
             if (STATS) ++st_compact;
-            if (!have) continue;  // keep draining
         }
-        if (!have) {
-            if (phase == 0) {
-                phase = 1;
-                wk.start(t, need);
-                continue;
-            }
-            break;
-        }
-        // ---- candidates of one leaf: SMEM broadcast, branch-free accept ----
-        if (STATS) ++st_leaves;
-        const Leaf lf = t.leaves[leaf];
-        const u32 posbase = leaf * LEAF;
+        if (have) {
+            // ---- candidates of one leaf: SMEM broadcast, branch-free accept ----
+            if (STATS) ++st_leaves;
+            const Leaf lf = t.leaves[leaf];
+            const u32 posbase = leaf * LEAF;
 #pragma unroll
-        for (int j = 0; j < LEAF; ++j) {
-            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-            float d2 = sq3(dx, dy, dz);
-            float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-            float m2 = d2 <= tau ? m : -1.f;   // NaN padding points fail here
-            bool acc = m2 >= eps;               // outside the eps-box (eps >= 0)
-            int slot = acc ? cnt : BUF;
-            col[slot * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
-            cnt += acc ? 1 : 0;
-            if (STATS) st_app += acc ? 1u : 0u;
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                float d2 = sq3(dx, dy, dz);
+                float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
+                bool acc = m2 >= eps;              // outside the eps-box (eps >= 0)
+                int slot = acc ? cnt : BUF;
+                col[slot * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
+                cnt += acc ? 1 : 0;
+                if (STATS) st_app += acc ? 1u : 0u;
+            }
+        } else if (!trig) {
+            // drained: seed chunk -> tree walk -> finished
+            if (!walking) {
+                walking = true;
+                bool root_leaf = wk.start(t, need, st_expand);
+                (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
+            } else {
+                running = false;
+            }
         }
     }
 
@@ -557,7 +548,7 @@ __global__ __launch_bounds__(256, KCAP <= 16 ? 3 : 1) void k_knn(TreeView t, Que
     bool unordered = false;
 #pragma unroll
     for (int s = 0; s + 1 < KCAP; ++s) unordered |= best[s] > best[s + 1];
-    if (__ballot(unordered) != 0ull) bitonic_sort_payload<KCAP>(best, pos);  // exact-tie repair, rare
+    if (any_lane(unordered)) bitonic_sort_payload<KCAP>(best, pos);  // exact-tie repair, rare
 
     if (!valid) return;
     u32 found = 0;
@@ -653,9 +644,10 @@ __global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 gro
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
 
     Walker wk;
-    wk.start(t, need);
     u32 leaf = 0, nexp = 0;
-    while (wk.next(t, need, leaf, nexp)) {
+    bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
+    if (!more) more = wk.next(t, need, leaf, nexp);
+    while (more) {
         const Leaf lf = t.leaves[leaf];
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
@@ -666,6 +658,7 @@ __global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 gro
             }
             cnt += in ? 1u : 0u;
         }
+        more = wk.next(t, need, leaf, nexp);
     }
     if (valid && !FILL) out_cnt[row] = cnt;
 }
@@ -695,9 +688,10 @@ __global__ __launch_bounds__(256) void k_range_aabb(TreeView t, const float* __r
         return o & (n.poison == 0.f) & valid;
     };
     Walker wk;
-    wk.start(t, need);
     u32 leaf = 0, nexp = 0;
-    while (wk.next(t, need, leaf, nexp)) {
+    bool more = wk.start(t, need, nexp);
+    if (!more) more = wk.next(t, need, leaf, nexp);
+    while (more) {
         const Leaf lf = t.leaves[leaf];
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
@@ -708,6 +702,7 @@ __global__ __launch_bounds__(256) void k_range_aabb(TreeView t, const float* __r
             }
             cnt += in ? 1u : 0u;
         }
+        more = wk.next(t, need, leaf, nexp);
     }
     if (valid && !FILL) out_cnt[p] = cnt;
 }
