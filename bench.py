@@ -207,14 +207,16 @@ def main():
         launches, total_ms = prof["knn"]
         avg_s = total_ms / launches / 1e3
         q_per_launch = main_res["shard"][1]
-        bytes_per_q = 12 + 4 * k  # kNN = 12 B read + 4k B index write per query
+        # kNN + normals with the indices also written = 12 B read + 4k B index
+        # write + 12 B normal write per query (84 B at k = 15); the fused k_knn launch does exactly that
+        bytes_per_q = 12 + 4 * k + 12
         achieved = q_per_launch * bytes_per_q / avg_s
         roofline = {"bound": "hbm", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_query": bytes_per_q, "queries_per_launch": q_per_launch,
-                    "note": "k_knn is VALU/LDS bound (wave-uniform traversal + register bitonic merges), not HBM "
-                            "bound: see DESIGN.md; traffic = PMC HBM bytes per launch from profiles/ when collected"}
+                    "note": "fused kNN+normals kernel; it is instruction-issue (VALU+SALU) bound, not HBM bound: see "
+                            "DESIGN.md 'Roofline'; traffic = PMC HBM bytes per launch (profiles/r01_hbm_traffic.json)"}
         traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpcpx.so")
+LIB_PATH = os.environ.get("PCPX_LIB") or os.path.join(HERE, "libpcpx.so")  # PCPX_LIB: tuning variants (tools/)
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

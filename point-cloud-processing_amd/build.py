@@ -17,7 +17,10 @@ HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(INCLUDE, "pcpx.h"
 ARCH = "gfx950"
 # -ffp-contract=off: the reference evaluates dx*dx+dy*dy+dz*dz without FMA; neighbour order and the
 # eigen-solver restatement are only bit-comparable with it if the GPU does not fuse either.
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-I" + INCLUDE]
+# -fno-slp-vectorize: SLP packs the scalar f32 distance code into v_pk_* ops plus v_mov shuffles; packed
+# f32 is not faster than scalar VALU on gfx950 and the shuffles cost ~4 % (measured, tools/ab_variants.py).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=" + ARCH,
+         "-I" + INCLUDE]
 
 
 def _hipcc():
@@ -34,25 +37,29 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force=False, verbose=False, extra_flags=(), tag=""):
+    """tag/extra_flags build a tuning variant libpcpx_<tag>.so (tools/ab_variants.py); the default build
+    has neither."""
+    obj_dir = OBJ_DIR + ("_" + tag if tag else "")
+    lib = LIB if not tag else os.path.join(HERE, "libpcpx_%s.so" % tag)
+    os.makedirs(obj_dir, exist_ok=True)
     objs = []
     hipcc = _hipcc()
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

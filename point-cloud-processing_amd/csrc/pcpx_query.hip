@@ -39,7 +39,10 @@ namespace pcpx {
 namespace {
 
 constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID): larger than every real key, a finite double
-constexpr int WAVES_PER_BLOCK = 4;
+#ifndef PCPX_WPB
+#define PCPX_WPB 1
+#endif
+constexpr int WAVES_PER_BLOCK = PCPX_WPB;  // 1: a finished wave frees its LDS at once (no intra-block tail)
 
 __device__ __forceinline__ u32 wave_in_block() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
@@ -148,16 +151,24 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
     }
 }
 
+// Rows of the per-lane append buffer.  A leaf may append LEAF keys, so a compaction runs whenever a
+// lane holds more than BUF - LEAF keys; fewer rows = less LDS per wave = more resident waves.
+#ifndef PCPX_BUF16
+#define PCPX_BUF16 15  // measured on MI355X (10 M uniform, k=15): 24 rows 416, 20 rows 451, 16 rows 490, 15 rows 512, 10 rows 489 Mq/s
+#endif
+__host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 16 ? PCPX_BUF16 : kcap + LEAF; }
+
 // Fold the first KCAP buffered keys of this lane into its sorted best-list; leftovers move down.
 // All LDS traffic is unconditional (stale slots are masked to PAD_KEY in registers): no exec games.
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
     u64 nw[KCAP];
+    constexpr int TAKE = BUF < KCAP ? BUF : KCAP;
 #pragma unroll
-    for (int j = 0; j < KCAP; ++j) nw[j] = col[j * 64];
+    for (int j = 0; j < KCAP; ++j) nw[j] = j < TAKE ? col[j * 64] : PAD_KEY;
 #pragma unroll
-    for (int j = 0; j < KCAP; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
+    for (int j = 0; j < TAKE; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
 #pragma unroll
     for (int j = 0; j < BUF - KCAP; ++j) col[j * 64] = col[(KCAP + j) * 64];
     cnt = cnt > KCAP ? cnt - KCAP : 0;
@@ -406,13 +417,16 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 // ------------------------------------------------------------------------------------------------
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
+#ifndef PCPX_MINW
+#define PCPX_MINW 1
+#endif
 template <int KCAP, bool SELF, bool STATS>
-__global__ __launch_bounds__(256, KCAP <= 16 ? 3 : 1) void k_knn(TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) void k_knn(TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k,
                                              float eps, u32* __restrict__ out_idx, u32* __restrict__ out_cnt,
                                              float* __restrict__ out_d2, float* __restrict__ out_nrm,
                                              unsigned long long* __restrict__ stats)
 {
-    constexpr int BUF = KCAP + LEAF;  // usable rows; row BUF is the trash row
+    constexpr int BUF = buf_rows(KCAP);  // usable rows; row BUF is the trash row
     extern __shared__ u64 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = wave_in_block();
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(256, KCAP <= 16 ? 3 : 1) void k_knn(TreeView t, Que
             } while (have && leaf >= s0 && leaf < s1);
         }
         // compaction: buffer nearly full, or a lane could get a finite tau now, or draining at a phase end
-        bool trig = have ? any_lane(cnt > KCAP || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
+        bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
             compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(256, KCAP <= 16 ? 3 : 1) void k_knn(TreeView t, Que
 // every point with d2 <= r*r, query included)
 // ------------------------------------------------------------------------------------------------
 template <bool SELF, bool FILL>
-__global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
                                                const float* __restrict__ radii, u32* __restrict__ out_cnt,
                                                const u64* __restrict__ offsets, u32* __restrict__ out_idx)
 {
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(256) void k_range(TreeView t, QueryView qv, u32 gro
 // test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
 // (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
                                                     u32* __restrict__ out_cnt, const u64* __restrict__ offsets,
                                                     u32* __restrict__ out_idx)
 {
@@ -890,13 +904,13 @@ template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, u32* oi,
                         u32* oc, float* od, float* on)
 {
-    constexpr int BUF = KCAP + LEAF;
+    constexpr int BUF = buf_rows(KCAP);
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
     u32 grid = grid_for_groups(gcount);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     ProfileScope prof(ix, PCPX_K_KNN);
-    if (self) k_knn<KCAP, true, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
-    else k_knn<KCAP, false, false><<<grid, 256, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
+    if (self) k_knn<KCAP, true, false><<<grid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
+    else k_knn<KCAP, false, false><<<grid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
@@ -916,12 +930,12 @@ int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 g
 // instrumented self-kNN (k <= 16): traversal statistics summed over all waves into d_stats[8]
 int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
 {
-    constexpr int KCAP = 16, BUF = KCAP + LEAF;
+    constexpr int KCAP = 16, BUF = buf_rows(KCAP);
     u64 groups = (ix.n + GROUP - 1) / GROUP;
     if (groups == 0) return PCPX_OK;
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
-    k_knn<KCAP, true, true><<<grid_for_groups(groups), 256, lds, ix.stream>>>(
+    k_knn<KCAP, true, true><<<grid_for_groups(groups), 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
         ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), nullptr, nullptr, nullptr, nullptr, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
@@ -934,9 +948,9 @@ int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_firs
     u32 gf = static_cast<u32>(group_first), ge = static_cast<u32>(group_first + group_count);
     ProfileScope prof(ix, PCPX_K_RANGE);
     if (self)
-        k_range<true, false><<<grid, 256, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
+        k_range<true, false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
     else
-        k_range<false, false><<<grid, 256, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
+        k_range<false, false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
     return check_hip(hipGetLastError(), "k_range launch", __FILE__, __LINE__);
 }
 
@@ -946,7 +960,7 @@ int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float*
     u64 groups = (static_cast<u64>(qv.nq) + GROUP - 1) / GROUP;
     if (groups == 0) return PCPX_OK;
     ProfileScope prof(ix, PCPX_K_RANGE);
-    k_range<false, true><<<grid_for_groups(groups), 256, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
+    k_range<false, true><<<grid_for_groups(groups), 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
                                                                            d_radii, nullptr, d_offsets, d_out_idx);
     return check_hip(hipGetLastError(), "k_range fill launch", __FILE__, __LINE__);
 }
@@ -954,18 +968,18 @@ int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float*
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt)
 {
     if (nb == 0) return PCPX_OK;
-    u32 grid = static_cast<u32>((nb + 255) / 256);
+    u32 grid = static_cast<u32>((nb + 64 * WAVES_PER_BLOCK - 1) / (64 * WAVES_PER_BLOCK));
     ProfileScope prof(ix, PCPX_K_RANGE);
-    k_range_aabb<false><<<grid, 256, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), d_out_cnt, nullptr, nullptr);
+    k_range_aabb<false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), d_out_cnt, nullptr, nullptr);
     return check_hip(hipGetLastError(), "k_range_aabb launch", __FILE__, __LINE__);
 }
 
 int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx)
 {
     if (nb == 0) return PCPX_OK;
-    u32 grid = static_cast<u32>((nb + 255) / 256);
+    u32 grid = static_cast<u32>((nb + 64 * WAVES_PER_BLOCK - 1) / (64 * WAVES_PER_BLOCK));
     ProfileScope prof(ix, PCPX_K_RANGE);
-    k_range_aabb<true><<<grid, 256, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), nullptr, d_offsets, d_out_idx);
+    k_range_aabb<true><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), nullptr, d_offsets, d_out_idx);
     return check_hip(hipGetLastError(), "k_range_aabb fill launch", __FILE__, __LINE__);
 }
 
