@@ -1,0 +1,6 @@
+// drop-in for include/pcp/algorithm/algorithm.hpp (hot-path subset)
+#ifndef PCP_ALGORITHM_ALGORITHM_HPP
+#define PCP_ALGORITHM_ALGORITHM_HPP
+#include "pcp/algorithm/common.hpp"
+#include "pcp/algorithm/estimate_normals.hpp"
+#endif

@@ -1,0 +1,192 @@
+// pcp::kdtree::construction_params_t / pcp::basic_linked_kdtree_t -- drop-in for
+// include/pcp/kdtree/linked_kdtree.hpp:24-33 and :64-560 of the reference, for construction,
+// nearest_neighbours (coordinates and element overloads), range_search, aabb(), size/empty/clear and
+// begin()/end().
+//
+// Same template parameters <Element, K, CoordinateMap>, constructor, member names and result conventions
+// (ascending kNN, eps-coincident points skipped per coordinate, range results unordered and including the
+// query point).  Only K == 3 with float coordinates is the hot path and is what is implemented.  The
+// construction parameters are accepted for source compatibility: they shaped the reference's median-split
+// tree (depth, leaf size), not the query results.  Storage keeps the elements in input order (the
+// reference permutes its storage with nth_element; that order was never specified).
+#ifndef PCP_KDTREE_LINKED_KDTREE_HPP
+#define PCP_KDTREE_LINKED_KDTREE_HPP
+
+#include "pcp/common/axis_aligned_bounding_box.hpp"
+#include "pcp/common/sphere.hpp"
+#include "pcp/gpu/device_index.hpp"
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+namespace pcp {
+
+namespace kdtree {
+enum class construction_t { nth_element, presort };
+
+struct construction_params_t
+{
+    std::size_t max_depth                           = 12u;
+    construction_t construction                     = construction_t::nth_element;
+    std::size_t min_element_count_for_parallel_exec = 32'768;
+    bool compute_max_depth                          = false;
+    std::size_t max_elements_per_leaf               = 64u;
+};
+} // namespace kdtree
+
+template <class Element, std::size_t K, class CoordinateMap>
+class basic_linked_kdtree_t
+{
+    static_assert(K == 3, "the GPU hot path indexes 3-dimensional points");
+
+  public:
+    using self_type        = basic_linked_kdtree_t;
+    using element_type     = Element;
+    using coordinates_type = std::invoke_result_t<CoordinateMap, Element>;
+    using coordinate_type  = typename coordinates_type::value_type;
+    using aabb_type        = kd_axis_aligned_bounding_box_t<coordinate_type, K>;
+    using iterator         = typename std::vector<element_type>::iterator;
+    using const_iterator   = typename std::vector<element_type>::const_iterator;
+    using value_type       = element_type;
+    using reference        = value_type&;
+    using const_reference  = value_type const&;
+    using size_type        = typename std::vector<element_type>::size_type;
+
+    template <class ForwardIter>
+    basic_linked_kdtree_t(ForwardIter begin, ForwardIter end, CoordinateMap coordinate_map = CoordinateMap{},
+                          kdtree::construction_params_t params = kdtree::construction_params_t{})
+        : storage_(begin, end), coordinate_map_(coordinate_map), params_(params)
+    {
+        xyz_.reserve(storage_.size() * 3);
+        for (auto const& e : storage_)
+        {
+            auto const c = coordinate_map_(e);
+            xyz_.push_back(static_cast<float>(c[0]));
+            xyz_.push_back(static_cast<float>(c[1]));
+            xyz_.push_back(static_cast<float>(c[2]));
+        }
+        aabb_ = kd_bounding_box<coordinate_type, K, CoordinateMap, const_iterator>(storage_.cbegin(), storage_.cend(),
+                                                                                  coordinate_map_);
+    }
+    basic_linked_kdtree_t(self_type&&) = default;
+    self_type& operator=(self_type&&) = default;
+
+    bool empty() const { return storage_.empty(); }
+    std::size_t size() const { return storage_.size(); }
+    void clear()
+    {
+        storage_.clear();
+        xyz_.clear();
+        index_.reset();
+    }
+    iterator begin() { return storage_.begin(); }
+    iterator end() { return storage_.end(); }
+    const_iterator cbegin() const { return storage_.cbegin(); }
+    const_iterator cend() const { return storage_.cend(); }
+    aabb_type const& aabb() const { return aabb_; }
+
+    std::vector<element_type> nearest_neighbours(coordinates_type const& target, std::size_t k,
+                                                 coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
+    {
+        if (k == 0 || storage_.empty()) return {};
+        float const q[3] = {static_cast<float>(target[0]), static_cast<float>(target[1]), static_cast<float>(target[2])};
+        auto const r = index().knn(q, 1, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+        return gather(r.idx.data(), r.count[0]);
+    }
+    std::vector<element_type> nearest_neighbours(element_type const& element_target, std::size_t k,
+                                                 coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
+    {
+        return nearest_neighbours(coordinate_map_(element_target), k, eps);
+    }
+
+    template <class Range>
+    std::vector<element_type> range_search(Range const& range) const
+    {
+        if (storage_.empty()) return {};
+        std::vector<std::uint64_t> off;
+        std::vector<std::uint32_t> idx;
+        if constexpr (std::is_same_v<Range, sphere_a<coordinate_type>>)
+        {
+            float const c[3] = {static_cast<float>(range.position[0]), static_cast<float>(range.position[1]),
+                                static_cast<float>(range.position[2])};
+            float const r = static_cast<float>(range.radius);
+            index().range_spheres(c, &r, 1, off, idx);
+        }
+        else if constexpr (std::is_same_v<Range, aabb_type>)
+        {
+            float const b[6] = {static_cast<float>(range.min[0]), static_cast<float>(range.min[1]), static_cast<float>(range.min[2]),
+                                static_cast<float>(range.max[0]), static_cast<float>(range.max[1]), static_cast<float>(range.max[2])};
+            index().range_boxes(b, 1, off, idx);
+        }
+        else
+        {
+            std::vector<element_type> out;
+            for (auto const& e : storage_)
+                if (range.contains(coordinate_map_(e))) out.push_back(e);
+            return out;
+        }
+        return gather(idx.data(), idx.size());
+    }
+
+    // ---- batched additions --------------------------------------------------------------------
+    template <class ForwardIter>
+    std::vector<std::vector<element_type>> nearest_neighbours_batch(ForwardIter begin, ForwardIter end, std::size_t k,
+                                                                    coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
+    {
+        std::vector<float> q;
+        for (; begin != end; ++begin)
+        {
+            auto const c = coordinate_map_(*begin);
+            q.push_back(static_cast<float>(c[0]));
+            q.push_back(static_cast<float>(c[1]));
+            q.push_back(static_cast<float>(c[2]));
+        }
+        std::size_t const nq = q.size() / 3;
+        std::vector<std::vector<element_type>> rows(nq);
+        if (k == 0 || storage_.empty() || nq == 0) return rows;
+        auto const r = index().knn(q.data(), nq, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+        for (std::size_t i = 0; i < nq; ++i) rows[i] = gather(r.idx.data() + i * k, r.count[i]);
+        return rows;
+    }
+    std::vector<std::uint32_t> range_count_self(float radius) const
+    {
+        if (storage_.empty()) return {};
+        return index().range_count(xyz_.data(), storage_.size(), radius);
+    }
+
+    gpu::device_index_t const& index() const
+    {
+        std::lock_guard<std::mutex> lock(*mutex_);
+        if (!index_.valid()) index_.build(xyz_.data(), storage_.size());
+        return index_;
+    }
+    std::vector<float> const& coordinates() const { return xyz_; }
+    element_type const& element(std::size_t i) const { return storage_[i]; }
+    CoordinateMap const& coordinate_map() const { return coordinate_map_; }
+
+  private:
+    std::vector<element_type> gather(std::uint32_t const* idx, std::size_t n) const
+    {
+        std::vector<element_type> out;
+        out.reserve(n);
+        for (std::size_t i = 0; i < n; ++i) out.push_back(storage_[idx[i]]);
+        return out;
+    }
+
+    std::vector<element_type> storage_;
+    std::vector<float> xyz_;
+    CoordinateMap coordinate_map_;
+    kdtree::construction_params_t params_;
+    aabb_type aabb_{};
+    mutable gpu::device_index_t index_;
+    mutable std::unique_ptr<std::mutex> mutex_ = std::make_unique<std::mutex>();
+};
+
+} // namespace pcp
+
+#endif

@@ -5,9 +5,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
     n = r["Name"]
-    m = re.search(r"(k_[a-z_0-9]+(<[^>]*>)?)", n)
+    m = re.search(r"pcpx::\(anonymous namespace\)::(k_[a-z_0-9]+(<[^>]*>)?)", n)
     if m: n = m.group(1)
     elif "radix_sort_onesweep_iteration" in n: n = "rocprim::radix_sort_onesweep_iteration"
     elif "onesweep_histograms" in n: n = "rocprim::radix_sort_onesweep_histograms"
+    elif "rocprim" in n: n = "rocprim::(other)"
     else: n = n[:46]
     print("%-46s %6s %14s %12.0f %7.2f" % (n[:46], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), float(r["Percentage"])))
