@@ -110,6 +110,7 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_nodes);
     (void)hipFree(ix->d_scalars);
     (void)hipFree(ix->d_scratch);
+    (void)hipFree(ix->d_queue);
     if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }

@@ -106,6 +106,8 @@ struct Index {
     bool profiling = false;
     std::vector<Interval> intervals;
 
+    u32* d_queue = nullptr;  // work-queue counters of the persistent query kernels
+
     // scratch for batch queries (grown on demand)
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;

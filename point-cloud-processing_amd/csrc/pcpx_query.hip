@@ -178,6 +178,51 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
     bitonic_merge<KCAP>(best);
 }
 
+// ---- exec-masked append (hand-written: hipcc has no way to emit v_cmpx from C++) ---------------------
+// Appends key (d2, pos) to the lane's LDS column at byte address `wa` iff d2 <= tau and m >= eps, then
+// advances wa by one row (512 B).  v_cmpx writes EXEC directly, so the two tests cost 2 VALU and the LDS
+// write and the address bump simply run under the narrowed EXEC; EXEC is restored before leaving.
+// The C++ equivalent (two compares, three selects, address math, count) costs 9 VALU per candidate.
+// gfx9 v_cmpx also writes VCC.  No wait states are needed between the VALU EXEC write and the DS issue.
+#ifndef PCPX_ASM_ACCEPT
+#define PCPX_ASM_ACCEPT 1
+#endif
+__device__ __forceinline__ void append_if(float d2, float tau, float m, float eps, u32 pos, u32& wa)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                 "v_cmpx_le_f32_e32 %[eps], %[m]\n\t"
+                 "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                 "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [wa] "+v"(wa), [sv] "=&s"(saved)
+                 : [d2] "v"(d2), [tau] "v"(tau), [m] "v"(m), [eps] "s"(eps), [pos] "v"(pos)
+                 : "vcc", "memory");
+}
+
+// Index records (leaves, node boxes) are immutable while a query kernel runs.  Reading them through
+// constant-address-space pointers makes every wave-uniform read a scalar (SMEM) load unconditionally;
+// through generic pointers hipcc only does that while it can prove no store (or asm with a memory
+// clobber, like append_if) may alias them.
+template <class T>
+__device__ __forceinline__ T load_const(const T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "record size");
+    typedef const __attribute__((address_space(4))) u32* const_u32_ptr;
+    const_u32_ptr c = (const_u32_ptr)(reinterpret_cast<uintptr_t>(p));
+    T out;
+    u32* o = reinterpret_cast<u32*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = c[i];
+    return out;
+}
+
+__device__ __forceinline__ u32 lds_address(const void* p)
+{
+    return static_cast<u32>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS pointer = LDS offset
+}
+
 // ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
 __device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
@@ -194,7 +239,11 @@ struct Walker {
     template <class Need>
     __device__ __forceinline__ u32 child_mask(const TreeView& t, u32 node, Need&& need)
     {
+#if defined(PCPX_NODE_VMEM)
         const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1);
+#else
+        const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1));
+#endif
         u32 m = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
@@ -210,7 +259,7 @@ struct Walker {
         l = 0;
         done = true;
         if (t.nleaves == 0) return false;
-        const NodeBox root = t.nodes[0];
+        const NodeBox root = load_const(t.nodes);
         if (!any_lane(need(root))) return false;
         if (t.depth == 0) return true;
         ++n_expand;
@@ -418,21 +467,16 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
 #ifndef PCPX_MINW
-#define PCPX_MINW 1
+#define PCPX_MINW 5  // <= 96 VGPRs for the k <= 16 kernel: 5 waves/SIMD, what 8 KB of LDS per wave also allows
 #endif
+// One query group (64 Morton-consecutive queries, one per lane) from start to finish.
 template <int KCAP, bool SELF, bool STATS>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) void k_knn(TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k,
-                                             float eps, u32* __restrict__ out_idx, u32* __restrict__ out_cnt,
-                                             float* __restrict__ out_d2, float* __restrict__ out_nrm,
-                                             unsigned long long* __restrict__ stats)
+__device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k, const float eps,
+                                          u32* __restrict__ out_idx, u32* __restrict__ out_cnt, float* __restrict__ out_d2,
+                                          float* __restrict__ out_nrm, unsigned long long* __restrict__ stats,
+                                          u64* __restrict__ col, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows; row BUF is the trash row
-    extern __shared__ u64 lds[];
-    const u32 lane = threadIdx.x & 63u;
-    const u32 wib = wave_in_block();
-    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wib;
-    if (g >= group_end) return;
-    u64* col = lds + static_cast<size_t>(wib) * (BUF + 1) * 64 + lane;
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
     u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0;
@@ -464,6 +508,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
     const float inf = std::numeric_limits<float>::infinity();
     float tau = valid ? inf : -1.f;  // -1: an idle lane never accepts a candidate nor needs a node
     int cnt = 0;
+    const u32 col_addr = lds_address(col);  // byte address of row 0 of this lane's column
+    u32 wa = col_addr;                      // byte address of the next free row (PCPX_ASM_ACCEPT)
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
 
@@ -497,29 +543,40 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
             } while (have && leaf >= s0 && leaf < s1);
         }
         // compaction: buffer nearly full, or a lane could get a finite tau now, or draining at a phase end
+        if (PCPX_ASM_ACCEPT) cnt = static_cast<int>((wa - col_addr) >> 9);
         bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
             compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = valid ? nt : -1.f;
+            wa = col_addr + (static_cast<u32>(cnt) << 9);
             if (STATS) ++st_compact;
         }
         if (have) {
             // ---- candidates of one leaf: SMEM broadcast, branch-free accept ----
             if (STATS) ++st_leaves;
-            const Leaf lf = t.leaves[leaf];
+#if defined(PCPX_LEAF_VMEM)
+            const Leaf lf = t.leaves[leaf];  // experiment: vector-memory path (uniform address)
+#else
+            const Leaf lf = load_const(t.leaves + leaf);
+#endif
             const u32 posbase = leaf * LEAF;
 #pragma unroll
             for (int j = 0; j < LEAF; ++j) {
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
                 float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+#if PCPX_ASM_ACCEPT
+                if (STATS) st_app += (d2 <= tau && m >= eps) ? 1u : 0u;
+                append_if(d2, tau, m, eps, posbase + j, wa);  // NaN padding points fail d2 <= tau
+#else
                 float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
                 bool acc = m2 >= eps;              // outside the eps-box (eps >= 0)
                 int slot = acc ? cnt : BUF;
                 col[slot * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
                 cnt += acc ? 1 : 0;
                 if (STATS) st_app += acc ? 1u : 0u;
+#endif
             }
         } else if (!trig) {
             // drained: seed chunk -> tree walk -> finished
@@ -619,6 +676,44 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
     }
 }
 
+// Persistent launch: the grid is exactly the number of waves the GPU can hold, and every wave pulls query
+// groups from work queues until they are empty (group run times differ by 2-3x, so a static assignment
+// would leave a long tail, and 156 k single-wave workgroups per 10 M queries need not go through the
+// dispatcher).  There is one queue per XCD-sized eighth of the Morton order (blocks b and b+8 share an XCD,
+// so its L2 keeps serving one region); a wave drains its home queue first, then helps the others.  Counters
+// sit on separate 64-B lines and are zeroed before each launch.  Measured equal to one group per workgroup
+// on MI355X (19.0 vs 19.1 ms); note rocprofv3's MeanOccupancyPerCU reads 11.5 of 20 for both, i.e. it
+// under-reports on gfx950 (this grid is fully resident by construction).
+constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
+
+template <int KCAP, bool SELF, bool STATS>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) void k_knn(
+    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, u32* __restrict__ out_idx,
+    u32* __restrict__ out_cnt, float* __restrict__ out_d2, float* __restrict__ out_nrm, u32* __restrict__ queue,
+    unsigned long long* __restrict__ stats)
+{
+    constexpr int BUF = buf_rows(KCAP);
+    extern __shared__ u64 lds[];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wib = wave_in_block();
+    u64* col = lds + static_cast<size_t>(wib) * (BUF + 1) * 64 + lane;
+    const u32 ngroups = group_end - group_first;
+    const u32 per = (ngroups + 7u) >> 3;
+    const u32 home = blockIdx.x & 7u;
+    for (u32 s = 0; s < 8u; ++s) {
+        const u32 q = (home + s) & 7u;
+        const u32 qbeg = q * per;
+        const u32 qend = qbeg + per < ngroups ? qbeg + per : ngroups;
+        for (;;) {
+            u32 gi = 0;
+            if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
+            gi = __builtin_amdgcn_readfirstlane(gi);
+            if (qbeg + gi >= qend) break;
+            knn_group<KCAP, SELF, STATS>(t, qv, group_first + qbeg + gi, k, eps, out_idx, out_cnt, out_d2, out_nrm, stats, col, lane);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
 // every point with d2 <= r*r, query included)
@@ -662,7 +757,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, Quer
     bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
     if (!more) more = wk.next(t, need, leaf, nexp);
     while (more) {
-        const Leaf lf = t.leaves[leaf];
+        const Leaf lf = load_const(t.leaves + leaf);
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
             float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
@@ -706,7 +801,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
     bool more = wk.start(t, need, nexp);
     if (!more) more = wk.next(t, need, leaf, nexp);
     while (more) {
-        const Leaf lf = t.leaves[leaf];
+        const Leaf lf = load_const(t.leaves + leaf);
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
             float x = lf.x[j], y = lf.y[j], z = lf.z[j];
@@ -858,6 +953,28 @@ inline u32 grid_for_groups(u64 groups)
 
 inline float sanitize_eps(float eps) { return eps > 0.f ? eps : 0.f; }  // eps <= 0 or NaN: nothing is "equal"
 
+// zeroed work-queue counters for one persistent launch (stream-ordered)
+int prepare_queue(Index& ix)
+{
+    if (!ix.d_queue) PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix.d_queue), 8 * QUEUE_STRIDE * sizeof(u32)));
+    PCPX_HIP(hipMemsetAsync(ix.d_queue, 0, 8 * QUEUE_STRIDE * sizeof(u32), ix.stream));
+    return PCPX_OK;
+}
+
+// number of workgroups that are resident at once (occupancy API x CUs), never more than there is work
+u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups)
+{
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    u64 want = static_cast<u64>(per_cu) * cus;
+    u64 need = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    u64 g = want < need ? want : need;
+    g = (g + 7) / 8 * 8;
+    return static_cast<u32>(g < 8 ? 8 : g);
+}
+
 }  // namespace
 
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
@@ -908,9 +1025,14 @@ static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
     u32 grid = grid_for_groups(gcount);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
+    int st = prepare_queue(ix);
+    if (st != PCPX_OK) return st;
+    (void)grid;
+    const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false>) : reinterpret_cast<const void*>(k_knn<KCAP, false, false>);
+    u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount);
     ProfileScope prof(ix, PCPX_K_KNN);
-    if (self) k_knn<KCAP, true, false><<<grid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
-    else k_knn<KCAP, false, false><<<grid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, nullptr);
+    if (self) k_knn<KCAP, true, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, ix.d_queue, nullptr);
+    else k_knn<KCAP, false, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, ix.d_queue, nullptr);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
@@ -935,8 +1057,11 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
     if (groups == 0) return PCPX_OK;
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
-    k_knn<KCAP, true, true><<<grid_for_groups(groups), 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), nullptr, nullptr, nullptr, nullptr, d_stats);
+    int st = prepare_queue(ix);
+    if (st != PCPX_OK) return st;
+    u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WAVES_PER_BLOCK, lds, groups);
+    k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), nullptr, nullptr, nullptr, nullptr, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 
