@@ -168,6 +168,9 @@ typedef struct pcpx_profile {
 /* Diagnostic build of the self-kNN kernel (k <= 16): out_stats = {leaves visited, node expansions,
  * compactions, keys appended, wavefronts, seed leaves, 0, 0} summed over the launch. */
 int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t out_stats[8]);
+/* Diagnostic access to the build's radix sort: stable sort of (key, value) pairs by key. */
+int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
+                          uint32_t* out_vals);
 int pcpx_profile_begin(pcpx_index* idx);
 int pcpx_profile_end(pcpx_index* idx, pcpx_profile* out);
 

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ_DIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libpcpx.so")
-SOURCES = ["pcpx_query.hip", "pcpx_build.hip", "pcpx_api.hip"]
+SOURCES = ["pcpx_query.hip", "pcpx_build.hip", "pcpx_sort.hip", "pcpx_api.hip"]
 HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(INCLUDE, "pcpx.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the reference evaluates dx*dx+dy*dy+dz*dz without FMA; neighbour order and the

@@ -611,6 +611,31 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t out_stat
     return PCPX_OK;
 }
 
+int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
+                          uint32_t* out_vals)
+{
+    int st = select_device(device);
+    if (st != PCPX_OK) return st;
+    if (n > 0 && (!keys || !vals || !out_keys || !out_vals)) return PCPX_ERR_INVALID;
+    size_t tb = 0;
+    if ((st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, nullptr)) != PCPX_OK) return st;
+    DevBuf ki, ko, vi, vo, tmp;
+    if ((st = ki.alloc(n * 8)) != PCPX_OK || (st = ko.alloc(n * 8)) != PCPX_OK || (st = vi.alloc(n * 4)) != PCPX_OK ||
+        (st = vo.alloc(n * 4)) != PCPX_OK || (st = tmp.alloc(tb)) != PCPX_OK)
+        return st;
+    if (n > 0) {
+        PCPX_HIP(hipMemcpy(ki.p, keys, n * 8, hipMemcpyHostToDevice));
+        PCPX_HIP(hipMemcpy(vi.p, vals, n * 4, hipMemcpyHostToDevice));
+    }
+    if ((st = sort_pairs_u64(tmp.p, tb, ki.as<u64>(), ko.as<u64>(), vi.as<u32>(), vo.as<u32>(), n, nullptr)) != PCPX_OK) return st;
+    PCPX_HIP(hipDeviceSynchronize());
+    if (n > 0) {
+        PCPX_HIP(hipMemcpy(out_keys, ko.p, n * 8, hipMemcpyDeviceToHost));
+        PCPX_HIP(hipMemcpy(out_vals, vo.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    return PCPX_OK;
+}
+
 int pcpx_profile_begin(pcpx_index* h)
 {
     Index* ix = reinterpret_cast<Index*>(h);

@@ -4,11 +4,9 @@
 // and recursive nth_element kd-tree build (include/pcp/kdtree/linked_kdtree.hpp:343-424).  Only query
 // RESULTS are observable through the reference API, not the tree shape, so the structure here is a
 // Morton-sorted implicit AABB tree (pcpx_internal.h) built by:
-//   bbox reduce -> 63-bit Morton codes (+ out-of-grid drop) -> radix sort of (code, index)
+//   bbox reduce -> 63-bit Morton codes (+ out-of-grid drop) -> radix sort of (code, index) (pcpx_sort.hip)
 //   -> leaf records (SoA, NaN padded) -> leaf AABBs -> bottom-up sweep of the W-ary levels.
 #include "pcpx_internal.h"
-
-#include <rocprim/rocprim.hpp>
 
 #include <cmath>
 #include <limits>
@@ -99,21 +97,32 @@ __device__ __forceinline__ u32 quant21(float v, float lo, float hi)
 // end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive containment,
 // include/pcp/common/axis_aligned_bounding_box.hpp:111-125).
 __global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6,
-                                               u64* __restrict__ codes, u32* __restrict__ vals, u32* valid_counter)
+                                               u64* __restrict__ codes, u32* __restrict__ vals)
 {
     u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
-    bool ok = false;
     if (i < n) {
         float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
-        ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
+        const bool ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
         u64 c = PAD_CODE;
         if (ok) c = (spread21(quant21(x, b0, b3)) << 2) | (spread21(quant21(y, b1, b4)) << 1) | spread21(quant21(z, b2, b5));
         codes[i] = c;
         vals[i] = static_cast<u32>(i);
     }
-    u64 m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(valid_counter, static_cast<u32>(__popcll(m)));
+}
+
+// number of inserted points = position of the first pad code in the sorted codes (one thread: a binary
+// search; a per-wave atomic counter in k_codes serialises at ~90 atomics/us and cost 1.8 ms at 10 M points)
+__global__ void k_count_valid(const u64* __restrict__ sorted_codes, u32 n, u32* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        u32 m = lo + ((hi - lo) >> 1);
+        if (sorted_codes[m] != PAD_CODE) lo = m + 1;
+        else hi = m;
+    }
+    *out = lo;
 }
 
 __global__ __launch_bounds__(256) void k_fill_leaves(const float* __restrict__ xyz, const u32* __restrict__ perm,
@@ -226,15 +235,6 @@ int dev_alloc(T*& p, size_t count)
 
 }  // namespace
 
-int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n,
-                   hipStream_t s)
-{
-    // TODO(round 2): replace with the hand-written onesweep radix sort; rocPRIM is the first cut
-    // SURVEY.md section 7 (PR3) allows.
-    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, static_cast<size_t>(n), 0u, 64u, s);
-    return check_hip(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
-}
-
 int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6)
 {
     k_bbox_init<<<1, 64, 0, s>>>(d_enc6, d_enc6 + 6);
@@ -328,11 +328,14 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     u32 nvalid = 0;
     if (n > 0) {
         unsigned blocks = static_cast<unsigned>((n + 255) / 256);
-        k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.d_codes[0], ix.d_vals[0], ix.d_scalars + 6);
+        k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.d_codes[0], ix.d_vals[0]);
         PCPX_HIP(hipGetLastError());
         size_t tb = ix.sort_tmp_bytes;
         int st = sort_pairs_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], n, s);
         if (st != PCPX_OK) return st;
+        k_count_valid<<<1, 64, 0, s>>>(ix.d_codes[1], static_cast<u32>(n), ix.d_scalars + 6);
+    } else {
+        PCPX_HIP(hipMemsetAsync(ix.d_scalars + 6, 0, sizeof(u32), s));
     }
     float hb[8];
     PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, 8 * sizeof(u32), hipMemcpyDeviceToHost, s));
