@@ -136,6 +136,18 @@ int pcpx_normals_knn_self(pcpx_index* idx, uint32_t k, float eps, float* out_nor
 int pcpx_normals_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first,
                               uint64_t sorted_count, float* d_out_normals, uint32_t* d_opt_out_idx,
                               uint32_t* d_opt_out_count);
+/* ---- tangent planes / mean neighbour distance (the callers right next to the normal loop) -------- */
+/* estimate_tangent_planes (include/pcp/algorithm/estimate_tangent_planes.hpp:50-98): plane of point i =
+ * (center_of_geometry of its k nearest neighbours, include/pcp/common/vector3d_queries.hpp:77-99; their PCA
+ * normal).  out_centroids and out_normals are n x 3. */
+int pcpx_tangent_planes_knn_self(pcpx_index* idx, uint32_t k, float eps, float* out_centroids, float* out_normals);
+/* average_distances_to_neighbors (include/pcp/algorithm/average_distance_to_neighbors.hpp:32-73): for every
+ * indexed point the mean Euclidean distance to its k nearest neighbours (NaN for an empty neighbourhood). */
+int pcpx_mean_knn_distance_self(pcpx_index* idx, uint32_t k, float eps, float* out_mean_dist);
+/* Device form of both plus normals; any output may be NULL (not all). Sorted-slice arguments as pcpx_knn_self_dev. */
+int pcpx_neighbourhoods_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                                 float* d_opt_normals, float* d_opt_centroids, float* d_opt_mean_dist);
+
 /* estimate_normal over explicit neighbourhoods: row q = nbr_idx[q*k .. q*k+count[q]) indexes the
  * index's points.  opt_out_evals (nq x 3, ascending eigenvalues) may be NULL. */
 int pcpx_normals_from_knn(pcpx_index* idx, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq,

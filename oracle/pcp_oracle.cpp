@@ -770,6 +770,40 @@ void orc_estimate_normals(void* h, int tree_kind, u64 first, u64 count, u32 k, f
     });
 }
 
+// pcp::common::center_of_geometry (include/pcp/common/vector3d_queries.hpp:77-99) of every neighbour row:
+// accumulate from point_type{} = (0,0,0) in row order, then divide by n.  This is the point of the plane
+// estimate_tangent_planes builds (include/pcp/algorithm/estimate_tangent_planes.hpp:79-96).
+void orc_centroids_from_knn(float const* xyz, u32 const* nbr, u32 const* cnt, u64 nq, u32 k, float* out)
+{
+    P3 const* pts = reinterpret_cast<P3 const*>(xyz);
+    for (u64 q = 0; q < nq; ++q) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (u32 j = 0; j < cnt[q]; ++j) {
+            P3 const& p = pts[nbr[q * k + j]];
+            sx = sx + p.x; sy = sy + p.y; sz = sz + p.z;
+        }
+        float const np = static_cast<float>(cnt[q]);
+        out[3 * q] = sx / np; out[3 * q + 1] = sy / np; out[3 * q + 2] = sz / np;
+    }
+}
+
+// pcp::algorithm::average_distances_to_neighbors (include/pcp/algorithm/average_distance_to_neighbors.hpp:52-70):
+// mean_i = (sum_j norm(p_i - p_j)) / |neighbours|, norm = sqrt(x*x + y*y + z*z) (include/pcp/common/norm.hpp:58-70)
+void orc_mean_dist_from_knn(float const* xyz, float const* qxyz, u32 const* nbr, u32 const* cnt, u64 nq, u32 k, float* out)
+{
+    P3 const* pts = reinterpret_cast<P3 const*>(xyz);
+    P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
+    for (u64 q = 0; q < nq; ++q) {
+        float sum = 0.f;
+        for (u32 j = 0; j < cnt[q]; ++j) {
+            P3 const& pj = pts[nbr[q * k + j]];
+            float const x = qs[q].x - pj.x, y = qs[q].y - pj.y, z = qs[q].z - pj.z;
+            sum = sum + std::sqrt(x * x + y * y + z * z);
+        }
+        out[q] = sum / static_cast<float>(cnt[q]);
+    }
+}
+
 int orc_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
 
 }  // extern "C"

@@ -195,3 +195,27 @@ def normals_from_knn(xyz, nbr, cnt, nthreads=1, want_evals=False):
     lib().orc_normals_from_knn(_p(xyz, _f32p), _p(nbr, _u32p), _p(cnt, _u32p), C.c_uint64(nq), C.c_uint32(k),
                                _p(out, _f32p), _p(ev, _f32p), C.c_int(nthreads))
     return (out, ev) if want_evals else out
+
+
+def centroids_from_knn(xyz, nbr, cnt):
+    """center_of_geometry of every neighbour row (the tangent plane's point)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    nbr = np.ascontiguousarray(nbr, np.uint32)
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    nq, k = nbr.shape
+    out = np.empty((nq, 3), np.float32)
+    lib().orc_centroids_from_knn(_p(xyz, _f32p), _p(nbr, _u32p), _p(cnt, _u32p), C.c_uint64(nq), C.c_uint32(k), _p(out, _f32p))
+    return out
+
+
+def mean_dist_from_knn(xyz, queries, nbr, cnt):
+    """average_distances_to_neighbors: mean Euclidean distance from each query to its neighbour row."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    q = _f32(queries).reshape(-1, 3)
+    nbr = np.ascontiguousarray(nbr, np.uint32)
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    nq, k = nbr.shape
+    out = np.empty(nq, np.float32)
+    lib().orc_mean_dist_from_knn(_p(xyz, _f32p), _p(q, _f32p), _p(nbr, _u32p), _p(cnt, _u32p), C.c_uint64(nq), C.c_uint32(k),
+                                 _p(out, _f32p))
+    return out

@@ -69,6 +69,10 @@ SIGNATURES = {
     "pcpx_normals_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcpx_normals_knn_self_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    "pcpx_tangent_planes_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]),
+    "pcpx_mean_knn_distance_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
+    "pcpx_neighbourhoods_self_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]),
     "pcpx_normals_from_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                         C.c_void_p]),
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),

@@ -302,7 +302,11 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
     u64 gf, gc;
     slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
-    return launch_knn(*ix, qv, true, gf, gc, k, eps, d_out_idx, d_out_count, d_out_d2, nullptr);
+    KnnOutputs o;
+    o.idx = d_out_idx;
+    o.cnt = d_out_count;
+    o.d2 = d_out_d2;
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
 }
 
 int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count, float* out_d2)
@@ -343,7 +347,11 @@ int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_
     if (!d_q_xyz || !d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
     QueryView qv;
     if ((st = prepare_queries(*ix, d_q_xyz, nq, qv)) != PCPX_OK) return st;
-    return launch_knn(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, k, eps, d_out_idx, d_out_count, d_out_d2, nullptr);
+    KnnOutputs o;
+    o.idx = d_out_idx;
+    o.cnt = d_out_count;
+    o.d2 = d_out_d2;
+    return launch_knn(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, k, eps, o);
 }
 
 int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, float eps, uint32_t* out_idx,
@@ -520,7 +528,68 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     u64 gf, gc;
     slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
-    return launch_knn(*ix, qv, true, gf, gc, k, eps, d_opt_out_idx, d_opt_out_count, nullptr, d_out_normals);
+    KnnOutputs o;
+    o.idx = d_opt_out_idx;
+    o.cnt = d_opt_out_count;
+    o.normals = d_out_normals;
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
+}
+
+// estimate_tangent_planes / average_distances_to_neighbors over the index's own points
+int pcpx_neighbourhoods_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                                 float* d_opt_normals, float* d_opt_centroids, float* d_opt_mean_dist)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (k == 0 || (!d_opt_normals && !d_opt_centroids && !d_opt_mean_dist)) return PCPX_ERR_INVALID;
+    if (sorted_first % GROUP != 0) {
+        set_error("pcpx_neighbourhoods_self_dev: sorted_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
+    }
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    KnnOutputs o;
+    o.normals = d_opt_normals;
+    o.centroids = d_opt_centroids;
+    o.meandist = d_opt_mean_dist;
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
+}
+
+int pcpx_tangent_planes_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_centroids, float* out_normals)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_centroids || !out_normals || k == 0) return PCPX_ERR_INVALID;
+    u64 rows = ix->n_in;
+    DevBuf dc, dn;
+    if ((st = dc.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * 3 * sizeof(float), ix->stream));
+    PCPX_HIP(hipMemsetAsync(dn.p, 0, rows * 3 * sizeof(float), ix->stream));
+    if ((st = pcpx_neighbourhoods_self_dev(h, k, eps, 0, UINT64_MAX, dn.as<float>(), dc.as<float>(), nullptr)) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_centroids, dc.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_mean_knn_distance_self(pcpx_index* h, uint32_t k, float eps, float* out_mean_dist)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_mean_dist || k == 0) return PCPX_ERR_INVALID;
+    u64 rows = ix->n_in;
+    DevBuf dm;
+    if ((st = dm.alloc(rows * sizeof(float))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemsetAsync(dm.p, 0, rows * sizeof(float), ix->stream));
+    if ((st = pcpx_neighbourhoods_self_dev(h, k, eps, 0, UINT64_MAX, nullptr, nullptr, dm.as<float>())) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_mean_dist, dm.p, rows * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
 }
 
 int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,

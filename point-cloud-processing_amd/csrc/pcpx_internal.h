@@ -64,6 +64,16 @@ struct TreeView {
     u32 leaf0;
 };
 
+// Device outputs of the fused kNN kernel, one row per query (row index = input index of the query).
+struct KnnOutputs {
+    u32* idx = nullptr;         // rows x k neighbour indices, ascending (d2, index), INVALID_ID padded
+    u32* cnt = nullptr;         // rows: valid entries per row
+    float* d2 = nullptr;        // rows x k squared distances
+    float* normals = nullptr;   // rows x 3: pcp::estimate_normal of the row
+    float* centroids = nullptr; // rows x 3: pcp::common::center_of_geometry of the row (tangent plane point)
+    float* meandist = nullptr;  // rows: mean Euclidean distance to the row's neighbours
+};
+
 // Queries of a batch, in Morton-sorted order.  For self queries qx == nullptr and the query of
 // sorted position p is point p of the leaves.
 struct QueryView {
@@ -155,9 +165,9 @@ int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, cons
 int ensure_scratch(Index& ix, size_t bytes);
 
 // query.hip
-// kNN (+ fused PCA normals when d_out_normals != nullptr); any of the outputs may be nullptr
+// kNN + whatever per-neighbourhood products are requested (any pointer may be nullptr); all fused in k_knn
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
-               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2, float* d_out_normals);
+               const KnnOutputs& o);
 int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats);
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
                        const float* d_radii, u32* d_out_cnt);

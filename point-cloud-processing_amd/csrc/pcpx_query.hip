@@ -472,8 +472,7 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 // One query group (64 Morton-consecutive queries, one per lane) from start to finish.
 template <int KCAP, bool SELF, bool STATS>
 __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k, const float eps,
-                                          u32* __restrict__ out_idx, u32* __restrict__ out_cnt, float* __restrict__ out_d2,
-                                          float* __restrict__ out_nrm, unsigned long long* __restrict__ stats,
+                                          const KnnOutputs& o, unsigned long long* __restrict__ stats,
                                           u64* __restrict__ col, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows; row BUF is the trash row
@@ -631,17 +630,30 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (j >= 0) {
             u64 key = best[s];
             bool ok = key != PAD_KEY;
-            if (out_idx) out_idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
-            if (out_d2) out_d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
+            if (o.idx) o.idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
+            if (o.d2) o.d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
             found += ok ? 1u : 0u;
             okmask |= ok ? (1u << s) : 0u;
         }
     }
-    if (out_cnt) out_cnt[row] = found;
+    if (o.cnt) o.cnt[row] = found;
+
+    // ---- fused pcp::algorithm::average_distances_to_neighbors (average_distance_to_neighbors.hpp:52-70):
+    //      (sum of sqrt(d2) over the row, in row order) / row size; an empty row gives 0/0 = NaN ----
+    if (o.meandist) {
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            bool ok = (okmask >> s) & 1u;
+            float d = sqrtf(__uint_as_float(static_cast<u32>(best[s] >> 32)));
+            sum += ok ? d : 0.f;
+        }
+        o.meandist[row] = sum / static_cast<float>(found);
+    }
 
     // ---- fused pcp::estimate_normal over the row (normal_estimation.hpp:41-77), coordinates gathered
     //      from the leaf records in row order ----
-    if (out_nrm) {
+    if (o.normals || o.centroids) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) {
@@ -654,6 +666,12 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         }
         float fn = static_cast<float>(found);
         float mx = sx / fn, my = sy / fn, mz = sz / fn;
+        if (o.centroids) {  // pcp::common::center_of_geometry (vector3d_queries.hpp:77-99): the tangent plane's point
+            o.centroids[3ull * row] = mx;
+            o.centroids[3ull * row + 1] = my;
+            o.centroids[3ull * row + 2] = mz;
+        }
+        if (!o.normals) return;
         float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) {
@@ -670,9 +688,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         }
         float nrm[3], ev[3];
         eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
-        out_nrm[3ull * row] = nrm[0];
-        out_nrm[3ull * row + 1] = nrm[1];
-        out_nrm[3ull * row + 2] = nrm[2];
+        o.normals[3ull * row] = nrm[0];
+        o.normals[3ull * row + 1] = nrm[1];
+        o.normals[3ull * row + 2] = nrm[2];
     }
 }
 
@@ -688,8 +706,7 @@ constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
 template <int KCAP, bool SELF, bool STATS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) void k_knn(
-    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, u32* __restrict__ out_idx,
-    u32* __restrict__ out_cnt, float* __restrict__ out_d2, float* __restrict__ out_nrm, u32* __restrict__ queue,
+    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, KnnOutputs o, u32* __restrict__ queue,
     unsigned long long* __restrict__ stats)
 {
     constexpr int BUF = buf_rows(KCAP);
@@ -709,7 +726,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
             if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (qbeg + gi >= qend) break;
-            knn_group<KCAP, SELF, STATS>(t, qv, group_first + qbeg + gi, k, eps, out_idx, out_cnt, out_d2, out_nrm, stats, col, lane);
+            knn_group<KCAP, SELF, STATS>(t, qv, group_first + qbeg + gi, k, eps, o, stats, col, lane);
         }
     }
 }
@@ -1018,8 +1035,7 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
 }
 
 template <int KCAP>
-static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, u32* oi,
-                        u32* oc, float* od, float* on)
+static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, const KnnOutputs& o)
 {
     constexpr int BUF = buf_rows(KCAP);
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
@@ -1031,20 +1047,18 @@ static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u
     const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false>) : reinterpret_cast<const void*>(k_knn<KCAP, false, false>);
     u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount);
     ProfileScope prof(ix, PCPX_K_KNN);
-    if (self) k_knn<KCAP, true, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, ix.d_queue, nullptr);
-    else k_knn<KCAP, false, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, oi, oc, od, on, ix.d_queue, nullptr);
+    if (self) k_knn<KCAP, true, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, ix.d_queue, nullptr);
+    else k_knn<KCAP, false, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, ix.d_queue, nullptr);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
-               u32* d_out_idx, u32* d_out_cnt, float* d_out_d2, float* d_out_normals)
+               const KnnOutputs& o)
 {
     if (group_count == 0) return PCPX_OK;
     eps = sanitize_eps(eps);
-    if (k <= 16)
-        return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2, d_out_normals);
-    if (k <= 32)
-        return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, d_out_idx, d_out_cnt, d_out_d2, d_out_normals);
+    if (k <= 16) return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, o);
+    if (k <= 32) return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, o);
     set_error("pcpx: k = %u > 32 is not supported yet", k);
     return PCPX_ERR_UNSUPPORTED;
 }
@@ -1061,7 +1075,7 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
     if (st != PCPX_OK) return st;
     u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WAVES_PER_BLOCK, lds, groups);
     k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), nullptr, nullptr, nullptr, nullptr, ix.d_queue, d_stats);
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), KnnOutputs{}, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 

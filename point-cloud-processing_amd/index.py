@@ -179,6 +179,19 @@ class Index:
         check(self._lib.pcpx_normals_knn_self(self._h, k, eps, _vp(nrm), _vp(idx), _vp(cnt)))
         return (nrm, idx, cnt) if want_knn else nrm
 
+    def tangent_planes_knn_self(self, k, eps=1e-5):
+        """pcp::algorithm::estimate_tangent_planes: (centroids, normals) of every point's k-neighbourhood."""
+        cen = np.empty((self.n_in, 3), np.float32)
+        nrm = np.empty((self.n_in, 3), np.float32)
+        check(self._lib.pcpx_tangent_planes_knn_self(self._h, k, eps, _vp(cen), _vp(nrm)))
+        return cen, nrm
+
+    def mean_knn_distance_self(self, k, eps=1e-5):
+        """pcp::algorithm::average_distances_to_neighbors: mean distance to the k nearest neighbours, per point."""
+        out = np.empty(self.n_in, np.float32)
+        check(self._lib.pcpx_mean_knn_distance_self(self._h, k, eps, _vp(out)))
+        return out
+
     def normals_from_knn(self, nbr, cnt, want_evals=False):
         nbr = np.ascontiguousarray(nbr, np.uint32)
         cnt = np.ascontiguousarray(cnt, np.uint32)

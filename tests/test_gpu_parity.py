@@ -394,3 +394,26 @@ def test_radix_sort_is_a_stable_sort(pkg, n):
     capi.check(lib.pcpx_debug_sort_pairs(vp(keys), vp(vals), n, 0, vp(ok), vp(ov)))
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
+
+
+# ---- the callers right next to the normal loop ----------------------
+def test_tangent_planes_and_mean_distances(pkg, oracle, bunny):
+    """estimate_tangent_planes (plane = centroid of the k-neighbourhood + PCA normal) and
+    average_distances_to_neighbors, fused into the kNN kernel, against the oracle's restatement."""
+    for pts, k in ((bunny, 15), (pkg.synthetic.clustered_cloud(50_000, seed=44), 9)):
+        ix = pkg.Index(pts)
+        idx, cnt = ix.knn_self(k)
+        cen, nrm = ix.tangent_planes_knn_self(k)
+        md = ix.mean_knn_distance_self(k)
+        assert np.array_equal(cen, oracle.centroids_from_knn(pts, idx, cnt))
+        assert _cos_err(nrm, oracle.normals_from_knn(pts, idx, cnt, nthreads=8)).max() <= COS_TOL
+        assert np.array_equal(nrm, ix.normals_knn_self(k))
+        assert np.array_equal(md, oracle.mean_dist_from_knn(pts, pts, idx, cnt))
+        # the reference's scalar: average of the per-point means (std::reduce order is unspecified)
+        assert abs(float(md.astype(np.float64).mean()) - float(oracle.mean_dist_from_knn(pts, pts, idx, cnt).astype(np.float64).mean())) < 1e-9
+    # the 7-point plane KAT of test/common/plane3d.cpp:33-69: centroid (0,0,0), normal +-(0,0,1)
+    seven = np.array([[0, 0, 0], [-2, 0, 0], [2, 0, 0], [0, -2, 0], [0, 2, 0], [0, 0, -1], [0, 0, 1]], np.float32)
+    far = np.array([[100, 100, 100]], np.float32)  # query whose 7 neighbours are exactly the 7 points
+    ix = pkg.Index(np.concatenate([seven, far]))
+    cen, nrm = ix.tangent_planes_knn_self(7)
+    assert np.all(np.abs(cen[7]) < 1e-6) and abs(abs(nrm[7][2]) - 1) < 1e-5
