@@ -111,6 +111,7 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_scalars);
     (void)hipFree(ix->d_scratch);
     (void)hipFree(ix->d_queue);
+    (void)hipFree(ix->d_multi);
     if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -532,6 +533,12 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     o.idx = d_opt_out_idx;
     o.cnt = d_opt_out_count;
     o.normals = d_out_normals;
+    if (k > 32 && (!o.idx || !o.cnt)) {  // the multi-pass path materialises rows: keep them in index scratch
+        size_t need_idx = (static_cast<size_t>(ix->n_in) * k * sizeof(u32) + 255) / 256 * 256;
+        if ((st = ensure_scratch(*ix, need_idx + static_cast<size_t>(ix->n_in) * sizeof(u32))) != PCPX_OK) return st;
+        if (!o.idx) o.idx = static_cast<u32*>(ix->d_scratch);
+        if (!o.cnt) o.cnt = reinterpret_cast<u32*>(static_cast<char*>(ix->d_scratch) + need_idx);
+    }
     return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
 }
 

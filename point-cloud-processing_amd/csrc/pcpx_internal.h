@@ -117,6 +117,8 @@ struct Index {
     std::vector<Interval> intervals;
 
     u32* d_queue = nullptr;  // work-queue counters of the persistent query kernels
+    u64* d_multi = nullptr;  // k > 32: per-query pass keys + pass bounds
+    size_t multi_bytes = 0;
 
     // scratch for batch queries (grown on demand)
     void* d_scratch = nullptr;

@@ -467,12 +467,25 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
 #ifndef PCPX_MINW
-#define PCPX_MINW 5  // <= 96 VGPRs for the k <= 16 kernel: 5 waves/SIMD, what 8 KB of LDS per wave also allows
+#define PCPX_MINW 4  // k <= 16 kernel: hipcc lands at 91 VGPRs without scratch (5 waves/SIMD, what 8 KB of LDS per wave
+                     // also allows); asking for 5 makes it spill 10 registers for the same occupancy
 #endif
+// k > 32: pass p of a multi-pass search returns the (at most 32) smallest keys strictly greater than the
+// last key of pass p-1, so ceil(k/32) passes enumerate the k nearest in order.  Keys (d2, sorted position)
+// are kept raw per query slot; k_assemble turns them into rows.
+struct MultiPass {
+    const u64* lo = nullptr;  // per query slot: exclusive lower bound (nullptr on the first pass)
+    u64* lo_out = nullptr;    // per query slot: last key of this pass
+    u64* keys = nullptr;      // per query slot: `stride` keys; this pass writes [offset, offset + k)
+    u32 stride = 0;
+    u32 offset = 0;
+    u32 slot0 = 0;            // query slot of the first group of the launch
+};
+
 // One query group (64 Morton-consecutive queries, one per lane) from start to finish.
-template <int KCAP, bool SELF, bool STATS>
+template <int KCAP, bool SELF, bool STATS, bool MULTI>
 __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k, const float eps,
-                                          const KnnOutputs& o, unsigned long long* __restrict__ stats,
+                                          const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
                                           u64* __restrict__ col, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows; row BUF is the trash row
@@ -499,6 +512,12 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             qz = qv.qz[p];
             row = qv.row[p];
         }
+    }
+    u64 lo_key = 0;
+    bool has_lo = false;
+    if (MULTI && mp.lo && valid) {
+        lo_key = mp.lo[p - mp.slot0];
+        has_lo = true;
     }
     // best-list: KCAP-k leading zero keys act as -inf sentinels so that tau is always best[KCAP-1]
     u64 best[KCAP];
@@ -542,7 +561,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             } while (have && leaf >= s0 && leaf < s1);
         }
         // compaction: buffer nearly full, or a lane could get a finite tau now, or draining at a phase end
-        if (PCPX_ASM_ACCEPT) cnt = static_cast<int>((wa - col_addr) >> 9);
+        if (PCPX_ASM_ACCEPT && !MULTI) cnt = static_cast<int>((wa - col_addr) >> 9);
         bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
             compact<KCAP, BUF>(best, col, cnt);
@@ -565,17 +584,19 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
                 float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-#if PCPX_ASM_ACCEPT
-                if (STATS) st_app += (d2 <= tau && m >= eps) ? 1u : 0u;
-                append_if(d2, tau, m, eps, posbase + j, wa);  // NaN padding points fail d2 <= tau
-#else
-                float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
-                bool acc = m2 >= eps;              // outside the eps-box (eps >= 0)
-                int slot = acc ? cnt : BUF;
-                col[slot * 64] = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
-                cnt += acc ? 1 : 0;
-                if (STATS) st_app += acc ? 1u : 0u;
-#endif
+                if (PCPX_ASM_ACCEPT && !MULTI) {
+                    if (STATS) st_app += (d2 <= tau && m >= eps) ? 1u : 0u;
+                    append_if(d2, tau, m, eps, posbase + j, wa);  // NaN padding points fail d2 <= tau
+                } else {
+                    const u64 key = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
+                    float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
+                    bool acc = m2 >= eps;              // outside the eps-box (eps >= 0)
+                    if (MULTI) acc = acc && (!has_lo || key > lo_key);
+                    int slot = acc ? cnt : BUF;
+                    col[slot * 64] = key;
+                    cnt += acc ? 1 : 0;
+                    if (STATS) st_app += acc ? 1u : 0u;
+                }
             }
         } else if (!trig) {
             // drained: seed chunk -> tree walk -> finished
@@ -603,8 +624,20 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         }
     }
 
-    // ---- sorted position -> original index; order rows by (d2, index) ----
     const int first_slot = KCAP - static_cast<int>(k);
+    if (MULTI) {  // raw (d2, sorted position) keys of this pass; rows are built by k_assemble
+        if (valid) {
+            u64* dst = mp.keys + static_cast<u64>(p - mp.slot0) * mp.stride + mp.offset;
+#pragma unroll
+            for (int s = 0; s < KCAP; ++s) {
+                int j = s - first_slot;
+                if (j >= 0) dst[j] = best[s];
+            }
+            mp.lo_out[p - mp.slot0] = best[KCAP - 1];
+        }
+        return;
+    }
+    // ---- sorted position -> original index; order rows by (d2, index) ----
     u32 pos[KCAP];
 #pragma unroll
     for (int s = 0; s < KCAP; ++s) {
@@ -704,10 +737,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 // under-reports on gfx950 (this grid is fully resident by construction).
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
-template <int KCAP, bool SELF, bool STATS>
+template <int KCAP, bool SELF, bool STATS, bool MULTI = false>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) void k_knn(
-    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, KnnOutputs o, u32* __restrict__ queue,
-    unsigned long long* __restrict__ stats)
+    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, KnnOutputs o, MultiPass mp,
+    u32* __restrict__ queue, unsigned long long* __restrict__ stats)
 {
     constexpr int BUF = buf_rows(KCAP);
     extern __shared__ u64 lds[];
@@ -726,7 +759,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
             if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (qbeg + gi >= qend) break;
-            knn_group<KCAP, SELF, STATS>(t, qv, group_first + qbeg + gi, k, eps, o, stats, col, lane);
+            knn_group<KCAP, SELF, STATS, MULTI>(t, qv, group_first + qbeg + gi, k, eps, o, mp, stats, col, lane);
         }
     }
 }
@@ -1047,9 +1080,112 @@ static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u
     const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false>) : reinterpret_cast<const void*>(k_knn<KCAP, false, false>);
     u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount);
     ProfileScope prof(ix, PCPX_K_KNN);
-    if (self) k_knn<KCAP, true, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, ix.d_queue, nullptr);
-    else k_knn<KCAP, false, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, ix.d_queue, nullptr);
+    if (self) k_knn<KCAP, true, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, MultiPass{}, ix.d_queue, nullptr);
+    else k_knn<KCAP, false, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, MultiPass{}, ix.d_queue, nullptr);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
+}
+
+// ---- k > 32: stitch the per-pass keys of every query into its output row -----------------------------
+// One thread per query slot.  Keys are already ascending in (d2, sorted position); converting the low word
+// to the original index can only disorder runs of equal d2, which a local insertion sort repairs in place.
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_assemble(TreeView t, QueryView qv, u32 slot0, u32 nslots, u32 k, u32 stride,
+                                                  u64* __restrict__ keys, KnnOutputs o)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const u32 p = slot0 + i;
+    const u32 nq = SELF ? t.n : qv.nq;
+    if (p >= nq) return;
+    const u32 row = SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
+    u64* r = keys + static_cast<u64>(i) * stride;
+    u32 found = 0;
+    for (u32 j = 0; j < k; ++j) {
+        u64 key = r[j];
+        if (key == PAD_KEY) break;
+        const u32 ps = static_cast<u32>(key);
+        key = (key & 0xFFFFFFFF00000000ull) | t.leaves[ps / LEAF].id[ps % LEAF];
+        u32 a = j;
+        while (a > 0 && r[a - 1] > key) {
+            r[a] = r[a - 1];
+            --a;
+        }
+        r[a] = key;
+        ++found;
+    }
+    const u64 ob = static_cast<u64>(row) * k;
+    for (u32 j = 0; j < k; ++j) {
+        const bool ok = j < found;
+        if (o.idx) o.idx[ob + j] = ok ? static_cast<u32>(r[j]) : INVALID_ID;
+        if (o.d2) o.d2[ob + j] = ok ? __uint_as_float(static_cast<u32>(r[j] >> 32)) : std::numeric_limits<float>::infinity();
+    }
+    if (o.cnt) o.cnt[row] = found;
+}
+
+static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps,
+                                const KnnOutputs& o)
+{
+    constexpr int KCAP = 32, BUF = buf_rows(KCAP);
+    if (o.centroids || o.meandist) {
+        set_error("pcpx: tangent planes / mean distances are limited to k <= 32");
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    const u32 npass = (k + KCAP - 1) / KCAP;
+    const u32 stride = npass * KCAP;
+    const u64 nslots = gcount * GROUP;
+    const size_t need = static_cast<size_t>(nslots) * (stride + 2) * sizeof(u64);
+    if (need > ix.multi_bytes) {
+        if (ix.d_multi) {
+            PCPX_HIP(hipStreamSynchronize(ix.stream));
+            (void)hipFree(ix.d_multi);
+            ix.d_multi = nullptr;
+            ix.multi_bytes = 0;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix.d_multi), need);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) for the k > 32 key buffer failed: %s", need, hipGetErrorString(e));
+            return PCPX_ERR_ALLOC;
+        }
+        ix.multi_bytes = need;
+    }
+    u64* keys = ix.d_multi;
+    u64* lo[2] = {ix.d_multi + nslots * stride, ix.d_multi + nslots * stride + nslots};
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
+    u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
+    const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false, true>)
+                          : reinterpret_cast<const void*>(k_knn<KCAP, false, false, true>);
+    u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount);
+    ProfileScope prof(ix, PCPX_K_KNN);
+    for (u32 pass = 0; pass < npass; ++pass) {
+        MultiPass mp;
+        mp.lo = pass ? lo[(pass + 1) & 1] : nullptr;
+        mp.lo_out = lo[pass & 1];
+        mp.keys = keys;
+        mp.stride = stride;
+        mp.offset = pass * KCAP;
+        mp.slot0 = gf * GROUP;
+        const u32 kp = (pass + 1 < npass) ? KCAP : k - pass * KCAP;
+        int st = prepare_queue(ix);
+        if (st != PCPX_OK) return st;
+        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, KnnOutputs{}, mp, ix.d_queue, nullptr);
+        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, KnnOutputs{}, mp, ix.d_queue, nullptr);
+    }
+    const u32 n32 = static_cast<u32>(nslots);
+    if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
+    else k_assemble<false><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
+    PCPX_HIP(hipGetLastError());
+    if (o.normals) {
+        if (!o.idx || !o.cnt) {
+            set_error("pcpx: normals with k > 32 need the neighbour rows as outputs too");
+            return PCPX_ERR_INVALID;
+        }
+        // rows are complete in HBM: PCA normal per row (row order: sorted slots -> rows)
+        const u32* rowmap = self ? ix.perm() : qv.row;
+        return launch_normals(ix, o.idx, o.cnt, rowmap, static_cast<u64>(gf) * GROUP,
+                              (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP < nslots ? (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP : nslots,
+                              k, o.normals, nullptr);
+    }
+    return PCPX_OK;
 }
 
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
@@ -1059,8 +1195,7 @@ int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 g
     eps = sanitize_eps(eps);
     if (k <= 16) return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, o);
     if (k <= 32) return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, o);
-    set_error("pcpx: k = %u > 32 is not supported yet", k);
-    return PCPX_ERR_UNSUPPORTED;
+    return launch_knn_multipass(ix, qv, self, group_first, group_count, k, eps, o);
 }
 
 // instrumented self-kNN (k <= 16): traversal statistics summed over all waves into d_stats[8]
@@ -1075,7 +1210,7 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
     if (st != PCPX_OK) return st;
     u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WAVES_PER_BLOCK, lds, groups);
     k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), KnnOutputs{}, ix.d_queue, d_stats);
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), KnnOutputs{}, MultiPass{}, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 

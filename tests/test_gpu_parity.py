@@ -155,14 +155,15 @@ def test_bunny_full_against_oracle_trees(pkg, oracle, bunny):
 
 # ---- seeded random clouds against the brute-force oracle --------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 257, 1000, 4099])
-@pytest.mark.parametrize("k", [1, 15, 16, 17, 32])
+@pytest.mark.parametrize("k", [1, 15, 16, 17, 32, 40])
 def test_knn_self_small(pkg, oracle, n, k):
     rng = np.random.default_rng(1000 * n + k)
     pts = rng.random((n, 3), dtype=np.float32)
     _check_knn_exact(pkg, oracle, pts, None, k, self_query=True)
 
 
-@pytest.mark.parametrize("n,nq,k", [(1, 5, 3), (50, 1, 15), (1000, 777, 15), (20000, 3000, 10), (20000, 130, 32)])
+@pytest.mark.parametrize("n,nq,k", [(1, 5, 3), (50, 1, 15), (1000, 777, 15), (20000, 3000, 10), (20000, 130, 32),
+                                    (20000, 500, 33), (5000, 200, 64), (3000, 100, 100), (40, 7, 70)])
 def test_knn_batch_arbitrary_queries(pkg, oracle, n, nq, k):
     rng = np.random.default_rng(n + nq + k)
     pts = rng.random((n, 3), dtype=np.float32)
@@ -178,8 +179,8 @@ def test_knn_empty_and_k0(pkg):
     ix = pkg.Index(np.random.default_rng(0).random((100, 3), dtype=np.float32))
     idx, cnt = ix.knn([[0.5, 0.5, 0.5]], 0)
     assert idx.shape == (1, 0) and cnt[0] == 0
-    with pytest.raises(pkg.PcpxError):
-        ix.knn([[0.5, 0.5, 0.5]], 33)  # k > 32 not built yet: must fail loudly, not silently truncate
+    idx, cnt = ix.knn([[0.5, 0.5, 0.5]], 150)  # k > n: short row
+    assert cnt[0] == 100 and np.all(idx[0, 100:] == 0xFFFFFFFF) and len(set(idx[0, :100].tolist())) == 100
 
 
 def test_knn_coincident_points_and_eps(pkg, oracle):
@@ -417,3 +418,16 @@ def test_tangent_planes_and_mean_distances(pkg, oracle, bunny):
     ix = pkg.Index(np.concatenate([seven, far]))
     cen, nrm = ix.tangent_planes_knn_self(7)
     assert np.all(np.abs(cen[7]) < 1e-6) and abs(abs(nrm[7][2]) - 1) < 1e-5
+
+
+def test_large_k_multipass(pkg, oracle):
+    """k > 32 runs ceil(k/32) passes with a key lower bound and stitches the rows; ties across a pass
+    boundary (lattice) and normals over long rows included."""
+    g = np.arange(9, dtype=np.float32) / np.float32(8)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    lattice = lattice[np.random.default_rng(1).permutation(len(lattice))]
+    _check_knn_exact(pkg, oracle, lattice, None, 50, self_query=True)
+    pts = pkg.synthetic.clustered_cloud(30_000, seed=44)
+    ix = _check_knn_exact(pkg, oracle, pts, None, 48, self_query=True)
+    nrm, idx, cnt = ix.normals_knn_self(48, want_knn=True)
+    assert _cos_err(nrm, oracle.normals_from_knn(pts, idx, cnt, nthreads=8)).max() <= COS_TOL
