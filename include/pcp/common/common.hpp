@@ -6,6 +6,7 @@
 #include "pcp/common/norm.hpp"
 #include "pcp/common/normals/normal.hpp"
 #include "pcp/common/normals/normal_estimation.hpp"
+#include "pcp/common/plane3d.hpp"
 #include "pcp/common/points/point.hpp"
 #include "pcp/common/points/point_view.hpp"
 #include "pcp/common/points/vertex.hpp"

@@ -142,6 +142,21 @@ class device_index_t
         if (rows) check(pcpx_normals_knn_self(h_, k, eps, nrm.data(), nullptr, nullptr), "pcpx_normals_knn_self");
         return nrm;
     }
+    // fused kNN + (centroid, PCA normal) of every indexed point: the tangent planes
+    void tangent_planes_self(std::uint32_t k, float eps, std::uint64_t rows, std::vector<float>& centroids,
+                             std::vector<float>& normals) const
+    {
+        centroids.assign(static_cast<std::size_t>(rows) * 3, 0.f);
+        normals.assign(static_cast<std::size_t>(rows) * 3, 0.f);
+        if (rows) check(pcpx_tangent_planes_knn_self(h_, k, eps, centroids.data(), normals.data()), "pcpx_tangent_planes_knn_self");
+    }
+    // fused kNN + mean Euclidean distance to the k neighbours of every indexed point
+    std::vector<float> mean_knn_distance_self(std::uint32_t k, float eps, std::uint64_t rows) const
+    {
+        std::vector<float> m(static_cast<std::size_t>(rows), 0.f);
+        if (rows) check(pcpx_mean_knn_distance_self(h_, k, eps, m.data()), "pcpx_mean_knn_distance_self");
+        return m;
+    }
     std::vector<float> normals_from_knn(knn_result_t const& r) const
     {
         std::vector<float> nrm(r.count.size() * 3, 0.f);

@@ -211,6 +211,34 @@ static void normal_scenarios()
         REQUIRE(rows[i].size() == one.size());
         for (std::size_t j = 0; j < one.size(); ++j) REQUIRE(pcp::common::are_vectors_equal(rows[i][j], one[j]));
     }
+    // tangent planes and mean neighbour distances (test/algorithm/estimate_tangent_planes.cpp,
+    // test/algorithm/average_distance_to_neighbors.cpp): fused GPU path == the per-element reference path
+    {
+        std::vector<pcp::common::plane3d_t> planes(cloud.size());
+        pcp::algorithm::estimate_tangent_planes(std::execution::par, cloud.cbegin(), cloud.cend(), planes.begin(), point_map,
+                                                pcp::gpu::self_knn_map(octree, k),
+                                                pcp::algorithm::default_plane_transform<point_t, pcp::common::plane3d_t>);
+        std::vector<float> const means = pcp::algorithm::average_distances_to_neighbors(cloud.cbegin(), cloud.cend(), point_map,
+                                                                                         pcp::gpu::self_knn_map(octree, k));
+        for (std::size_t i = 0; i < cloud.size(); i += 97)
+        {
+            auto const neighbours = octree.nearest_neighbours(cloud[i], k, point_map);
+            auto const expect     = pcp::common::tangent_plane(neighbours.cbegin(), neighbours.cend(), point_map);
+            REQUIRE(pcp::common::are_vectors_equal(planes[i].point(), expect.point()));
+            REQUIRE(pcp::common::are_vectors_equal(planes[i].normal(), expect.normal()) ||
+                    pcp::common::are_vectors_equal(planes[i].normal(), -expect.normal()));
+            float sum = 0.f;
+            for (auto const& pj : neighbours) sum += std::sqrt(pcp::common::squared_distance(cloud[i], pj));
+            REQUIRE(pcp::common::floating_point_equals(means[i], sum / static_cast<float>(neighbours.size()), 1e-4f));
+        }
+        float const mu = pcp::algorithm::average_distance_to_neighbors(cloud.cbegin(), cloud.cend(), point_map, pcp::gpu::self_knn_map(octree, k));
+        REQUIRE(mu > 0.f && std::isfinite(mu));
+        // the 7-point plane KAT (test/common/plane3d.cpp:33-69)
+        auto const plane = pcp::common::tangent_plane(points.cbegin(), points.cend(), point_map);
+        REQUIRE(pcp::common::are_vectors_equal(plane.point(), point_t{0.f, 0.f, 0.f}));
+        REQUIRE(pcp::common::are_vectors_equal(plane.normal(), expected) || pcp::common::are_vectors_equal(plane.normal(), -expected));
+        REQUIRE(plane.contains(point_t{1.f, -1.f, 0.f}));
+    }
     // point views and index elements as Element types (examples/simple_example.cpp, examples/normals_estimation.cpp)
     std::vector<pcp::point_view_t> views;
     for (auto& p : cloud) views.push_back(pcp::point_view_t{&p});
