@@ -156,7 +156,19 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     torch.cuda.synchronize()
     rebuild_ms = (time.perf_counter() - t0) * 1e3 / reb
 
-    res = {"n": n, "k": k, "elapsed": elapsed, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
+    # config 3 shape on the same cloud: radius count r = 0.01 around every point (device resident)
+    range_ms = None
+    if name == "uniform_10m_k15" and world == 1:
+        d_rc = torch.empty(n, dtype=torch.int32, device=dev)
+        ix.range_count_self_dev(0.01, d_rc.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ix.range_count_self_dev(0.01, d_rc.data_ptr())
+        torch.cuda.synchronize()
+        range_ms = (time.perf_counter() - t0) * 1e3 / 3
+
+    res = {"n": n, "k": k, "elapsed": elapsed, "range_ms": range_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
            "mqps": n * steps / elapsed / 1e6, "first_build_ms": first_build_ms, "rebuild_ms": rebuild_ms,
            "profile": prof, "shard": (first, count), "pts": pts,
            "min_count": int(d_cnt.min().item()) if world == 1 else None}
@@ -198,6 +210,9 @@ def main():
              "shard_of_rank0": list(main_res["shard"])}
     if main_res["min_count"] is not None:
         extra["min_neighbours_found"] = main_res["min_count"]
+    if main_res.get("range_ms"):
+        extra["config3_range_count_r0.01_ms"] = round(main_res["range_ms"], 3)
+        extra["config3_range_count_r0.01_mqps"] = round(n / main_res["range_ms"] / 1e3, 1)
 
     roofline = None
     prof = main_res["profile"]

@@ -178,8 +178,10 @@ typedef struct pcpx_profile {
     float total_ms[PCPX_K_FAMILIES];
 } pcpx_profile;
 /* Diagnostic build of the self-kNN kernel (k <= 16): out_stats = {leaves visited, node expansions,
- * compactions, keys appended, wavefronts, seed leaves, 0, 0} summed over the launch. */
-int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t out_stats[8]);
+ * compactions, keys appended, query groups, seed leaves, 0...} summed over the launch in out_stats[0..16),
+ * followed (capacity permitting) by {start, end (100 MHz ticks), groups done, slowest group ticks, its id}
+ * of every persistent wave. */
+int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t* out_stats, uint64_t capacity);
 /* Diagnostic access to the build's radix sort: stable sort of (key, value) pairs by key. */
 int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
                           uint32_t* out_vals);

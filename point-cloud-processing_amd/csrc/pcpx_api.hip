@@ -672,17 +672,19 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
     return PCPX_OK;
 }
 
-int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t out_stats[8])
+int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_stats, uint64_t capacity)
 {
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
-    if (!out_stats || k == 0 || k > 16) return PCPX_ERR_INVALID;
+    if (!out_stats || capacity < 16 || k == 0 || k > 16) return PCPX_ERR_INVALID;
     DevBuf ds;
-    if ((st = ds.alloc(8 * sizeof(u64))) != PCPX_OK) return st;
-    PCPX_HIP(hipMemsetAsync(ds.p, 0, 8 * sizeof(u64), ix->stream));
+    const size_t cap = 16 + 5 * 65536;  // 16 counters + 5-word records of up to 65536 persistent waves
+    if ((st = ds.alloc(cap * sizeof(u64))) != PCPX_OK) return st;
+    PCPX_HIP(hipMemsetAsync(ds.p, 0, cap * sizeof(u64), ix->stream));
     if ((st = launch_knn_stats(*ix, k, eps, ds.as<unsigned long long>())) != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(out_stats, ds.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, ix->stream));
+    const size_t ncopy = capacity < cap ? capacity : cap;
+    PCPX_HIP(hipMemcpyAsync(out_stats, ds.p, ncopy * sizeof(u64), hipMemcpyDeviceToHost, ix->stream));
     PCPX_HIP(hipStreamSynchronize(ix->stream));
     return PCPX_OK;
 }

@@ -470,6 +470,26 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 #define PCPX_MINW 4  // k <= 16 kernel: hipcc lands at 91 VGPRs without scratch (5 waves/SIMD, what 8 KB of LDS per wave
                      // also allows); asking for 5 makes it spill 10 registers for the same occupancy
 #endif
+// 4 x the median of the finite seeded taus of the wave's valid lanes (inf if there is none): rank every lane's
+// value by counting (64 readlanes), pick the middle one.
+__device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane)
+{
+    const float inf = std::numeric_limits<float>::infinity();
+    const float x = (valid && tau < inf) ? tau : inf;
+    const u64 finite = __builtin_amdgcn_ballot_w64(x < inf);
+    const u32 nfinite = static_cast<u32>(__builtin_popcountll(finite));
+    if (nfinite == 0) return inf;
+    u32 rank = 0;
+#pragma unroll 8
+    for (u32 l = 0; l < 64; ++l) {
+        const float other = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
+        rank += (other < x || (other == x && l < lane)) ? 1u : 0u;
+    }
+    const u64 is_med = __builtin_amdgcn_ballot_w64(x < inf && rank == nfinite / 2);
+    const float med = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(is_med))));
+    return med * 4.f;
+}
+
 // k > 32: pass p of a multi-pass search returns the (at most 32) smallest keys strictly greater than the
 // last key of pass p-1, so ceil(k/32) passes enumerate the k nearest in order.  Keys (d2, sorted position)
 // are kept raw per query slot; k_assemble turns them into rows.
@@ -491,7 +511,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     constexpr int BUF = buf_rows(KCAP);  // usable rows; row BUF is the trash row
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
-    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0;
+    //                                           [6] groups that needed the second (uncapped) walk round
+    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0;
 
     // ---- my query ----
     const u32 p = g * GROUP + lane;
@@ -525,6 +546,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     for (int j = 0; j < KCAP; ++j) best[j] = (j < KCAP - static_cast<int>(k)) ? 0ull : PAD_KEY;
     const float inf = std::numeric_limits<float>::infinity();
     float tau = valid ? inf : -1.f;  // -1: an idle lane never accepts a candidate nor needs a node
+    bool active = valid;             // lanes still searching (the second walk round keeps only the failed ones)
     int cnt = 0;
     const u32 col_addr = lds_address(col);  // byte address of row 0 of this lane's column
     u32 wa = col_addr;                      // byte address of the next free row (PCPX_ASM_ACCEPT)
@@ -545,6 +567,15 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     wk.parent = 0;
     wk.l = 0;
     wk.done = true;
+    // First walk round: no lane searches farther than `cap` = 4 x the wave's median seeded tau.  A lane whose
+    // 64-point seed chunk lies across a Morton-curve jump starts with a tau hundreds of times too large and
+    // would drag the whole wave through thousands of leaves (measured: 7 ms groups against a 0.37 ms mean).
+    // After the round a lane is exact iff its k-th distance <= cap (then all its k nearest are within cap,
+    // and everything within cap was visited).  Lanes that fail -- genuinely isolated points -- get a second
+    // round over the tree with their real tau, accepting only d2 > cap so that nothing is seen twice.
+    float cap = inf;       // wave-uniform; inf = no cap
+    float lo_d2 = -1.f;    // wave-uniform; second round accepts only d2 > lo_d2
+    bool second_round = false;
     u32 seedcur = s0;
     bool walking = false;
     bool running = true;
@@ -561,12 +592,12 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             } while (have && leaf >= s0 && leaf < s1);
         }
         // compaction: buffer nearly full, or a lane could get a finite tau now, or draining at a phase end
-        if (PCPX_ASM_ACCEPT && !MULTI) cnt = static_cast<int>((wa - col_addr) >> 9);
+        if (PCPX_ASM_ACCEPT && !MULTI && !second_round) cnt = static_cast<int>((wa - col_addr) >> 9);
         bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
             compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
-            tau = valid ? nt : -1.f;
+            tau = active ? fminf(nt, cap) : -1.f;
             wa = col_addr + (static_cast<u32>(cnt) << 9);
             if (STATS) ++st_compact;
         }
@@ -584,13 +615,13 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
                 float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-                if (PCPX_ASM_ACCEPT && !MULTI) {
+                if (PCPX_ASM_ACCEPT && !MULTI && !second_round) {
                     if (STATS) st_app += (d2 <= tau && m >= eps) ? 1u : 0u;
                     append_if(d2, tau, m, eps, posbase + j, wa);  // NaN padding points fail d2 <= tau
                 } else {
                     const u64 key = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
                     float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
-                    bool acc = m2 >= eps;              // outside the eps-box (eps >= 0)
+                    bool acc = m2 >= eps && d2 > lo_d2;  // outside the eps-box (eps >= 0); not seen in round one
                     if (MULTI) acc = acc && (!has_lo || key > lo_key);
                     int slot = acc ? cnt : BUF;
                     col[slot * 64] = key;
@@ -599,11 +630,29 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 }
             }
         } else if (!trig) {
-            // drained: seed chunk -> tree walk -> finished
+            // drained: seed chunk -> capped tree walk -> (rarely) uncapped walk of the failed lanes -> finished
             if (!walking) {
                 walking = true;
+                cap = wave_radius_cap(tau, valid, lane);
+                tau = active ? fminf(tau, cap) : -1.f;
                 bool root_leaf = wk.start(t, need, st_expand);
                 (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
+            } else if (!second_round && cap < inf) {
+                const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+                const bool failed = valid && !(kth <= cap);
+                if (any_lane(failed)) {
+                    second_round = true;
+                    if (STATS) ++st_round2;
+                    lo_d2 = cap;
+                    cap = inf;
+                    active = failed;
+                    tau = active ? kth : -1.f;
+                    cnt = 0;
+                    bool root_leaf = wk.start(t, need, st_expand);
+                    (void)root_leaf;
+                } else {
+                    running = false;
+                }
             } else {
                 running = false;
             }
@@ -621,6 +670,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             atomicAdd(&stats[3], static_cast<unsigned long long>(app));
             atomicAdd(&stats[4], 1ull);
             atomicAdd(&stats[5], static_cast<unsigned long long>(s1 - s0));
+            atomicAdd(&stats[6], static_cast<unsigned long long>(st_round2));
         }
     }
 
@@ -750,6 +800,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
     const u32 ngroups = group_end - group_first;
     const u32 per = (ngroups + 7u) >> 3;
     const u32 home = blockIdx.x & 7u;
+    unsigned long long t_start = 0, t_max = 0, g_max = 0;
+    u32 n_done = 0;
+    if (STATS) t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock
     for (u32 s = 0; s < 8u; ++s) {
         const u32 q = (home + s) & 7u;
         const u32 qbeg = q * per;
@@ -759,8 +812,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) v
             if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (qbeg + gi >= qend) break;
+            unsigned long long tg = 0;
+            if (STATS) tg = __builtin_amdgcn_s_memrealtime();
             knn_group<KCAP, SELF, STATS, MULTI>(t, qv, group_first + qbeg + gi, k, eps, o, mp, stats, col, lane);
+            if (STATS) {
+                ++n_done;
+                tg = __builtin_amdgcn_s_memrealtime() - tg;
+                if (tg > t_max) {
+                    t_max = tg;
+                    g_max = group_first + qbeg + gi;
+                }
+            }
         }
+    }
+    if (STATS && lane == 0 && wib == 0) {  // per-wave diagnostic record: start, end, groups done, slowest group (ticks, id)
+        stats[16 + 5ull * blockIdx.x] = t_start;
+        stats[17 + 5ull * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        stats[18 + 5ull * blockIdx.x] = n_done;
+        stats[19 + 5ull * blockIdx.x] = t_max;
+        stats[20 + 5ull * blockIdx.x] = g_max;
     }
 }
 

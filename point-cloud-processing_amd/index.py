@@ -232,11 +232,16 @@ class Index:
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 
-    def debug_knn_stats(self, k, eps=1e-5):
-        out = (C.c_uint64 * 8)()
-        check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out))
-        names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves"]
-        return {n: int(out[i]) for i, n in enumerate(names)}
+    def debug_knn_stats(self, k, eps=1e-5, want_waves=False):
+        cap = 16 + 5 * 65536
+        out = (C.c_uint64 * cap)()
+        check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out, cap))
+        names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves", "second_round_groups"]
+        d = {n: int(out[i]) for i, n in enumerate(names)}
+        if want_waves:
+            w = np.frombuffer(out, dtype=np.uint64)[16:].reshape(-1, 5)
+            d["wave_times"] = w[w[:, 1] > 0].copy()
+        return d
 
     def profile_begin(self):
         check(self._lib.pcpx_profile_begin(self._h))
