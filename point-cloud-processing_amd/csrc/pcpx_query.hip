@@ -154,7 +154,7 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 // Rows of the per-lane append buffer.  A leaf may append LEAF keys, so a compaction runs whenever a
 // lane holds more than BUF - LEAF keys; fewer rows = less LDS per wave = more resident waves.
 #ifndef PCPX_BUF16
-#define PCPX_BUF16 15  // measured on MI355X (10 M uniform, k=15): 24 rows 416, 20 rows 451, 16 rows 490, 15 rows 512, 10 rows 489 Mq/s
+#define PCPX_BUF16 14  // measured on MI355X (10 M uniform, k=15, 5 waves/SIMD): 20 rows 688, 15 rows 758, 14 rows 793, 13 rows 785, 12 rows 771 Mq/s
 #endif
 __host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 16 ? PCPX_BUF16 : kcap + LEAF; }
 
@@ -467,8 +467,8 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
 #ifndef PCPX_MINW
-#define PCPX_MINW 4  // k <= 16 kernel: hipcc lands at 91 VGPRs without scratch (5 waves/SIMD, what 8 KB of LDS per wave
-                     // also allows); asking for 5 makes it spill 10 registers for the same occupancy
+#define PCPX_MINW 5  // k <= 16 kernel: <= 96 VGPRs = 5 waves/SIMD (measured 758 vs 725 Mq/s at 4 waves/SIMD); asking for 6
+                     // (<= 80 VGPRs) makes hipcc spill 172 B/lane to scratch and is 2x slower
 #endif
 // 4 x the median of the finite seeded taus of the wave's valid lanes (inf if there is none): rank every lane's
 // value by counting (64 readlanes), pick the middle one.
@@ -487,7 +487,10 @@ __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane
     }
     const u64 is_med = __builtin_amdgcn_ballot_w64(x < inf && rank == nfinite / 2);
     const float med = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(is_med))));
-    return med * 4.f;
+#ifndef PCPX_CAP_MULT
+#define PCPX_CAP_MULT 4.f
+#endif
+    return med * PCPX_CAP_MULT;
 }
 
 // k > 32: pass p of a multi-pass search returns the (at most 32) smallest keys strictly greater than the
@@ -567,12 +570,13 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     wk.parent = 0;
     wk.l = 0;
     wk.done = true;
-    // First walk round: no lane searches farther than `cap` = 4 x the wave's median seeded tau.  A lane whose
-    // 64-point seed chunk lies across a Morton-curve jump starts with a tau hundreds of times too large and
-    // would drag the whole wave through thousands of leaves (measured: 7 ms groups against a 0.37 ms mean).
-    // After the round a lane is exact iff its k-th distance <= cap (then all its k nearest are within cap,
-    // and everything within cap was visited).  Lanes that fail -- genuinely isolated points -- get a second
-    // round over the tree with their real tau, accepting only d2 > cap so that nothing is seen twice.
+    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = 4 x the
+    // wave's median seeded tau: a lane whose 64-point seed chunk lies across a Morton-curve jump starts with a
+    // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
+    // 7 ms groups against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all
+    // its k nearest are within cap, and everything within cap has been visited).  Lanes that fail -- points in
+    // genuinely sparse places -- go round again with cap x 4, accepting only the new shell lo_d2 < d2 <= cap so
+    // that nothing is seen twice, until they verify or the cap covers the whole cloud.
     float cap = inf;       // wave-uniform; inf = no cap
     float lo_d2 = -1.f;    // wave-uniform; second round accepts only d2 > lo_d2
     bool second_round = false;
@@ -637,16 +641,22 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 tau = active ? fminf(tau, cap) : -1.f;
                 bool root_leaf = wk.start(t, need, st_expand);
                 (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
-            } else if (!second_round && cap < inf) {
+            } else if (cap < inf) {
+                // a capped round ended: lanes whose k-th distance is within the cap are exact; the others go
+                // round again with 4x the radius^2, accepting only the new shell (lo_d2, cap]
                 const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
-                const bool failed = valid && !(kth <= cap);
+                const bool failed = active && !(kth <= cap);
                 if (any_lane(failed)) {
                     second_round = true;
                     if (STATS) ++st_round2;
                     lo_d2 = cap;
-                    cap = inf;
+                    const NodeBox root = load_const(t.nodes);
+                    const float ex = root.hi[0] - root.lo[0], ey = root.hi[1] - root.lo[1], ez = root.hi[2] - root.lo[2];
+                    const float diag2 = sq3(ex, ey, ez);
+                    cap = cap * PCPX_CAP_MULT;
+                    if (!(cap < diag2 * 4.f)) cap = inf;  // covers the whole cloud from any query inside 2x its box: last round
                     active = failed;
-                    tau = active ? kth : -1.f;
+                    tau = active ? fminf(kth, cap) : -1.f;
                     cnt = 0;
                     bool root_leaf = wk.start(t, need, st_expand);
                     (void)root_leaf;

@@ -5,7 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("point-cloud-processing_amd")
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
-pts = pkg.synthetic.uniform_cloud(n, 43)
+kind = sys.argv[2] if len(sys.argv) > 2 else "uniform"
+pts = pkg.synthetic.uniform_cloud(n, 43) if kind == "uniform" else pkg.synthetic.clustered_cloud(n, 44)
 ix = pkg.Index(pts)
 ix.debug_knn_stats(15)
 d = ix.debug_knn_stats(15, want_waves=True)
@@ -31,6 +32,7 @@ print("waves ending late:", len(late))
 top = w[np.argsort(-w[:, 3])][:12]
 print("slowest groups (ms, group id, of", int(w[:, 2].sum()), "groups; mean group ms =", round(float((w[:, 1] - w[:, 0])[worked].sum() / max(1, w[:, 2].sum())) / 1e5, 4), "):")
 for r in top: print("   ", round(r[3] / 1e5, 3), int(r[4]), " wave end at", round((r[1] - t0) / 1e5, 3))
+print("second-round groups:", d.get("second_round_groups"), " leaves/group:", round(d["leaves"] / d["waves"], 1), " compactions/group:", round(d["compactions"] / d["waves"], 1))
 print(json.dumps({"waves_launched": int(len(w)), "waves_that_got_work": int(worked.sum()), "kernel_ms": dur / 1e5,
                   "max_concurrent": int(conc.max()), "mean_concurrent": round(mean_conc, 1), "per_CU_mean": round(mean_conc / 256, 2),
                   "start_spread_ms": round(float(np.percentile(w[:, 0] - t0, 99)) / 1e5, 3),
