@@ -9,11 +9,16 @@ uniform synthetic cloud, k = 15, every point queries the cloud (kNN) and gets it
 1 M-point configs[1] figure is reported beside it under "extra" (DESIGN.md "Measurement" says why 10 M
 is the headline: it is the cloud the target is quoted on and 1 M does not fill 256 CUs).
 
-One STEP = one pass of the query hot path over the whole cloud with the index resident in HBM:
-k_knn (k nearest neighbours of every point, rows written to HBM) + k_normals (3x3 scatter matrix +
-eigen-solve per point).  The index build is timed separately and reported in "extra" (the reference's own
-benchmarks also build once and time queries: benchmark/spatial_data_structures_benchmark.cpp:243-264);
-"extra.value_incl_build" gives the rate with a rebuild inside every step.
+One STEP = one pass of the query hot path over the whole cloud with the index resident in HBM: one
+k_knn launch (k nearest neighbours of every point, rows written to HBM, with the 3x3 scatter matrix +
+eigen-solve of every point's neighbourhood fused in, normals written to HBM).  The index build is timed
+separately and reported in "extra" (the reference's own benchmarks also build once and time queries:
+benchmark/spatial_data_structures_benchmark.cpp:243-264); "extra.value_incl_build" gives the rate with a
+rebuild inside every step.
+
+Other workloads (--workload; never the driver's default): clustered_10m_k15 (configs[3]'s cloud) and
+uniform_50m_k32_stream (configs[4]: every step re-jitters the cloud, rebuilds the index and answers
+k = 32 for every point -- the rebuild is INSIDE the step there).
 
 Multi-GPU: one process per GPU.  Every rank holds the whole cloud (120 MB; exact kNN needs all
 candidates), computes the bounding box of ITS slice of the input, the per-rank boxes are all-gathered
@@ -40,8 +45,10 @@ WORKLOADS = {
     "uniform_10m_k15": ("uniform", 10_000_000, 43, 15),
     "uniform_1m_k15": ("uniform", 1_000_000, 42, 15),
     "clustered_10m_k15": ("clustered", 10_000_000, 44, 15),
-    "uniform_50m_k32": ("uniform", 50_000_000, 45, 32),
+    "uniform_50m_k32_stream": ("uniform", 50_000_000, 45, 32),
+    "uniform_10m_k32_stream": ("uniform", 10_000_000, 45, 32),
 }
+STREAMING = ("uniform_50m_k32_stream", "uniform_10m_k32_stream")  # rebuild inside the step, kNN rows only
 
 
 def make_cloud(pkg, kind, n, seed):
@@ -122,8 +129,21 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
     d_nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
 
-    def step():
-        ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
+    streaming = name in STREAMING
+    if streaming:
+        # configs[4]: the cloud moves between iterations (jitter U(-1e-3, 1e-3), seed 45 + it); two jittered
+        # copies alternate so every step rebuilds on coordinates that differ from the previous step's
+        variants = [d_pts] + [torch.from_numpy(np.clip(pkg.synthetic.jitter(pts, seed + it), grid[:3], grid[3:])).to(dev)
+                              for it in (1, 2)]
+        it_no = [0]
+
+        def step():
+            it_no[0] += 1
+            ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, voxel_grid=grid)
+            ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
+    else:
+        def step():
+            ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
 
     for _ in range(warmup):
         step()
@@ -222,7 +242,7 @@ def main():
         q_per_launch = main_res["shard"][1]
         # kNN + normals with the indices also written = 12 B read + 4k B index
         # write + 12 B normal write per query (84 B at k = 15); the fused k_knn launch does exactly that
-        bytes_per_q = 12 + 4 * k + 12
+        bytes_per_q = 12 + 4 * k + (0 if args.workload in STREAMING else 12)
         achieved = q_per_launch * bytes_per_q / avg_s
         roofline = {"bound": "hbm", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
@@ -256,7 +276,9 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
-        line = {"metric": "kNN+normal-estimation Mqueries/s (k=15)", "value": round(main_res["mqps"], 3),
+        metric = ("kNN+normal-estimation Mqueries/s (k=%d)" % k) if args.workload not in STREAMING else \
+                 ("index rebuild + kNN Mqueries/s (k=%d)" % k)
+        line = {"metric": metric, "value": round(main_res["mqps"], 3),
                 "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

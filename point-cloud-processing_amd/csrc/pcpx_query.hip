@@ -61,6 +61,7 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx *
 // of sq3(p - q) for every p inside the box; NaN for a padding node.
 __device__ __forceinline__ float box_d2(const NodeBox& b, float qx, float qy, float qz)
 {
+    // (v_med3_f32(q, lo, hi) takes two SGPR operands, which gfx9 VALU encodings do not allow: no cheaper)
     float dx = fmaxf(fmaxf(b.lo[0] - qx, qx - b.hi[0]), 0.f);
     float dy = fmaxf(fmaxf(b.lo[1] - qy, qy - b.hi[1]), 0.f);
     float dz = fmaxf(fmaxf(b.lo[2] - qz, qz - b.hi[2]), 0.f);
@@ -70,6 +71,8 @@ __device__ __forceinline__ float box_d2(const NodeBox& b, float qx, float qy, fl
 struct NodeBox4 {
     NodeBox c[W];
 };
+
+__device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
 // ---- selection network on 64-bit keys -------------------------------------------------------------
 // Keys are (float32 d2 >= 0 bits) << 32 | u32: as IEEE doubles they are finite, non-negative and
@@ -178,6 +181,43 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
     bitonic_merge<KCAP>(best);
 }
 
+#ifndef PCPX_COMPACT16
+#define PCPX_COMPACT16 1
+#endif
+// compact() for KCAP 16 with a short cut: when no lane of the wave holds more than 8 keys (the usual case late in
+// a walk, when a leaf adds one or two keys per lane) only 8 rows are read and sorted (24 compare-exchanges
+// instead of 80); the tail of the new list is PAD_KEY either way and the merge with best[] is shared.
+template <int BUF>
+__device__ __forceinline__ void compact16(u64 (&best)[16], u64* __restrict__ col, int& cnt)
+{
+    static_assert(BUF >= 8 && BUF <= 16, "rows");
+    u64 nw[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
+    if (!any_lane(cnt > 8)) {
+        u64 lo8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo8[j] = nw[j];
+        bitonic_sort<8>(lo8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nw[j] = lo8[j];
+#pragma unroll
+        for (int j = 8; j < 16; ++j) nw[j] = PAD_KEY;
+    } else {
+#pragma unroll
+        for (int j = 8; j < 16; ++j) nw[j] = j < BUF ? col[j * 64] : PAD_KEY;
+#pragma unroll
+        for (int j = 8; j < BUF; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
+        bitonic_sort<16>(nw);
+    }
+    cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) best[j] = key_min(best[j], nw[15 - j]);
+    bitonic_merge<16>(best);
+}
+
 // ---- exec-masked append (hand-written: hipcc has no way to emit v_cmpx from C++) ---------------------
 // Appends key (d2, pos) to the lane's LDS column at byte address `wa` iff d2 <= tau and m >= eps, then
 // advances wa by one row (512 B).  v_cmpx writes EXEC directly, so the two tests cost 2 VALU and the LDS
@@ -187,17 +227,24 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
 #endif
-__device__ __forceinline__ void append_if(float d2, float tau, float m, float eps, u32 pos, u32& wa)
+__device__ __forceinline__ u64 save_exec()
 {
-    unsigned long long saved;
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+    u64 saved;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(saved));
+    return saved;
+}
+// `saved` = EXEC on entry (save_exec() once per leaf: the walk is wave-uniform, EXEC does not change inside
+// a leaf); also steps pos to the next point of the leaf, outside the mask.
+__device__ __forceinline__ void append_if(float d2, float tau, float m, float eps, u32& pos, u32& wa, u64 saved)
+{
+    asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
                  "v_cmpx_le_f32_e32 %[eps], %[m]\n\t"
                  "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
                  "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [wa] "+v"(wa), [sv] "=&s"(saved)
-                 : [d2] "v"(d2), [tau] "v"(tau), [m] "v"(m), [eps] "s"(eps), [pos] "v"(pos)
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_u32_e32 %[pos], 1, %[pos]"
+                 : [wa] "+v"(wa), [pos] "+v"(pos)
+                 : [d2] "v"(d2), [tau] "v"(tau), [m] "v"(m), [eps] "s"(eps), [sv] "s"(saved)
                  : "vcc", "memory");
 }
 
@@ -224,30 +271,35 @@ __device__ __forceinline__ u32 lds_address(const void* p)
 }
 
 // ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
-__device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
 // All members are wave-uniform (SGPRs).  next() yields, in Morton order, every leaf whose box is still
-// needed by at least one lane at the time its parent is expanded.  State: `pend` holds one nibble per
-// height l = the children (height l) of the current ancestor at height l+1 that are still to visit;
-// `parent` is that ancestor's heap id.
+// needed by at least one lane at the time its parent is expanded.  State: bit 4*h + c of `pend` = child c
+// (a node of height h; leaves have height 0) of the current ancestor of height h+1 is still to visit.  A
+// depth-first walk always continues with the LOWEST set bit of pend, so popping is one find-first-set: no
+// per-level loop.  `ploc` is the level-local index of the ancestor of height l+1 (node ids are never
+// stored: heap id = (4^d - 1)/3 + local index at tree level d, and a leaf's local index is its number).
 struct Walker {
     u64 pend;
-    u32 parent;
+    u32 ploc;
     int l;
-    bool done;
 
+    // first heap id of tree level d >= 1: (4^d - 1) / 3 = 0b0101...01 (d pairs)
+    static __device__ __forceinline__ u32 level_base(int d) { return 0x55555555u >> (32 - 2 * d); }
+
+    // bit c set: child c of the node with local index `loc` at tree level d is needed by some lane
     template <class Need>
-    __device__ __forceinline__ u32 child_mask(const TreeView& t, u32 node, Need&& need)
+    __device__ __forceinline__ u32 child_mask(const TreeView& t, int d, u32 loc, Need&& need)
     {
+        const u32 first_child = level_base(d + 1) + (loc << LOGW);  // heap id of child 0
 #if defined(PCPX_NODE_VMEM)
-        const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1);
+        const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + first_child);
 #else
-        const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + (static_cast<u64>(node) << LOGW) + 1));
+        const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
 #endif
         u32 m = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
-        return m;
+        return __builtin_amdgcn_readfirstlane(m);  // keeps the walk state in SGPRs (hipcc may build m with v_cndmask)
     }
 
     // returns true if the root itself is the single leaf (depth 0) and is needed
@@ -255,42 +307,36 @@ struct Walker {
     __device__ __forceinline__ bool start(const TreeView& t, Need&& need, u32& n_expand)
     {
         pend = 0;
-        parent = 0;
+        ploc = 0;
         l = 0;
-        done = true;
         if (t.nleaves == 0) return false;
         const NodeBox root = load_const(t.nodes);
         if (!any_lane(need(root))) return false;
         if (t.depth == 0) return true;
         ++n_expand;
         l = t.depth - 1;
-        pend = static_cast<u64>(child_mask(t, 0u, need)) << (W * l);
-        done = false;
+        pend = static_cast<u64>(child_mask(t, 0, 0u, need)) << (W * l);
         return false;
     }
 
     template <class Need>
     __device__ __forceinline__ bool next(const TreeView& t, Need&& need, u32& leaf, u32& n_expand)
     {
-        while (!done) {
-            u32 mm = static_cast<u32>(pend >> (W * l)) & ((1u << W) - 1u);
-            if (mm == 0) {
-                ++l;
-                if (l >= t.depth) done = true;
-                parent = (parent - 1u) >> LOGW;
-                continue;
-            }
-            u32 b = static_cast<u32>(__builtin_ctz(mm));
-            pend &= ~(1ull << (W * l + b));
-            u32 child = (parent << LOGW) + 1u + b;
-            if (l == 0) {
-                leaf = child - t.leaf0;
+        while (pend != 0) {
+            const int bit = __builtin_ctzll(pend);
+            pend &= ~(1ull << bit);
+            const int h = bit >> LOGW;
+            const u32 loc = ((ploc >> (LOGW * (h - l))) << LOGW) + (static_cast<u32>(bit) & (W - 1u));  // climb h - l levels, step down
+            if (h == 0) {
+                ploc = loc >> LOGW;
+                l = 0;
+                leaf = loc;
                 return true;
             }
             ++n_expand;
-            --l;
-            parent = child;
-            pend |= static_cast<u64>(child_mask(t, child, need)) << (W * l);
+            l = h - 1;
+            ploc = loc;
+            pend |= static_cast<u64>(child_mask(t, t.depth - h, loc, need)) << (W * l);
         }
         return false;
     }
@@ -567,9 +613,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // tree walk), runs the one compaction site if needed, then the one candidate site.
     Walker wk;
     wk.pend = 0;
-    wk.parent = 0;
+    wk.ploc = 0;
     wk.l = 0;
-    wk.done = true;
     // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = 4 x the
     // wave's median seeded tau: a lane whose 64-point seed chunk lies across a Morton-curve jump starts with a
     // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
@@ -599,7 +644,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (PCPX_ASM_ACCEPT && !MULTI && !second_round) cnt = static_cast<int>((wa - col_addr) >> 9);
         bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
-            compact<KCAP, BUF>(best, col, cnt);
+            if constexpr (PCPX_COMPACT16 && KCAP == 16 && BUF <= 16) compact16<BUF>(best, col, cnt);
+            else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
             wa = col_addr + (static_cast<u32>(cnt) << 9);
@@ -614,15 +660,24 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             const Leaf lf = load_const(t.leaves + leaf);
 #endif
             const u32 posbase = leaf * LEAF;
+            // two copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
+            if (PCPX_ASM_ACCEPT && !MULTI && !second_round) {
+                u32 posv = posbase;
+                const u64 saved = save_exec();
 #pragma unroll
-            for (int j = 0; j < LEAF; ++j) {
-                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-                float d2 = sq3(dx, dy, dz);
-                float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-                if (PCPX_ASM_ACCEPT && !MULTI && !second_round) {
+                for (int j = 0; j < LEAF; ++j) {
+                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                    float d2 = sq3(dx, dy, dz);
+                    float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
                     if (STATS) st_app += (d2 <= tau && m >= eps) ? 1u : 0u;
-                    append_if(d2, tau, m, eps, posbase + j, wa);  // NaN padding points fail d2 <= tau
-                } else {
+                    append_if(d2, tau, m, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < LEAF; ++j) {
+                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                    float d2 = sq3(dx, dy, dz);
+                    float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
                     const u64 key = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
                     float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
                     bool acc = m2 >= eps && d2 > lo_d2;  // outside the eps-box (eps >= 0); not seen in round one

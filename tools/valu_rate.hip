@@ -1,0 +1,167 @@
+// valu_rate.hip -- issue cost (cycles per wave-instruction per SIMD) of the VALU/LDS instructions k_knn is made
+// of, measured on the device: decides which instruction mixes are worth hand-writing (DESIGN.md "Roofline").
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
+// Each kernel runs ITER iterations of 32 independent copies of one instruction; grid = CUs x 4 SIMDs x W waves.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x)                                                                   \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));           \
+            std::exit(1);                                                          \
+        }                                                                          \
+    } while (0)
+
+constexpr int ITER = 4096;
+
+#define REP4(s) s s s s
+#define REP8(s) REP4(s) REP4(s)
+
+// 8 accumulators a0..a7 (32-bit) / d0..d7 (64-bit), 4 rounds per iteration = 32 instructions
+#define KERNEL32(name, body)                                                                             \
+    __global__ __launch_bounds__(64) void name(float* out, float seed)                                    \
+    {                                                                                                    \
+        float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,   \
+              a6 = a0 + 6, a7 = a0 + 7, b = seed * 0.5f, c = seed * 0.25f;                                \
+        for (int i = 0; i < ITER; ++i) {                                                                 \
+            asm volatile(REP4(body) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), \
+                         "+v"(a7)                                                                        \
+                         : "v"(b), "v"(c)                                                                \
+                         : "vcc");                                                                       \
+        }                                                                                                \
+        out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                        \
+    }
+
+#define KERNEL64(name, body)                                                                             \
+    __global__ __launch_bounds__(64) void name(float* out, float seed)                                    \
+    {                                                                                                    \
+        double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,  \
+               a6 = a0 + 6, a7 = a0 + 7, b = seed * 0.5, c = seed * 0.25;                                 \
+        for (int i = 0; i < ITER; ++i) {                                                                 \
+            asm volatile(REP4(body) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), \
+                         "+v"(a7)                                                                        \
+                         : "v"(b), "v"(c)                                                                \
+                         : "vcc");                                                                       \
+        }                                                                                                \
+        out[blockIdx.x * 64 + threadIdx.x] = static_cast<float>(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);   \
+    }
+
+#define EACH8(op, tail)                                                                                          \
+    op " %0, %0, " tail "\n" op " %1, %1, " tail "\n" op " %2, %2, " tail "\n" op " %3, %3, " tail "\n" op " %4, %4, " tail \
+       "\n" op " %5, %5, " tail "\n" op " %6, %6, " tail "\n" op " %7, %7, " tail "\n"
+
+KERNEL32(k_mul_f32, EACH8("v_mul_f32", "%8"))
+KERNEL32(k_add_f32, EACH8("v_add_f32", "%8"))
+KERNEL32(k_max3_f32, EACH8("v_max3_f32", "%8, %9"))
+KERNEL32(k_med3_f32, EACH8("v_med3_f32", "%8, %9"))
+KERNEL32(k_cndmask, EACH8("v_cndmask_b32", "%8, vcc"))
+KERNEL32(k_cmp_f32, REP8("v_cmp_le_f32 vcc, %0, %8\n"))
+KERNEL32(k_mov_b32, "v_mov_b32 %0, %8\nv_mov_b32 %1, %8\nv_mov_b32 %2, %8\nv_mov_b32 %3, %8\nv_mov_b32 %4, %8\nv_mov_b32 %5, "
+                    "%8\nv_mov_b32 %6, %8\nv_mov_b32 %7, %8\n")
+KERNEL64(k_pk_mul_f32, EACH8("v_pk_mul_f32", "%8"))
+KERNEL64(k_pk_add_f32, EACH8("v_pk_add_f32", "%8"))
+KERNEL64(k_pk_fma_f32, EACH8("v_pk_fma_f32", "%8, %9"))
+KERNEL64(k_min_f64, EACH8("v_min_f64", "%8"))
+KERNEL64(k_max_f64, EACH8("v_max_f64", "%8"))
+KERNEL64(k_add_f64, EACH8("v_add_f64", "%8"))
+KERNEL64(k_cmp_u64, REP8("v_cmp_lt_u64 vcc, %0, %8\n"))
+KERNEL64(k_mov_b64, "v_mov_b64 %0, %8\nv_mov_b64 %1, %8\nv_mov_b64 %2, %8\nv_mov_b64 %3, %8\nv_mov_b64 %4, %8\nv_mov_b64 %5, "
+                    "%8\nv_mov_b64 %6, %8\nv_mov_b64 %7, %8\n")
+KERNEL64(k_pk_mov_b32, EACH8("v_pk_mov_b32", "%8"))
+
+// scalar ALU: 32 s_add_u32 per iteration on 8 SGPRs
+__global__ __launch_bounds__(64) void k_salu(float* out, float seed)
+{
+    int s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile(REP8("s_add_u32 %0, %0, 3\ns_add_u32 %1, %1, 5\ns_add_u32 %2, %2, 7\ns_add_u32 %3, %3, 9\n")
+                     : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
+                     :
+                     : "scc");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = seed + (s0 + s1 + s2 + s3);
+}
+
+// VALU and SALU interleaved 1:1 (does scalar issue overlap vector issue of the same wave / other waves?)
+__global__ __launch_bounds__(64) void k_valu_salu(float* out, float seed)
+{
+    int s0 = blockIdx.x, s1 = s0 + 1;
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, b = seed * 0.5f;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile(REP8("v_mul_f32 %0, %0, %4\ns_add_u32 %2, %2, 3\nv_mul_f32 %1, %1, %4\ns_add_u32 %3, %3, 5\n")
+                     : "+v"(a0), "+v"(a1), "+s"(s0), "+s"(s1)
+                     : "v"(b)
+                     : "scc");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + (s0 + s1);
+}
+
+// LDS: ds_write2_b32 to the lane's own column (stride 64 dwords), 16 per iteration
+__global__ __launch_bounds__(64) void k_ds_write2(float* out, float seed)
+{
+    __shared__ float buf[64 * 16];
+    float a0 = seed + threadIdx.x;
+    unsigned addr = threadIdx.x * 4;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile(REP8("ds_write2_b32 %0, %1, %1 offset1:64\nds_write2_b32 %0, %1, %1 offset0:128 offset1:192\n")
+                     :
+                     : "v"(addr), "v"(a0)
+                     : "memory");
+    }
+    __syncthreads();
+    out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x];
+}
+
+struct Case {
+    const char* name;
+    void (*fn)(float*, float);
+    int per_iter;
+};
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const double mhz = prop.clockRate / 1e3;  // kHz -> MHz
+    std::printf("device %s: %d CUs, clock %.0f MHz\n", prop.name, cus, mhz);
+    float* out;
+    CHECK(hipMalloc(&out, sizeof(float) * 64 * cus * 4 * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const Case cases[] = {
+        {"v_mul_f32", k_mul_f32, 32},       {"v_add_f32", k_add_f32, 32},       {"v_max3_f32", k_max3_f32, 32},
+        {"v_med3_f32", k_med3_f32, 32},     {"v_cndmask_b32", k_cndmask, 32},   {"v_cmp_le_f32", k_cmp_f32, 32},
+        {"v_mov_b32", k_mov_b32, 32},       {"v_pk_mul_f32", k_pk_mul_f32, 32}, {"v_pk_add_f32", k_pk_add_f32, 32},
+        {"v_pk_fma_f32", k_pk_fma_f32, 32}, {"v_min_f64", k_min_f64, 32},       {"v_max_f64", k_max_f64, 32},
+        {"v_add_f64", k_add_f64, 32},       {"v_cmp_lt_u64", k_cmp_u64, 32},    {"v_mov_b64", k_mov_b64, 32},
+        {"v_pk_mov_b32", k_pk_mov_b32, 32}, {"s_add_u32", k_salu, 32},          {"v_mul+s_add 1:1", k_valu_salu, 32},
+        {"ds_write2_b32", k_ds_write2, 16},
+    };
+    std::printf("%-18s %10s %10s %10s   (cycles per wave-instruction per SIMD at 1, 2, 4 waves/SIMD)\n", "instruction", "w=1", "w=2",
+                "w=4");
+    for (const Case& c : cases) {
+        std::printf("%-18s", c.name);
+        for (int w : {1, 2, 4}) {
+            const int grid = cus * 4 * w;
+            c.fn<<<grid, 64>>>(out, 1.0f);  // warm-up
+            CHECK(hipEventRecord(e0));
+            c.fn<<<grid, 64>>>(out, 1.0f);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double cycles = ms * 1e-3 * mhz * 1e6;
+            const double instr_per_simd = static_cast<double>(ITER) * c.per_iter * w;
+            std::printf(" %10.2f", cycles / instr_per_simd);
+        }
+        std::printf("\n");
+    }
+    CHECK(hipFree(out));
+    return 0;
+}
