@@ -159,38 +159,21 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 #ifndef PCPX_BUF16
 #define PCPX_BUF16 14  // measured on MI355X (10 M uniform, k=15, 5 waves/SIMD): 20 rows 688, 15 rows 758, 14 rows 793, 13 rows 785, 12 rows 771 Mq/s
 #endif
-__host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 16 ? PCPX_BUF16 : kcap + LEAF; }
+#ifndef PCPX_BUF32
+#define PCPX_BUF32 16
+#endif
+__host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 16 ? PCPX_BUF16 : PCPX_BUF32; }
 
-// Fold the first KCAP buffered keys of this lane into its sorted best-list; leftovers move down.
-// All LDS traffic is unconditional (stale slots are masked to PAD_KEY in registers): no exec games.
+// Fold this lane's buffered keys (cnt <= BUF <= 16) into its sorted best-list.  All LDS traffic is
+// unconditional (stale slots are masked to PAD_KEY in registers): no exec games.  The new keys are sorted
+// ascending in registers -- only 8 of them when no lane of the wave holds more than 8 (the usual case late
+// in a walk, when a leaf adds one or two keys per lane: 24 compare-exchanges instead of 80) -- then
+// best[KCAP-1-j] = min(best[KCAP-1-j], new[j]) leaves the KCAP smallest of both as a bitonic sequence,
+// which one merge network sorts.  At most 16 new keys are live beside best[]: KCAP 32 fits 128 VGPRs.
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
-    u64 nw[KCAP];
-    constexpr int TAKE = BUF < KCAP ? BUF : KCAP;
-#pragma unroll
-    for (int j = 0; j < KCAP; ++j) nw[j] = j < TAKE ? col[j * 64] : PAD_KEY;
-#pragma unroll
-    for (int j = 0; j < TAKE; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
-#pragma unroll
-    for (int j = 0; j < BUF - KCAP; ++j) col[j * 64] = col[(KCAP + j) * 64];
-    cnt = cnt > KCAP ? cnt - KCAP : 0;
-    bitonic_sort<KCAP>(nw);
-#pragma unroll
-    for (int j = 0; j < KCAP; ++j) best[j] = key_min(best[j], nw[KCAP - 1 - j]);
-    bitonic_merge<KCAP>(best);
-}
-
-#ifndef PCPX_COMPACT16
-#define PCPX_COMPACT16 1
-#endif
-// compact() for KCAP 16 with a short cut: when no lane of the wave holds more than 8 keys (the usual case late in
-// a walk, when a leaf adds one or two keys per lane) only 8 rows are read and sorted (24 compare-exchanges
-// instead of 80); the tail of the new list is PAD_KEY either way and the merge with best[] is shared.
-template <int BUF>
-__device__ __forceinline__ void compact16(u64 (&best)[16], u64* __restrict__ col, int& cnt)
-{
-    static_assert(BUF >= 8 && BUF <= 16, "rows");
+    static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 16, "rows");
     u64 nw[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
@@ -214,8 +197,8 @@ __device__ __forceinline__ void compact16(u64 (&best)[16], u64* __restrict__ col
     }
     cnt = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) best[j] = key_min(best[j], nw[15 - j]);
-    bitonic_merge<16>(best);
+    for (int j = 0; j < 16; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+    bitonic_merge<KCAP>(best);
 }
 
 // ---- exec-masked append (hand-written: hipcc has no way to emit v_cmpx from C++) ---------------------
@@ -512,6 +495,9 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 // ------------------------------------------------------------------------------------------------
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
+#ifndef PCPX_MINW32
+#define PCPX_MINW32 4  // k <= 32 kernel: <= 128 VGPRs = 4 waves/SIMD
+#endif
 #ifndef PCPX_MINW
 #define PCPX_MINW 5  // k <= 16 kernel: <= 96 VGPRs = 5 waves/SIMD (measured 758 vs 725 Mq/s at 4 waves/SIMD); asking for 6
                      // (<= 80 VGPRs) makes hipcc spill 172 B/lane to scratch and is 2x slower
@@ -644,8 +630,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (PCPX_ASM_ACCEPT && !MULTI && !second_round) cnt = static_cast<int>((wa - col_addr) >> 9);
         bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
         if (trig) {
-            if constexpr (PCPX_COMPACT16 && KCAP == 16 && BUF <= 16) compact16<BUF>(best, col, cnt);
-            else compact<KCAP, BUF>(best, col, cnt);
+            compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
             wa = col_addr + (static_cast<u32>(cnt) << 9);
@@ -853,7 +838,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
 template <int KCAP, bool SELF, bool STATS, bool MULTI = false>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : 1) void k_knn(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
     TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, KnnOutputs o, MultiPass mp,
     u32* __restrict__ queue, unsigned long long* __restrict__ stats)
 {
