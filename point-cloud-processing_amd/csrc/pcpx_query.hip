@@ -210,6 +210,8 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
 #endif
+// (tried: jumping over the eps test / LDS write / address bump with s_cbranch_execz when no lane is within tau
+// of a point: the branch costs more than the skipped issue slots, 998 vs 1048 Mq/s)
 __device__ __forceinline__ u64 save_exec()
 {
     u64 saved;
@@ -218,8 +220,10 @@ __device__ __forceinline__ u64 save_exec()
 }
 // `saved` = EXEC on entry (save_exec() once per leaf: the walk is wave-uniform, EXEC does not change inside
 // a leaf); also steps pos to the next point of the leaf, outside the mask.
-__device__ __forceinline__ void append_if(float d2, float tau, float m, float eps, u32& pos, u32& wa, u64 saved)
+__device__ __forceinline__ void append_if(float d2, float tau, float dx, float dy, float dz, float eps, u32& pos, u32& wa,
+                                          u64 saved)
 {
+    float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
     asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
                  "v_cmpx_le_f32_e32 %[eps], %[m]\n\t"
                  "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
@@ -502,7 +506,7 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 #define PCPX_MINW 5  // k <= 16 kernel: <= 96 VGPRs = 5 waves/SIMD (measured 758 vs 725 Mq/s at 4 waves/SIMD); asking for 6
                      // (<= 80 VGPRs) makes hipcc spill 172 B/lane to scratch and is 2x slower
 #endif
-// 4 x the median of the finite seeded taus of the wave's valid lanes (inf if there is none): rank every lane's
+// PCPX_CAP_MULT x the median of the finite seeded taus of the wave's valid lanes (inf if there is none): rank every lane's
 // value by counting (64 readlanes), pick the middle one.
 __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane)
 {
@@ -520,7 +524,10 @@ __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane
     const u64 is_med = __builtin_amdgcn_ballot_w64(x < inf && rank == nfinite / 2);
     const float med = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(is_med))));
 #ifndef PCPX_CAP_MULT
-#define PCPX_CAP_MULT 4.f
+#define PCPX_CAP_MULT 1.25f  // measured, 10 M points, Mq/s uniform / clustered: 4: 1022 / 891, 2: 1048 / 957, 1.5: 1062 / 958, 1.25: 1079 / 960, 1: 1097 / 943
+#endif
+#ifndef PCPX_CAP_GROW
+#define PCPX_CAP_GROW 4.f  // radius^2 growth per further round
 #endif
     return med * PCPX_CAP_MULT;
 }
@@ -601,7 +608,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     wk.pend = 0;
     wk.ploc = 0;
     wk.l = 0;
-    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = 4 x the
+    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = PCPX_CAP_MULT (1.25) x the
     // wave's median seeded tau: a lane whose 64-point seed chunk lies across a Morton-curve jump starts with a
     // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
     // 7 ms groups against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all
@@ -653,9 +660,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 for (int j = 0; j < LEAF; ++j) {
                     float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                     float d2 = sq3(dx, dy, dz);
-                    float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-                    if (STATS) st_app += (d2 <= tau && m >= eps) ? 1u : 0u;
-                    append_if(d2, tau, m, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
+                    if (STATS) st_app += (d2 <= tau && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
+                    append_if(d2, tau, dx, dy, dz, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
                 }
             } else {
 #pragma unroll
@@ -693,7 +699,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                     const NodeBox root = load_const(t.nodes);
                     const float ex = root.hi[0] - root.lo[0], ey = root.hi[1] - root.lo[1], ez = root.hi[2] - root.lo[2];
                     const float diag2 = sq3(ex, ey, ez);
-                    cap = cap * PCPX_CAP_MULT;
+                    cap = cap * PCPX_CAP_GROW;
                     if (!(cap < diag2 * 4.f)) cap = inf;  // covers the whole cloud from any query inside 2x its box: last round
                     active = failed;
                     tau = active ? fminf(kth, cap) : -1.f;
