@@ -506,29 +506,35 @@ __device__ void eig3_smallest(float a00, float a10, float a20, float a11, float 
 #define PCPX_MINW 5  // k <= 16 kernel: <= 96 VGPRs = 5 waves/SIMD (measured 758 vs 725 Mq/s at 4 waves/SIMD); asking for 6
                      // (<= 80 VGPRs) makes hipcc spill 172 B/lane to scratch and is 2x slower
 #endif
-// PCPX_CAP_MULT x the median of the finite seeded taus of the wave's valid lanes (inf if there is none): rank every lane's
-// value by counting (64 readlanes), pick the middle one.
-__device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane)
-{
-    const float inf = std::numeric_limits<float>::infinity();
-    const float x = (valid && tau < inf) ? tau : inf;
-    const u64 finite = __builtin_amdgcn_ballot_w64(x < inf);
-    const u32 nfinite = static_cast<u32>(__builtin_popcountll(finite));
-    if (nfinite == 0) return inf;
-    u32 rank = 0;
-#pragma unroll 8
-    for (u32 l = 0; l < 64; ++l) {
-        const float other = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
-        rank += (other < x || (other == x && l < lane)) ? 1u : 0u;
-    }
-    const u64 is_med = __builtin_amdgcn_ballot_w64(x < inf && rank == nfinite / 2);
-    const float med = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(is_med))));
+// PCPX_CAP_MULT x the median of the finite seeded taus of a sample of the wave's valid lanes (every fourth lane:
+// 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
+// The cap only steers the work, never the result (a lane that fails the cap goes round again).
 #ifndef PCPX_CAP_MULT
 #define PCPX_CAP_MULT 1.25f  // measured, 10 M points, Mq/s uniform / clustered: 4: 1022 / 891, 2: 1048 / 957, 1.5: 1062 / 958, 1.25: 1079 / 960, 1: 1097 / 943
 #endif
 #ifndef PCPX_CAP_GROW
 #define PCPX_CAP_GROW 4.f  // radius^2 growth per further round
 #endif
+__device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane)
+{
+    const float inf = std::numeric_limits<float>::infinity();
+    const bool sample = (lane & 3u) == 1u;
+    const float x = (valid && tau < inf) ? tau : inf;
+    const u64 finite = __builtin_amdgcn_ballot_w64(sample && x < inf);
+    const u32 nfinite = static_cast<u32>(__builtin_popcountll(finite));
+    if (nfinite == 0) {  // no finite sample: any finite lane, or none
+        const u64 any = __builtin_amdgcn_ballot_w64(x < inf);
+        if (any == 0) return inf;
+        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(any)))) * PCPX_CAP_MULT;
+    }
+    u32 rank = 0;
+#pragma unroll
+    for (u32 l = 1; l < 64; l += 4) {
+        const float other = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
+        rank += (other < x || (other == x && l < lane)) ? 1u : 0u;
+    }
+    const u64 is_med = __builtin_amdgcn_ballot_w64(sample && x < inf && rank == nfinite / 2);
+    const float med = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(is_med))));
     return med * PCPX_CAP_MULT;
 }
 
@@ -555,6 +561,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
     u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0;
+    // [7] shader cycles in the walker (pop + node expansions), [8] in compactions, [9] in leaf candidates,
+    // [10] in the whole search loop, [11] whole group incl. the epilogue (id gather, tie repair, stores, fused normal)
+    unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0;
+    if (STATS) tc0 = __builtin_amdgcn_s_memtime();
 
     // ---- my query ----
     const u32 p = g * GROUP + lane;
@@ -592,6 +602,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     int cnt = 0;
     const u32 col_addr = lds_address(col);  // byte address of row 0 of this lane's column
     u32 wa = col_addr;                      // byte address of the next free row (PCPX_ASM_ACCEPT)
+    const u32 wa_full = col_addr + (static_cast<u32>(BUF - LEAF) << 9);  // beyond this a leaf might not fit
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
 
@@ -629,23 +640,37 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             leaf = seedcur;
             seedcur += have ? 1u : 0u;
         } else {
+            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
             do {
                 have = wk.next(t, need, leaf, st_expand);
             } while (have && leaf >= s0 && leaf < s1);
+            if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
         }
-        // compaction: buffer nearly full, or a lane could get a finite tau now, or draining at a phase end
-        if (PCPX_ASM_ACCEPT && !MULTI && !second_round) cnt = static_cast<int>((wa - col_addr) >> 9);
-        bool trig = have ? any_lane(cnt > BUF - LEAF || (tau == inf && cnt >= static_cast<int>(k))) : any_lane(cnt > 0);
+        // compaction: buffer nearly full (a leaf may add LEAF keys), or draining at a phase end.  The fast accept
+        // path keeps only the write address `wa`, the other paths only `cnt`.
+        const bool fast = PCPX_ASM_ACCEPT && !MULTI && !second_round;
+        if (!fast) wa = col_addr + (static_cast<u32>(cnt) << 9);
+        bool trig = have ? any_lane(wa > wa_full) : any_lane(wa != col_addr);
         if (trig) {
+            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
+            if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
             compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
             wa = col_addr + (static_cast<u32>(cnt) << 9);
-            if (STATS) ++st_compact;
+            if (STATS) {
+                ++st_compact;
+                // the clock read must not be scheduled ahead of the merge network: make it depend on tau
+                asm volatile("" ::"v"(tau));
+                tc_compact += __builtin_amdgcn_s_memtime() - tc_mark;
+            }
         }
         if (have) {
             // ---- candidates of one leaf: SMEM broadcast, branch-free accept ----
-            if (STATS) ++st_leaves;
+            if (STATS) {
+                ++st_leaves;
+                tc_mark = __builtin_amdgcn_s_memtime();
+            }
 #if defined(PCPX_LEAF_VMEM)
             const Leaf lf = t.leaves[leaf];  // experiment: vector-memory path (uniform address)
 #else
@@ -678,6 +703,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                     cnt += acc ? 1 : 0;
                     if (STATS) st_app += acc ? 1u : 0u;
                 }
+            }
+            if (STATS) {
+                asm volatile("" ::"v"(wa), "v"(cnt));
+                tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
             }
         } else if (!trig) {
             // drained: seed chunk -> capped tree walk -> (rarely) uncapped walk of the failed lanes -> finished
@@ -727,6 +756,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             atomicAdd(&stats[4], 1ull);
             atomicAdd(&stats[5], static_cast<unsigned long long>(s1 - s0));
             atomicAdd(&stats[6], static_cast<unsigned long long>(st_round2));
+            atomicAdd(&stats[7], tc_walk);
+            atomicAdd(&stats[8], tc_compact);
+            atomicAdd(&stats[9], tc_leaf);
+            atomicAdd(&stats[10], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tc0);  // search loop
         }
     }
 
@@ -868,10 +901,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : PCPX
             if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (qbeg + gi >= qend) break;
-            unsigned long long tg = 0;
-            if (STATS) tg = __builtin_amdgcn_s_memrealtime();
+            unsigned long long tg = 0, tcg = 0;
+            if (STATS) {
+                tg = __builtin_amdgcn_s_memrealtime();
+                tcg = __builtin_amdgcn_s_memtime();
+            }
             knn_group<KCAP, SELF, STATS, MULTI>(t, qv, group_first + qbeg + gi, k, eps, o, mp, stats, col, lane);
             if (STATS) {
+                if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
                 ++n_done;
                 tg = __builtin_amdgcn_s_memrealtime() - tg;
                 if (tg > t_max) {

@@ -236,7 +236,8 @@ class Index:
         cap = 16 + 5 * 65536
         out = (C.c_uint64 * cap)()
         check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out, cap))
-        names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves", "second_round_groups"]
+        names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves", "second_round_groups",
+                 "cycles_walk", "cycles_compact", "cycles_leaf", "cycles_search_loop", "cycles_group"]
         d = {n: int(out[i]) for i, n in enumerate(names)}
         if want_waves:
             w = np.frombuffer(out, dtype=np.uint64)[16:].reshape(-1, 5)

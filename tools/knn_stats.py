@@ -10,5 +10,10 @@ pts = pkg.synthetic.uniform_cloud(n, 43) if kind == "uniform" else pkg.synthetic
 ix = pkg.Index(pts)
 st = ix.debug_knn_stats(k)
 w = st["waves"]
-print(json.dumps({"n": n, "kind": kind, "k": k, **st, "per_wave": {a: round(st[a] / w, 2) for a in st if a != "waves"},
-                  "appended_per_query": round(st["appended"] / n, 2)}))
+tot = max(1, st["cycles_group"])
+phases = {a[7:]: round(st[a] / tot, 4) for a in st if a.startswith("cycles_") and a != "cycles_group"}
+phases["epilogue"] = round(1.0 - st["cycles_search_loop"] / tot, 4)
+phases["seed_cap_control"] = round((st["cycles_search_loop"] - st["cycles_walk"] - st["cycles_compact"] - st["cycles_leaf"]) / tot, 4)
+print(json.dumps({"n": n, "kind": kind, "k": k, **st, "per_group": {a: round(st[a] / w, 2) for a in st if a != "waves"},
+                  "appended_per_query": round(st["appended"] / n, 2),
+                  "share_of_group_cycles (diagnostic build, wave-resident time incl. waiting for the other waves)": phases}))

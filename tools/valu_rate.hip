@@ -116,6 +116,115 @@ __global__ __launch_bounds__(64) void k_ds_write2(float* out, float seed)
     out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x];
 }
 
+// ds_write2_b32 with EXEC narrowed to `lanes` lanes (0, 1 or 4): what does a mostly rejected candidate cost?
+template <int LANES>
+__global__ __launch_bounds__(64) void k_ds_write2_masked(float* out, float seed)
+{
+    __shared__ float buf[64 * 16];
+    float a0 = seed + threadIdx.x;
+    unsigned addr = threadIdx.x * 4;
+    const unsigned long long mask = LANES == 0 ? 0ull : (LANES == 1 ? 1ull : 0x1111ull);
+    unsigned long long saved;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\t" REP8(
+                         "ds_write2_b32 %1, %2, %2 offset1:64\nds_write2_b32 %1, %2, %2 offset0:128 offset1:192\n") "s_mov_b64 exec, %0"
+                     : "=&s"(saved)
+                     : "v"(addr), "v"(a0), "s"(mask)
+                     : "memory");
+    }
+    __syncthreads();
+    out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x];
+}
+
+// the accept sequence of k_knn: 2 x v_cmpx, ds_write2 under the narrowed EXEC, address bump, EXEC restore, pos bump
+// (tau = -1: every lane rejects, the common case); 8 per iteration like one leaf
+__global__ __launch_bounds__(64) void k_accept_seq(float* out, float seed)
+{
+    __shared__ float buf[64 * 16];
+    float d2 = seed + threadIdx.x, tau = -1.f, m = 1.f;
+    unsigned wa = threadIdx.x * 4, pos = 0;
+    unsigned long long saved;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t" REP8("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                                                     "v_cmpx_le_f32_e32 %[eps], %[m]\n\t"
+                                                     "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                                                     "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                                                     "s_mov_b64 exec, %[sv]\n\t"
+                                                     "v_add_u32_e32 %[pos], 1, %[pos]\n\t")
+                     : [wa] "+v"(wa), [pos] "+v"(pos), [sv] "=&s"(saved)
+                     : [d2] "v"(d2), [tau] "v"(tau), [m] "v"(m), [eps] "s"(seed)
+                     : "vcc", "memory");
+    }
+    __syncthreads();
+    out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x] + wa + pos;
+}
+// the same without the LDS write (what do the EXEC round trips cost by themselves?)
+__global__ __launch_bounds__(64) void k_accept_seq_nolds(float* out, float seed)
+{
+    float d2 = seed + threadIdx.x, tau = -1.f, m = 1.f;
+    unsigned wa = threadIdx.x * 4, pos = 0;
+    unsigned long long saved;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t" REP8("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                                                     "v_cmpx_le_f32_e32 %[eps], %[m]\n\t"
+                                                     "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                                                     "s_mov_b64 exec, %[sv]\n\t"
+                                                     "v_add_u32_e32 %[pos], 1, %[pos]\n\t")
+                     : [wa] "+v"(wa), [pos] "+v"(pos), [sv] "=&s"(saved)
+                     : [d2] "v"(d2), [tau] "v"(tau), [m] "v"(m), [eps] "s"(seed)
+                     : "vcc");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = wa + pos;
+}
+// one candidate of a leaf as k_knn issues it: 8 distance ops + max3 + the accept sequence (13 VALU + 1 LDS + 1 SALU)
+__global__ __launch_bounds__(64) void k_candidate(float* out, float seed)
+{
+    __shared__ float buf[64 * 16];
+    float qx = seed + threadIdx.x, qy = qx * 0.5f, qz = qx * 0.25f, tau = -1.f;
+    unsigned wa = threadIdx.x * 4, pos = 0;
+    unsigned long long saved;
+    float dx, dy, dz, d2, t, m;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t" REP8("v_sub_f32_e32 %[dx], %[px], %[qx]\n\t"
+                                                     "v_sub_f32_e32 %[dy], %[px], %[qy]\n\t"
+                                                     "v_sub_f32_e32 %[dz], %[px], %[qz]\n\t"
+                                                     "v_mul_f32_e32 %[d2], %[dx], %[dx]\n\t"
+                                                     "v_mul_f32_e32 %[t], %[dy], %[dy]\n\t"
+                                                     "v_add_f32_e32 %[d2], %[d2], %[t]\n\t"
+                                                     "v_mul_f32_e32 %[t], %[dz], %[dz]\n\t"
+                                                     "v_add_f32_e32 %[d2], %[d2], %[t]\n\t"
+                                                     "v_max3_f32 %[m], |%[dx]|, |%[dy]|, |%[dz]|\n\t"
+                                                     "v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                                                     "v_cmpx_le_f32_e32 %[px], %[m]\n\t"
+                                                     "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                                                     "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                                                     "s_mov_b64 exec, %[sv]\n\t"
+                                                     "v_add_u32_e32 %[pos], 1, %[pos]\n\t")
+                     : [wa] "+v"(wa), [pos] "+v"(pos), [sv] "=&s"(saved), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz),
+                       [d2] "=&v"(d2), [t] "=&v"(t), [m] "=&v"(m)
+                     : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [tau] "v"(tau), [px] "s"(seed)
+                     : "vcc", "memory");
+    }
+    __syncthreads();
+    out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x] + wa + pos;
+}
+
+#define LDS_KERNEL(name, body, clob)                                                  \
+    __global__ __launch_bounds__(64) void name(float* out, float seed)                 \
+    {                                                                                 \
+        __shared__ float buf[64 * 16];                                                \
+        double a0 = seed + threadIdx.x;                                               \
+        unsigned addr = threadIdx.x * 8;                                              \
+        for (int i = 0; i < ITER; ++i) {                                              \
+            asm volatile(REP8(body) : "+v"(a0) : "v"(addr) : "memory");               \
+        }                                                                             \
+        __syncthreads();                                                              \
+        out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x] + static_cast<float>(a0); \
+    }
+LDS_KERNEL(k_ds_write_b64, "ds_write_b64 %1, %0\nds_write_b64 %1, %0 offset:512\n", 0)
+LDS_KERNEL(k_ds_write_b32, "ds_write_b32 %1, %1\nds_write_b32 %1, %1 offset:512\n", 0)
+LDS_KERNEL(k_ds_read_b64, "ds_read_b64 %0, %1\ns_waitcnt lgkmcnt(0)\nds_read_b64 %0, %1 offset:512\ns_waitcnt lgkmcnt(0)\n", 0)
+
 struct Case {
     const char* name;
     void (*fn)(float*, float);
@@ -130,7 +239,7 @@ int main()
     const double mhz = prop.clockRate / 1e3;  // kHz -> MHz
     std::printf("device %s: %d CUs, clock %.0f MHz\n", prop.name, cus, mhz);
     float* out;
-    CHECK(hipMalloc(&out, sizeof(float) * 64 * cus * 4 * 8));
+    CHECK(hipMalloc(&out, sizeof(float) * 64 * cus * 4 * 8 * 2));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -142,12 +251,21 @@ int main()
         {"v_add_f64", k_add_f64, 32},       {"v_cmp_lt_u64", k_cmp_u64, 32},    {"v_mov_b64", k_mov_b64, 32},
         {"v_pk_mov_b32", k_pk_mov_b32, 32}, {"s_add_u32", k_salu, 32},          {"v_mul+s_add 1:1", k_valu_salu, 32},
         {"ds_write2_b32", k_ds_write2, 16},
+        {"ds_write2 exec=4", k_ds_write2_masked<4>, 16},
+        {"ds_write2 exec=1", k_ds_write2_masked<1>, 16},
+        {"ds_write2 exec=0", k_ds_write2_masked<0>, 16},
+        {"ds_write_b64", k_ds_write_b64, 16},
+        {"ds_write_b32", k_ds_write_b32, 16},
+        {"ds_read_b64+wait", k_ds_read_b64, 16},
+        {"accept seq (x1)", k_accept_seq, 8},
+        {"accept seq no LDS", k_accept_seq_nolds, 8},
+        {"candidate (x1)", k_candidate, 8},
     };
-    std::printf("%-18s %10s %10s %10s   (cycles per wave-instruction per SIMD at 1, 2, 4 waves/SIMD)\n", "instruction", "w=1", "w=2",
-                "w=4");
+    std::printf("%-18s %10s %10s %10s   (cycles per wave-instruction [or per sequence] per SIMD at 1, 2, 4, 5 waves/SIMD)\n", "instruction", "w=1", "w=2",
+                "w=4 (w=5)");
     for (const Case& c : cases) {
         std::printf("%-18s", c.name);
-        for (int w : {1, 2, 4}) {
+        for (int w : {1, 2, 4, 5}) {
             const int grid = cus * 4 * w;
             c.fn<<<grid, 64>>>(out, 1.0f);  // warm-up
             CHECK(hipEventRecord(e0));
