@@ -571,19 +571,16 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     const u32 nq = SELF ? t.n : qv.nq;
     const bool valid = p < nq;
     float qx = 0.f, qy = 0.f, qz = 0.f;
-    u32 row = 0;
     if (valid) {
         if (SELF) {
             const Leaf& lf = t.leaves[p / LEAF];
             qx = lf.x[p % LEAF];
             qy = lf.y[p % LEAF];
             qz = lf.z[p % LEAF];
-            row = lf.id[p % LEAF];
         } else {
             qx = qv.qx[p];
             qy = qv.qy[p];
             qz = qv.qz[p];
-            row = qv.row[p];
         }
     }
     u64 lo_key = 0;
@@ -793,6 +790,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     if (any_lane(unordered)) bitonic_sort_payload<KCAP>(best, pos);  // exact-tie repair, rare
 
     if (!valid) return;
+    // output row = original index of the query (read here, not at the start: one VGPR less through the search loop)
+    const u32 row = SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
     u32 found = 0;
     u32 okmask = 0;
     const u64 ob = static_cast<u64>(row) * k;
