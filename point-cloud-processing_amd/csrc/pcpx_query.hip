@@ -31,6 +31,7 @@
 
 #include <cmath>
 #include <limits>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -170,6 +171,31 @@ __host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 16 ? PCPX_
 // in a walk, when a leaf adds one or two keys per lane: 24 compare-exchanges instead of 80) -- then
 // best[KCAP-1-j] = min(best[KCAP-1-j], new[j]) leaves the KCAP smallest of both as a bitonic sequence,
 // which one merge network sorts.  At most 16 new keys are live beside best[]: KCAP 32 fits 128 VGPRs.
+// key if j < cnt, else PAD_KEY -- by bit arithmetic: a v_cndmask_b32 whose mask is VCC (the form hipcc picks for
+// `j < cnt ? key : PAD_KEY`) issues in 23 cycles on gfx950 against 4 for the SGPR-mask form and 2.4-4.3 for
+// v_or_b32 / v_bfi_b32 (measured: tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt)
+// (hand-written: from the C++ bit arithmetic hipcc re-derives the compare + select.)
+template <int J>
+__device__ __forceinline__ u64 pad_from(u64 key, int cnt)
+{
+    u32 lo = static_cast<u32>(key), hi = static_cast<u32>(key >> 32), stale;
+    asm("v_subrev_u32_e32 %[m], %[j1], %[cnt]\n\t"  // cnt - (J + 1) < 0 iff J >= cnt
+        "v_ashrrev_i32_e32 %[m], 31, %[m]\n\t"    // all ones iff stale
+        "v_or_b32_e32 %[lo], %[lo], %[m]\n\t"
+        "v_bfi_b32 %[hi], %[m], %[padhi], %[hi]"    // stale ? padhi : hi
+        : [lo] "+v"(lo), [hi] "+v"(hi), [m] "=&v"(stale)
+        : [cnt] "v"(cnt), [j1] "n"(J + 1), [padhi] "s"(static_cast<u32>(PAD_KEY >> 32)));
+    return (static_cast<u64>(hi) << 32) | lo;
+}
+template <int J0, int J1, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (J0 < J1) {
+        f(std::integral_constant<int, J0>{});
+        static_for<J0 + 1, J1>(f);
+    }
+}
+
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
@@ -177,8 +203,7 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
     u64 nw[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
+    static_for<0, 8>([&](auto J) { nw[J] = pad_from<J>(nw[J], cnt); });
     if (!any_lane(cnt > 8)) {
         u64 lo8[8];
 #pragma unroll
@@ -191,8 +216,7 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
     } else {
 #pragma unroll
         for (int j = 8; j < 16; ++j) nw[j] = j < BUF ? col[j * 64] : PAD_KEY;
-#pragma unroll
-        for (int j = 8; j < BUF; ++j) nw[j] = j < cnt ? nw[j] : PAD_KEY;
+        static_for<8, BUF>([&](auto J) { nw[J] = pad_from<J>(nw[J], cnt); });
         bitonic_sort<16>(nw);
     }
     cnt = 0;

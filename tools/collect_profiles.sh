@@ -1,0 +1,31 @@
+#!/bin/bash
+# Collects every measurement DESIGN.md quotes, on the GPU box, into gpurun_out/<tag>/ :
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01'
+# then, back in the container:  python3 tools/collect_profiles.py r01   (copies the summaries into profiles/)
+set -u
+tag=${1:-r01}
+out=gpurun_out/$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# 1. the bench line (default workload, CPU baseline included)
+timeout -k 10 400 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
+echo "bench done"
+# 2. the same command under rocprofv3 --kernel-trace --stats
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprofv3.json" 2> "$out/trace.err" || { echo "trace failed"; tail -5 "$out/trace.err"; exit 1; }
+echo "trace done"
+# 3. PMC passes (separate runs per counter group, --kernel-trace only)
+bash tools/pmc_passes.sh "$out/pmc" --steps 3 --warmup 1 > "$out/pmc.txt" 2>&1 || { echo "pmc failed"; tail -5 "$out/pmc.txt"; exit 1; }
+echo "pmc done"
+# 4. traversal statistics + per-phase clocks (diagnostic build of the kernel)
+timeout -k 10 200 python3 tools/knn_stats.py 1e7 uniform 15 > "$out/stats_uniform.json" 2>> "$out/stats.err" &&
+timeout -k 10 200 python3 tools/knn_stats.py 1e7 clustered 15 > "$out/stats_clustered.json" 2>> "$out/stats.err" || { echo "stats failed"; exit 1; }
+echo "stats done"
+# 5. other workloads: configs[3]'s cloud on one GPU, configs[4] streaming
+timeout -k 10 300 python3 bench.py --workload clustered_10m_k15 --no-cpu-baseline --no-extra > "$out/bench_clustered_10m_k15.json" 2>> "$out/bench.err" &&
+timeout -k 10 500 python3 bench.py --workload uniform_50m_k32_stream --no-cpu-baseline --no-extra --steps 5 > "$out/bench_c5_50m_k32_stream.json" 2>> "$out/bench.err" || { echo "workloads failed"; exit 1; }
+echo "workloads done"
+# 6. PCIe-inclusive host-pointer ABI timings
+timeout -k 10 300 python3 tools/pcie_inclusive.py > "$out/pcie_inclusive.json" 2>> "$out/bench.err" || { echo "pcie failed"; exit 1; }
+# 7. instruction issue costs
+hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && timeout -k 10 120 /tmp/valu_rate > "$out/valu_issue_rates.txt" 2>&1
+echo "all done"

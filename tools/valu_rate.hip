@@ -59,6 +59,53 @@ KERNEL32(k_add_f32, EACH8("v_add_f32", "%8"))
 KERNEL32(k_max3_f32, EACH8("v_max3_f32", "%8, %9"))
 KERNEL32(k_med3_f32, EACH8("v_med3_f32", "%8, %9"))
 KERNEL32(k_cndmask, EACH8("v_cndmask_b32", "%8, vcc"))
+// v_cndmask variants: mask in an SGPR pair (VOP3), mask in VCC written once outside the loop, destinations
+// different from the sources
+__global__ __launch_bounds__(64) void k_cndmask_sgpr(float* out, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = seed * 0.5f;
+    unsigned long long mask = 0x5555555555555555ull;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile(REP8("v_cndmask_b32_e64 %0, %0, %4, %5\nv_cndmask_b32_e64 %1, %1, %4, %5\n"
+                          "v_cndmask_b32_e64 %2, %2, %4, %5\nv_cndmask_b32_e64 %3, %3, %4, %5\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     : "v"(b), "s"(mask));
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+__global__ __launch_bounds__(64) void k_cndmask_vcc_set(float* out, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = seed * 0.5f;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b64 vcc, 0x55555555\n" REP8("v_cndmask_b32_e32 %0, %0, %4, vcc\nv_cndmask_b32_e32 %1, %1, %4, vcc\n"
+                                                        "v_cndmask_b32_e32 %2, %2, %4, vcc\nv_cndmask_b32_e32 %3, %3, %4, vcc\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     : "v"(b)
+                     : "vcc");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+__global__ __launch_bounds__(64) void k_cndmask_fresh_dst(float* out, float seed)
+{
+    float a0, a1, a2, a3, b = seed * 0.5f, c = seed + threadIdx.x;
+    unsigned long long mask = 0x5555555555555555ull;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile(REP8("v_cndmask_b32_e64 %0, %4, %5, %6\nv_cndmask_b32_e64 %1, %4, %5, %6\n"
+                          "v_cndmask_b32_e64 %2, %4, %5, %6\nv_cndmask_b32_e64 %3, %4, %5, %6\n")
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                     : "v"(b), "v"(c), "s"(mask));
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+// bit-arithmetic alternative to "x = cond ? x : PAD": v_bfi_b32 and v_or_b32
+KERNEL32(k_bfi, EACH8("v_bfi_b32", "%8, %9"))
+KERNEL32(k_or, EACH8("v_or_b32", "%8"))
+KERNEL32(k_ashr, EACH8("v_ashrrev_i32", "%8"))
+KERNEL32(k_min_u32, EACH8("v_min_u32", "%8"))
+KERNEL32(k_min3_u32, EACH8("v_min3_u32", "%8, %9"))
+KERNEL32(k_add_u32, EACH8("v_add_u32", "%8"))
+KERNEL32(k_lshl_add, EACH8("v_lshl_add_u32", "%8, %9"))
+
 KERNEL32(k_cmp_f32, REP8("v_cmp_le_f32 vcc, %0, %8\n"))
 KERNEL32(k_mov_b32, "v_mov_b32 %0, %8\nv_mov_b32 %1, %8\nv_mov_b32 %2, %8\nv_mov_b32 %3, %8\nv_mov_b32 %4, %8\nv_mov_b32 %5, "
                     "%8\nv_mov_b32 %6, %8\nv_mov_b32 %7, %8\n")
@@ -246,6 +293,11 @@ int main()
     const Case cases[] = {
         {"v_mul_f32", k_mul_f32, 32},       {"v_add_f32", k_add_f32, 32},       {"v_max3_f32", k_max3_f32, 32},
         {"v_med3_f32", k_med3_f32, 32},     {"v_cndmask_b32", k_cndmask, 32},   {"v_cmp_le_f32", k_cmp_f32, 32},
+        {"v_cndmask e64 sgpr", k_cndmask_sgpr, 32}, {"v_cndmask vcc set", k_cndmask_vcc_set, 32},
+        {"v_cndmask fresh dst", k_cndmask_fresh_dst, 32},
+        {"v_bfi_b32", k_bfi, 32}, {"v_or_b32", k_or, 32}, {"v_ashrrev_i32", k_ashr, 32}, {"v_min_u32", k_min_u32, 32},
+        {"v_min3_u32", k_min3_u32, 32}, {"v_add_u32", k_add_u32, 32}, {"v_lshl_add_u32", k_lshl_add, 32},
+
         {"v_mov_b32", k_mov_b32, 32},       {"v_pk_mul_f32", k_pk_mul_f32, 32}, {"v_pk_add_f32", k_pk_add_f32, 32},
         {"v_pk_fma_f32", k_pk_fma_f32, 32}, {"v_min_f64", k_min_f64, 32},       {"v_max_f64", k_max_f64, 32},
         {"v_add_f64", k_add_f64, 32},       {"v_cmp_lt_u64", k_cmp_u64, 32},    {"v_mov_b64", k_mov_b64, 32},
