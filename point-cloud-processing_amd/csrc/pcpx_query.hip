@@ -259,6 +259,23 @@ __device__ __forceinline__ void append_if(float d2, float tau, float dx, float d
                  : "vcc", "memory");
 }
 
+// The same for the later walk rounds: additionally lo < d2 (only the new shell (lo, tau] is accepted).
+__device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, float dx, float dy, float dz, float eps, u32& pos,
+                                                u32& wa, u64 saved)
+{
+    float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                 "v_cmpx_lt_f32_e32 %[lo], %[d2]\n\t"
+                 "v_cmpx_le_f32_e32 %[eps], %[m]\n\t"
+                 "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                 "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_u32_e32 %[pos], 1, %[pos]"
+                 : [wa] "+v"(wa), [pos] "+v"(pos)
+                 : [d2] "v"(d2), [tau] "v"(tau), [lo] "s"(lo), [m] "v"(m), [eps] "s"(eps), [sv] "s"(saved)
+                 : "vcc", "memory");
+}
+
 // Index records (leaves, node boxes) are immutable while a query kernel runs.  Reading them through
 // constant-address-space pointers makes every wave-uniform read a scalar (SMEM) load unconditionally;
 // through generic pointers hipcc only does that while it can prove no store (or asm with a memory
@@ -669,7 +686,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         }
         // compaction: buffer nearly full (a leaf may add LEAF keys), or draining at a phase end.  The fast accept
         // path keeps only the write address `wa`, the other paths only `cnt`.
-        const bool fast = PCPX_ASM_ACCEPT && !MULTI && !second_round;
+        constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;
         if (!fast) wa = col_addr + (static_cast<u32>(cnt) << 9);
         bool trig = have ? any_lane(wa > wa_full) : any_lane(wa != col_addr);
         if (trig) {
@@ -698,8 +715,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             const Leaf lf = load_const(t.leaves + leaf);
 #endif
             const u32 posbase = leaf * LEAF;
-            // two copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
-            if (PCPX_ASM_ACCEPT && !MULTI && !second_round) {
+            // copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
+            if (fast && !second_round) {
                 u32 posv = posbase;
                 const u64 saved = save_exec();
 #pragma unroll
@@ -708,6 +725,16 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                     float d2 = sq3(dx, dy, dz);
                     if (STATS) st_app += (d2 <= tau && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
                     append_if(d2, tau, dx, dy, dz, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
+                }
+            } else if (fast) {  // later rounds: only the shell (lo_d2, tau]
+                u32 posv = posbase;
+                const u64 saved = save_exec();
+#pragma unroll
+                for (int j = 0; j < LEAF; ++j) {
+                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                    float d2 = sq3(dx, dy, dz);
+                    if (STATS) st_app += (d2 <= tau && d2 > lo_d2 && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
+                    append_if_shell(d2, tau, lo_d2, dx, dy, dz, eps, posv, wa, saved);
                 }
             } else {
 #pragma unroll
@@ -754,6 +781,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                     active = failed;
                     tau = active ? fminf(kth, cap) : -1.f;
                     cnt = 0;
+                    wa = col_addr;
                     bool root_leaf = wk.start(t, need, st_expand);
                     (void)root_leaf;
                 } else {
