@@ -2,19 +2,22 @@
 //
 // Execution model (DESIGN.md "Kernels"):
 //   * ONE WAVEFRONT = 64 Morton-consecutive queries, one query per lane.
-//   * Tree traversal is WAVE-UNIFORM: node ids, the pending-children bit stack and all control flow
-//     live in SGPRs; the 4 child boxes of a node (one 128-B record) and whole leaf records (128 B) are
-//     fetched with scalar (SMEM) loads and broadcast to the 64 lanes as SGPR operands of the per-lane
-//     VALU distance code.  A subtree is entered when ANY lane still needs it (ballot), so the wave
-//     walks the union of its lanes' search regions -- small, because the lanes are neighbours on the
+//   * Tree traversal is WAVE-UNIFORM: the pending-children bit stack (popped with one find-first-set) and
+//     all control flow live in SGPRs; the 4 child boxes of a node (one 128-B record) and whole leaf records
+//     (128 B) are fetched with scalar (SMEM) loads and broadcast to the 64 lanes as SGPR operands of the
+//     per-lane VALU distance code.  A subtree is entered when ANY lane still needs it (ballot), so the
+//     wave walks the union of its lanes' search regions -- small, because the lanes are neighbours on the
 //     Morton curve.
 //   * kNN selection: per lane a SORTED best-list of KCAP 64-bit keys (d2 bits << 32 | sorted position)
 //     in VGPRs plus an UNSORTED append buffer in LDS (one column per lane, conflict free).  Accepting a
-//     candidate is branch-free: the key is always stored, to the lane's next free slot if d2 <= tau
-//     and the point is outside the eps-box, else to a trash row.  When a column is nearly full the wave
-//     sorts the new keys in registers (bitonic network whose compare-exchange is v_min_f64 / v_max_f64:
-//     every key is the bit pattern of a finite non-negative double) and merges them with the best-list,
-//     which tightens tau = d2 of the k-th best.
+//     candidate is hand-written: two v_cmpx narrow EXEC to the lanes with d2 <= tau outside the eps-box,
+//     the LDS write and the address bump run under it.  When a column is nearly full the wave sorts the
+//     new keys in registers (bitonic network whose compare-exchange is v_min_f64 / v_max_f64: every key
+//     is the bit pattern of a finite non-negative double) and merges them with the best-list, which
+//     tightens tau = d2 of the k-th best.
+//   * Walk rounds: the first walk searches no farther than 1.25 x the wave's median seeded tau; a lane
+//     whose k-th distance ends up beyond that cap goes round again with a 4x larger one (shell accept).
+//   * Persistent waves pull query groups from 8 work queues (one per XCD-sized eighth of the Morton order).
 //   * The search is seeded with the 64 points of the query group itself (for arbitrary queries: the
 //     64-point chunk at the group's Morton position), so tau is tight before the traversal starts.
 //   * Keys carry the SORTED position, so neighbour ids and coordinates are gathered from the leaf
@@ -319,11 +322,7 @@ struct Walker {
     __device__ __forceinline__ u32 child_mask(const TreeView& t, int d, u32 loc, Need&& need)
     {
         const u32 first_child = level_base(d + 1) + (loc << LOGW);  // heap id of child 0
-#if defined(PCPX_NODE_VMEM)
-        const NodeBox4 cb = *reinterpret_cast<const NodeBox4*>(t.nodes + first_child);
-#else
         const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
-#endif
         u32 m = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
@@ -709,11 +708,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 ++st_leaves;
                 tc_mark = __builtin_amdgcn_s_memtime();
             }
-#if defined(PCPX_LEAF_VMEM)
-            const Leaf lf = t.leaves[leaf];  // experiment: vector-memory path (uniform address)
-#else
-            const Leaf lf = load_const(t.leaves + leaf);
-#endif
+            const Leaf lf = load_const(t.leaves + leaf);  // (a vector-memory fetch of the record measured the same)
             const u32 posbase = leaf * LEAF;
             // copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
             if (fast && !second_round) {
