@@ -6,8 +6,8 @@
 
 Workload (config.workload): the north-star target configuration of BASELINE.json -- a 10 M-point
 uniform synthetic cloud, k = 15, every point queries the cloud (kNN) and gets its PCA normal.  The
-1 M-point configs[1] figure is reported beside it under "extra" (DESIGN.md "Measurement" says why 10 M
-is the headline: it is the cloud the target is quoted on and 1 M does not fill 256 CUs).
+1 M-point configs[1] figure is reported under "extra" with --with-1m (DESIGN.md "Measurement" says why
+10 M is the headline: it is the cloud the target is quoted on and 1 M is 3 query groups per resident wave).
 
 One STEP = one pass of the query hot path over the whole cloud with the index resident in HBM: one
 k_knn launch (k nearest neighbours of every point, rows written to HBM, with the 3x3 scatter matrix +
@@ -203,7 +203,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="uniform_10m_k15", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] 1 M-point side measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (rebuild, range count)")
+    ap.add_argument("--with-1m", action="store_true",
+                    help="also time configs[1] (1 M points, k=15) and report it under extra; off by default so that the "
+                         "default command launches k_knn on the headline workload only (its rocprofv3 average then "
+                         "equals roofline.avg_launch_ms)")
     args = ap.parse_args()
 
     import torch  # before libpcpx so that both share one HIP runtime
@@ -248,14 +252,17 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_query": bytes_per_q, "queries_per_launch": q_per_launch,
-                    "note": "fused kNN+normals kernel; it is instruction-issue (VALU+SALU) bound, not HBM bound: see "
-                            "DESIGN.md 'Roofline'; traffic = PMC HBM bytes per launch (profiles/r01_hbm_traffic.json)"}
+                    "note": "fused kNN+normals kernel; it is VALU-issue bound, not HBM bound (DESIGN.md 'Roofline'); traffic = "
+                            "PMC HBM bytes per launch of an earlier profiled run (profiles/r01_hbm_traffic.json)"}
         traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
                 if tr.get("workload") == args.workload and world == 1:
                     roofline["traffic"] = tr.get("k_knn_hbm_bytes_per_launch")
+                    # report the measured HBM rate beside the algorithmic one
+                    roofline["hbm_measured_GBps"] = round(roofline["traffic"] / avg_s / 1e9, 1)
+                    roofline["hbm_measured_frac"] = round(roofline["traffic"] / avg_s / HBM_PEAK, 5)
             except Exception:
                 pass
         nl, nms = prof["normals"]
@@ -264,7 +271,7 @@ def main():
         extra["k_knn_avg_launch_ms"] = round(avg_s * 1e3, 4)
         extra["knn_only_mqps"] = round(q_per_launch * world / avg_s / 1e6, 3)
 
-    if rank == 0 and world == 1 and not args.no_extra and args.workload != "uniform_1m_k15":
+    if rank == 0 and world == 1 and args.with_1m and args.workload != "uniform_1m_k15":
         side = run_workload(pkg, torch, dist, "uniform_1m_k15", 0, 1, max(args.steps, 10), args.warmup, want_profile=False)
         extra["configs1_uniform_1m_k15_mqps"] = round(side["mqps"], 3)
         extra["configs1_uniform_1m_k15_ms_per_step"] = round(side["ms_per_step"], 4)

@@ -24,7 +24,7 @@ if stats:
     shutil.copyfile(stats[0], os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), stats[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rocprofv3_kernel_stats.txt"), "w").write(
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (MI355X, tools/collect_profiles.sh)\n" + txt)
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py   (MI355X, tools/collect_profiles.sh)\n" + txt)
 pmc = os.path.join(src, "pmc", "pmc_summary.json")
 if os.path.exists(pmc):
     shutil.copyfile(pmc, os.path.join(dst, tag + "_pmc_summary.json"))
