@@ -331,7 +331,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.d_codes[0], ix.d_vals[0]);
         PCPX_HIP(hipGetLastError());
         size_t tb = ix.sort_tmp_bytes;
-        int st = sort_pairs_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], n, s);
+        int st = sort_pairs_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], n, s, MORTON_SORT_FIRST_BIT);
         if (st != PCPX_OK) return st;
         k_count_valid<<<1, 64, 0, s>>>(ix.d_codes[1], static_cast<u32>(n), ix.d_scalars + 6);
     } else {

@@ -1190,11 +1190,11 @@ __global__ __launch_bounds__(256) void k_query_seeds(const u64* __restrict__ qco
     if (g >= ngroups) return;
     u32 mid = g * GROUP + GROUP / 2;
     if (mid >= nq) mid = nq - 1;
-    u64 c = qcodes[mid];
+    u64 c = qcodes[mid] >> MORTON_SORT_FIRST_BIT;  // the codes are ordered by these bits only
     u32 lo = 0, hi = n;  // lower_bound over the sorted point codes
     while (lo < hi) {
         u32 m = lo + ((hi - lo) >> 1);
-        if (pcodes[m] < c) lo = m + 1;
+        if ((pcodes[m] >> MORTON_SORT_FIRST_BIT) < c) lo = m + 1;
         else hi = m;
     }
     u32 chunk = lo / GROUP;
@@ -1266,7 +1266,7 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
     if (nq > 0) {
         const float* d_box = reinterpret_cast<const float*>(ix.d_scalars + 8);
         k_query_codes<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, n32, d_box, codes0, vals0);
-        if ((st = sort_pairs_u64(base + o_tmp, tb, codes0, codes1, vals0, vals1, nq, s)) != PCPX_OK) return st;
+        if ((st = sort_pairs_u64(base + o_tmp, tb, codes0, codes1, vals0, vals1, nq, s, MORTON_SORT_FIRST_BIT)) != PCPX_OK) return st;
         k_query_gather<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, vals1, n32, qx, qy, qz);
         k_query_seeds<<<static_cast<u32>((ngroups + 255) / 256), 256, 0, s>>>(
             codes1, n32, ix.sorted_codes(), static_cast<u32>(ix.n), ix.nleaves, seed, static_cast<u32>(ngroups));

@@ -1,7 +1,7 @@
 // pcpx_sort.hip -- stable LSD radix sort of (u64 key, u32 value) pairs, hand-written for gfx950 (wave64).
 //
 // Used for the Morton order of the index build and of arbitrary query batches (the "radix sort" step of
-// BASELINE.json's north_star).  8 passes of 8-bit digits.  Per pass:
+// BASELINE.json's north_star).  8-bit digits, one pass per digit of the key bits [first_bit, 64).  Per pass:
 //   k_sort_hist     each 256-thread block counts the digits of its tile          -> blockhist[block][256]
 //   k_sort_scan     per digit, exclusive prefix over blocks + base of the digit  -> blockhist in place
 //   k_sort_scatter  each block re-reads its tile, ranks every key among the equal digits before it in the
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_scatter(const u64* __restri
 
 // Temporary storage: blockhist[nblocks][256] + totals[256] + one ping-pong (key, value) buffer pair.
 // Result in (kout, vout).  Call with tmp == nullptr to get tmp_bytes.
-int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n, hipStream_t s)
+int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n, hipStream_t s,
+                   int first_bit)
 {
     const u64 nblocks = (n + SORT_TILE - 1) / SORT_TILE;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -191,13 +192,19 @@ int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, cons
     u32* totals = reinterpret_cast<u32*>(base + o_tot);
     u64* kt = reinterpret_cast<u64*>(base + o_k);
     u32* vt = reinterpret_cast<u32*>(base + o_v);
-    // 8 passes: in -> tmp -> out -> tmp -> ... ends in out after an even number of passes
+    if (first_bit < 0 || first_bit > 56 || (first_bit & 7)) {
+        set_error("pcpx: radix sort first_bit %d", first_bit);
+        return PCPX_ERR_INVALID;
+    }
+    // ping-pong between tmp and out so that the LAST pass writes out
+    const int passes = (64 - first_bit) / 8;
     const u64* ksrc = kin;
     const u32* vsrc = vin;
-    for (int pass = 0; pass < 8; ++pass) {
-        u64* kdst = (pass & 1) ? kout : kt;
-        u32* vdst = (pass & 1) ? vout : vt;
-        const int shift = 8 * pass;
+    for (int pass = 0; pass < passes; ++pass) {
+        const bool to_out = ((passes - 1 - pass) & 1) == 0;
+        u64* kdst = to_out ? kout : kt;
+        u32* vdst = to_out ? vout : vt;
+        const int shift = first_bit + 8 * pass;
         k_sort_hist<<<static_cast<u32>(nblocks), SORT_BLOCK, 0, s>>>(ksrc, n, shift, blockhist);
         k_sort_scan_blocks<<<RADIX, SORT_BLOCK, 0, s>>>(blockhist, static_cast<u32>(nblocks), totals);
         k_sort_scan_digits<<<1, RADIX, 0, s>>>(totals);
