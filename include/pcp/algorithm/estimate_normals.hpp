@@ -8,14 +8,19 @@
 // If the range is the container's own element sequence, pcp::gpu::self_knn_map_t selects the fused
 // kernel (kNN + PCA normal per point, neighbour lists never leave the GPU).
 //
-// propagate_normal_orientations (:187-302) is a sequential BFS over the kNN graph and is not part of
-// the data-parallel hot path.
+// propagate_normal_orientations (:187-302) keeps the reference's signature and result: a breadth-first
+// propagation over the directed kNN graph.  The visit order decides which parent orients a vertex, so the
+// search itself runs on the host like the reference's; what the GPU contributes is the graph -- with a
+// pcp::gpu::knn_map_t / self_knn_map_t all neighbour rows come from ONE batched launch instead of one
+// tree query per vertex.
 #ifndef PCP_ALGORITHM_ESTIMATE_NORMALS_HPP
 #define PCP_ALGORITHM_ESTIMATE_NORMALS_HPP
 
 #include "pcp/algorithm/common.hpp"
 #include "pcp/common/normals/normal.hpp"
 #include "pcp/common/normals/normal_estimation.hpp"
+#include "pcp/common/norm.hpp"
+#include "pcp/common/vector3d_queries.hpp"
 #include "pcp/gpu/device_index.hpp"
 
 #include <algorithm>
@@ -166,6 +171,103 @@ void estimate_normals(ForwardIter1 begin, ForwardIter1 end, ForwardIter2 out_beg
     using value_type = typename std::iterator_traits<ForwardIter1>::value_type;
     detail::estimate_normals_impl<ForwardIter1, PointViewMap, KnnMap, Normal>(
         begin, end, point_map, knn_map, [&](value_type const& v, Normal const& n) { *out_begin++ = op(v, n); });
+}
+
+// Orients the normals of [begin, end) consistently (include/pcp/algorithm/estimate_normals.hpp:187-302):
+// directed kNN graph (vertex -> its neighbours, in neighbour order; the sequence must be sorted by
+// index_map, ids 0..N-1, as the reference requires: knn_adjacency_list.hpp:100-103), root = first element of
+// largest z whose normal becomes (0,0,1), then a breadth-first search (graph/search.hpp:36-85) in which a
+// vertex reached for the first time gets its normal flipped -- op(v, -normal_map(v)) -- iff its inner
+// product with the (already oriented) normal of the vertex it was reached from is negative and not within
+// 1e-5 of zero.
+template <class ForwardIter1, class IndexMap, class KnnMap, class PointViewMap, class NormalMap, class TransformOp>
+void propagate_normal_orientations(ForwardIter1 begin, ForwardIter1 end, IndexMap const& index_map, KnnMap&& knn_map,
+                                   PointViewMap&& point_map, NormalMap& normal_map, TransformOp&& op)
+{
+    using element_type = typename std::iterator_traits<ForwardIter1>::value_type;
+    using normal_type  = std::remove_cv_t<std::remove_reference_t<std::invoke_result_t<NormalMap, element_type>>>;
+    using scalar_type  = typename normal_type::component_type;
+    using knn_type     = std::remove_cv_t<std::remove_reference_t<KnnMap>>;
+    static_assert(std::is_invocable_v<TransformOp, element_type, normal_type>, "op must be callable as op(element, normal)");
+
+    std::vector<element_type> const vertices(begin, end);
+    std::size_t const n = vertices.size();
+    if (n == 0) return;
+
+    // ---- the graph: out-edges of vertex i = ids of its neighbours, CSR ----
+    std::vector<std::size_t> first(n + 1, 0);
+    std::vector<std::size_t> target;
+    if constexpr (gpu::is_self_knn_map<knn_type>::value)
+    {
+        if (n != knn_map.tree->size())
+            throw std::invalid_argument("self_knn_map: the range must be the container's own element sequence");
+        auto const rows = knn_map.tree->index().knn_self(static_cast<std::uint32_t>(knn_map.k), knn_map.eps, n);
+        target.reserve(n * knn_map.k);
+        for (std::size_t i = 0; i < n; ++i)
+        {
+            for (std::uint32_t j = 0; j < rows.count[i]; ++j)
+                target.push_back(static_cast<std::size_t>(index_map(knn_map.tree->element(rows.idx[i * knn_map.k + j]))));
+            first[i + 1] = target.size();
+        }
+    }
+    else if constexpr (gpu::is_knn_map<knn_type>::value)
+    {
+        std::vector<float> q;
+        q.reserve(3 * n);
+        for (auto const& v : vertices)
+        {
+            auto const p = knn_map.query_point(v);
+            q.push_back(static_cast<float>(p.x()));
+            q.push_back(static_cast<float>(p.y()));
+            q.push_back(static_cast<float>(p.z()));
+        }
+        auto const rows = knn_map.tree->index().knn(q.data(), n, static_cast<std::uint32_t>(knn_map.k), knn_map.eps);
+        target.reserve(n * knn_map.k);
+        for (std::size_t i = 0; i < n; ++i)
+        {
+            for (std::uint32_t j = 0; j < rows.count[i]; ++j)
+                target.push_back(static_cast<std::size_t>(index_map(knn_map.tree->element(rows.idx[i * knn_map.k + j]))));
+            first[i + 1] = target.size();
+        }
+    }
+    else
+    {
+        for (std::size_t i = 0; i < n; ++i)
+        {
+            auto const neighbours = knn_map(vertices[i]);
+            for (auto const& nb : neighbours) target.push_back(static_cast<std::size_t>(index_map(nb)));
+            first[i + 1] = target.size();
+        }
+    }
+
+    // ---- root: the first element of largest z ----
+    std::size_t root = 0;
+    for (std::size_t i = 1; i < n; ++i)
+        if (point_map(vertices[root]).z() < point_map(vertices[i]).z()) root = i;
+    op(vertices[root], normal_type{static_cast<scalar_type>(0.0), static_cast<scalar_type>(0.0), static_cast<scalar_type>(1.0)});
+
+    // ---- breadth-first propagation ----
+    std::vector<bool> visited(n, false);
+    std::vector<std::size_t> order;
+    order.reserve(n + 1);
+    order.push_back(root);
+    scalar_type const zero = static_cast<scalar_type>(0.0);
+    for (std::size_t head = 0; head < order.size(); ++head)
+    {
+        std::size_t const u = order[head];
+        for (std::size_t e = first[u]; e < first[u + 1]; ++e)
+        {
+            std::size_t const v = target[e];
+            if (visited[v]) continue;
+            auto const n1   = normal_map(vertices[u]);
+            auto const n2   = normal_map(vertices[v]);
+            auto const prod = common::inner_product(n1, n2);
+            if (prod < zero && !common::floating_point_equals(prod, zero)) op(vertices[v], -n2);
+            visited[v] = true;
+            order.push_back(v);
+        }
+        visited[u] = true;
+    }
 }
 
 } // namespace algorithm

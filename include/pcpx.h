@@ -148,6 +148,19 @@ int pcpx_mean_knn_distance_self(pcpx_index* idx, uint32_t k, float eps, float* o
 int pcpx_neighbourhoods_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
                                  float* d_opt_normals, float* d_opt_centroids, float* d_opt_mean_dist);
 
+/* ---- normal orientation (the step right after the normal loop) ------------------------------------ */
+/* propagate_normal_orientations (include/pcp/algorithm/estimate_normals.hpp:187-302) over the kNN graph the
+ * query kernels produce: vertex i -> knn_idx[i*k .. i*k+count[i]) in row order (opt_knn_count NULL = k each).
+ * As in the reference the root is the first point of largest z, its normal becomes (0,0,1), and a
+ * breadth-first search (include/pcp/graph/search.hpp:36-85) flips the normal of every newly reached vertex v
+ * iff dot(n(v), n(parent)) < 0 and not |dot| < 1e-5.  The visit order decides which parent a vertex gets, so
+ * this is a sequential host pass over the rows (no GPU work; xyz, rows and normals are host arrays);
+ * normals (n x 3) are updated in place.  opt_out_reached (may be NULL) receives the number of vertices
+ * reached from the root.  PCPX_ERR_INVALID if a row holds an index >= n. */
+int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint32_t* knn_idx,
+                                       const uint32_t* opt_knn_count, uint32_t k, float* normals,
+                                       uint64_t* opt_out_reached);
+
 /* estimate_normal over explicit neighbourhoods: row q = nbr_idx[q*k .. q*k+count[q]) indexes the
  * index's points.  opt_out_evals (nq x 3, ascending eigenvalues) may be NULL. */
 int pcpx_normals_from_knn(pcpx_index* idx, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq,

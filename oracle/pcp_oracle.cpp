@@ -804,6 +804,52 @@ void orc_mean_dist_from_knn(float const* xyz, float const* qxyz, u32 const* nbr,
     }
 }
 
+// pcp::algorithm::propagate_normal_orientations (include/pcp/algorithm/estimate_normals.hpp:187-302):
+//  * directed kNN graph, vertex i -> its neighbour row in row order (include/pcp/graph/knn_adjacency_list.hpp:112-156)
+//  * root = std::max_element by z (the FIRST point of maximal z, :224-232); its normal becomes (0, 0, 1) (:234-239)
+//  * breadth-first search from the root (include/pcp/graph/search.hpp:36-85): for every out-edge (u, v) of the
+//    popped vertex whose target is not yet visited: prod = n(v).x*n(u).x + n(v).y*n(u).y + n(v).z*n(u).z
+//    (include/pcp/common/norm.hpp:34-45), flip n(v) iff prod < 0 and not |prod - 0| < 1e-5
+//    (vector3d_queries.hpp:31-35), mark v visited, enqueue it; the popped vertex is marked visited after its edges.
+// Returns the number of vertices reached from the root (the root included).
+u64 orc_propagate_normal_orientations(float const* xyz, u64 n, u32 const* nbr, u32 const* cnt, u32 k, float* normals)
+{
+    if (n == 0) return 0;
+    P3 const* pts = reinterpret_cast<P3 const*>(xyz);
+    u64 root = 0;
+    for (u64 i = 1; i < n; ++i)
+        if (pts[root].z < pts[i].z) root = i;
+    normals[3 * root] = 0.f;
+    normals[3 * root + 1] = 0.f;
+    normals[3 * root + 2] = 1.f;
+    std::vector<bool> visited(n, false);
+    std::queue<u64> bfs;
+    bfs.push(root);
+    u64 reached = 1;
+    while (!bfs.empty()) {
+        u64 const u = bfs.front();
+        bfs.pop();
+        for (u32 j = 0; j < cnt[u]; ++j) {
+            u64 const v = nbr[u * k + j];
+            if (visited[v]) continue;
+            float const* n1 = normals + 3 * u;
+            float* n2 = normals + 3 * v;
+            float const xx = n2[0] * n1[0], yy = n2[1] * n1[1], zz = n2[2] * n1[2];
+            float const prod = xx + yy + zz;
+            if (prod < 0.f && !(std::abs(prod - 0.f) < 1e-5f)) {
+                n2[0] = -n2[0];
+                n2[1] = -n2[1];
+                n2[2] = -n2[2];
+            }
+            visited[v] = true;
+            if (v != root) ++reached;
+            bfs.push(v);
+        }
+        visited[u] = true;
+    }
+    return reached;
+}
+
 int orc_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
 
 }  // extern "C"

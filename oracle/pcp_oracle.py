@@ -208,6 +208,19 @@ def centroids_from_knn(xyz, nbr, cnt):
     return out
 
 
+def propagate_normal_orientations(xyz, nbr, cnt, normals):
+    """propagate_normal_orientations over explicit neighbour rows; returns (oriented normals, vertices reached)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    nbr = np.ascontiguousarray(nbr, np.uint32)
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    n, k = nbr.shape
+    out = np.array(normals, dtype=np.float32, order="C", copy=True).reshape(-1, 3)
+    fn = lib().orc_propagate_normal_orientations
+    fn.restype = C.c_uint64
+    reached = fn(_p(xyz, _f32p), C.c_uint64(n), _p(nbr, _u32p), _p(cnt, _u32p), C.c_uint32(k), _p(out, _f32p))
+    return out, int(reached)
+
+
 def mean_dist_from_knn(xyz, queries, nbr, cnt):
     """average_distances_to_neighbors: mean Euclidean distance from each query to its neighbour row."""
     xyz = _f32(xyz).reshape(-1, 3)

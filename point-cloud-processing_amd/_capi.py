@@ -73,6 +73,8 @@ SIGNATURES = {
     "pcpx_mean_knn_distance_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
     "pcpx_neighbourhoods_self_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),
+    "pcpx_propagate_normal_orientations": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                     u64p]),
     "pcpx_normals_from_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                         C.c_void_p]),
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),

@@ -689,6 +689,74 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_sta
     return PCPX_OK;
 }
 
+int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint32_t* knn_idx, const uint32_t* opt_knn_count,
+                                       uint32_t k, float* normals, uint64_t* opt_out_reached)
+{
+    if (opt_out_reached) *opt_out_reached = 0;
+    if (n == 0) return PCPX_OK;
+    if (!xyz || !normals || (k > 0 && !knn_idx)) {
+        set_error("pcpx_propagate_normal_orientations: null argument");
+        return PCPX_ERR_INVALID;
+    }
+    if (n > 0xFFFFFFFFull) {
+        set_error("pcpx_propagate_normal_orientations: more than 2^32 - 1 vertices");
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    for (u64 i = 0; i < n; ++i) {
+        const u32 c = opt_knn_count ? opt_knn_count[i] : k;
+        if (c > k) {
+            set_error("pcpx_propagate_normal_orientations: count[%llu] = %u exceeds k = %u", static_cast<unsigned long long>(i), c, k);
+            return PCPX_ERR_INVALID;
+        }
+        for (u32 j = 0; j < c; ++j)
+            if (knn_idx[i * k + j] >= n) {
+                set_error("pcpx_propagate_normal_orientations: row %llu holds index %u >= n", static_cast<unsigned long long>(i),
+                          knn_idx[i * k + j]);
+                return PCPX_ERR_INVALID;
+            }
+    }
+    // root: first point of largest z
+    u32 root = 0;
+    for (u64 i = 1; i < n; ++i)
+        if (xyz[3 * i + 2] > xyz[3 * static_cast<u64>(root) + 2]) root = static_cast<u32>(i);
+    normals[3 * static_cast<u64>(root)] = 0.f;
+    normals[3 * static_cast<u64>(root) + 1] = 0.f;
+    normals[3 * static_cast<u64>(root) + 2] = 1.f;
+    // every vertex enters the queue at most once (it is marked when first reached), so a flat array is the queue;
+    // the root is only marked after its own edges, like in the reference, which cannot matter: a vertex is not
+    // its own neighbour... unless a caller's rows say so, hence the explicit mark order is kept.
+    std::vector<u32> order;
+    order.reserve(n);
+    std::vector<unsigned char> seen(n, 0);
+    order.push_back(root);
+    for (size_t head = 0; head < order.size(); ++head) {
+        const u64 u = order[head];
+        const u32 c = opt_knn_count ? opt_knn_count[u] : k;
+        for (u32 j = 0; j < c; ++j) {
+            const u64 v = knn_idx[u * k + j];
+            if (seen[v]) continue;
+            const float* a = normals + 3 * u;
+            float* b = normals + 3 * v;
+            const float xx = b[0] * a[0], yy = b[1] * a[1], zz = b[2] * a[2];
+            const float dot = xx + yy + zz;
+            if (dot < 0.f && !(std::fabs(dot - 0.f) < 1e-5f)) {
+                b[0] = -b[0];
+                b[1] = -b[1];
+                b[2] = -b[2];
+            }
+            seen[v] = 1;
+            order.push_back(static_cast<u32>(v));
+        }
+        seen[u] = 1;
+    }
+    if (opt_out_reached) {
+        u64 reached = 0;
+        for (u64 i = 0; i < n; ++i) reached += seen[i];
+        *opt_out_reached = reached;
+    }
+    return PCPX_OK;
+}
+
 int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
                           uint32_t* out_vals)
 {

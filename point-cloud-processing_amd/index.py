@@ -294,3 +294,21 @@ def estimate_normals(tree, k, eps=1e-5):
     """pcp::algorithm::estimate_normals with knn_map = tree.nearest_neighbours(point, k): one normal
     per indexed point (examples/simple_example.cpp:83-99)."""
     return tree.normals_knn_self(k, eps)
+
+
+def propagate_normal_orientations(points, knn_idx, normals, knn_count=None):
+    """pcp::algorithm::propagate_normal_orientations (include/pcp/algorithm/estimate_normals.hpp:187-302) over
+    the kNN rows the query kernels return (knn_idx n x k, optional per-row counts): root = first point of
+    largest z with normal (0,0,1), breadth-first flips.  Returns (oriented normals, vertices reached)."""
+    pts = _f32(points, 3)
+    nbr = np.ascontiguousarray(knn_idx, dtype=np.uint32)
+    if nbr.ndim != 2 or nbr.shape[0] != pts.shape[0]:
+        raise ValueError("knn_idx must be n x k")
+    out = np.array(normals, dtype=np.float32, order="C", copy=True).reshape(-1, 3)
+    if out.shape[0] != pts.shape[0]:
+        raise ValueError("normals must be n x 3")
+    cnt = None if knn_count is None else np.ascontiguousarray(knn_count, dtype=np.uint32)
+    reached = C.c_uint64(0)
+    check(_capi.load().pcpx_propagate_normal_orientations(_vp(pts), pts.shape[0], _vp(nbr), None if cnt is None else _vp(cnt),
+                                                          nbr.shape[1], _vp(out), C.byref(reached)))
+    return out, int(reached.value)

@@ -239,6 +239,35 @@ static void normal_scenarios()
         REQUIRE(pcp::common::are_vectors_equal(plane.normal(), expected) || pcp::common::are_vectors_equal(plane.normal(), -expected));
         REQUIRE(plane.contains(point_t{1.f, -1.f, 0.f}));
     }
+    // normal orientation (test/algorithm/estimate_normals.cpp:67-155): 5 points with inconsistent signs, k = 2
+    {
+        std::vector<point_t> pc = {{-1.f, -1.f, -.1f}, {-.9f, -1.f, .2f}, {.9f, .9f, .1f}, {1.1f, 1.1f, -.2f}, {1.1f, 1.1f, -.3f}};
+        std::vector<pcp::normal_t> const start = {{0.f, 0.f, -1.f}, {0.f, 0.f, 1.f}, {0.f, 0.f, 1.f}, {0.f, 0.f, -1.f}, {0.f, 0.f, -1.f}};
+        using vertex_type = pcp::vertex_t;
+        std::vector<vertex_type> vertices;
+        for (std::uint32_t i = 0; i < pc.size(); ++i) vertices.push_back(vertex_type{&pc[i], i});
+        auto const vpoint_map = [&pc](vertex_type const& v) { return pc[v.id()]; };
+        auto const index_map  = [](vertex_type const& v) { return v.id(); };
+        pcp::octree_parameters_t<point_t> vp;
+        vp.voxel_grid = {{-2.f, -2.f, -2.f}, {2.f, 2.f, 2.f}};
+        pcp::basic_linked_octree_t<vertex_type, decltype(vp)> voctree(vertices.cbegin(), vertices.cend(), vpoint_map, vp);
+        for (int variant = 0; variant < 3; ++variant)
+        {
+            std::vector<pcp::normal_t> normals = start;
+            auto const normal_map  = [&normals](vertex_type const& v) { return normals[v.id()]; };
+            auto const transform_op = [&normals](vertex_type const& v, pcp::normal_t const& nn) { normals[v.id()] = nn; };
+            auto const vknn = [&](vertex_type const& v) { return voctree.nearest_neighbours(vertices[v.id()], 2u, vpoint_map); };
+            if (variant == 0)  // the reference's call shape: per-vertex lambda
+                pcp::algorithm::propagate_normal_orientations(vertices.begin(), vertices.end(), index_map, vknn, vpoint_map, normal_map, transform_op);
+            else if (variant == 1)  // all rows from one batched launch
+                pcp::algorithm::propagate_normal_orientations(vertices.begin(), vertices.end(), index_map,
+                                                              pcp::gpu::knn_map(voctree, vpoint_map, 2u), vpoint_map, normal_map, transform_op);
+            else  // the range is the container's own sequence
+                pcp::algorithm::propagate_normal_orientations(vertices.begin(), vertices.end(), index_map,
+                                                              pcp::gpu::self_knn_map(voctree, 2u), vpoint_map, normal_map, transform_op);
+            for (auto const& nn : normals) REQUIRE(pcp::common::are_vectors_equal(nn, expected));
+        }
+    }
     // point views and index elements as Element types (examples/simple_example.cpp, examples/normals_estimation.cpp)
     std::vector<pcp::point_view_t> views;
     for (auto& p : cloud) views.push_back(pcp::point_view_t{&p});

@@ -6,7 +6,8 @@
 2. stanford_bunny.ply  -- copy of the reference's example DATA file examples/data/stanford_bunny.ply
    (BASELINE config 1 input; a data file, not source).
 3. bunny_k15.npz       -- oracle outputs on the bunny: (d2,index)-sorted 15-NN rows and PCA normals of
-   512 evenly spaced query points, plus sphere-range counts, produced by oracle/pcp_oracle.cpp after
+   512 evenly spaced query points, plus sphere-range counts, plus the normal-orientation pass over the
+   whole cloud (which normals the BFS flips, 1 bit per point), produced by oracle/pcp_oracle.cpp after
    it has been checked against (1) (tests/test_oracle.py does that check on every run).
 
 Run from the repo root in the build container: python tests/golden/make_golden.py
@@ -77,6 +78,13 @@ def kats():
         "normal": {"source": "test/common/normal_estimation.cpp:11-38, test/common/plane3d.cpp:33-69",
                    "points": [[0, 0, 0], [-2, 0, 0], [2, 0, 0], [0, -2, 0], [0, 2, 0], [0, 0, -1], [0, 0, 1]],
                    "expected_normal_up_to_sign": [0, 0, 1], "component_tolerance": 1e-5},
+        "normal_orientation": {
+            "source": "test/algorithm/estimate_normals.cpp:67-155 (5 points with inconsistent normal signs, k = 2 through an octree "
+                      "with voxel grid [-2,2]^3; expected: every normal equals (0,0,1) within 1e-5 per component)",
+            "voxel_grid": [-2, -2, -2, 2, 2, 2],
+            "points": [[-1., -1., -.1], [-.9, -1., .2], [.9, .9, .1], [1.1, 1.1, -.2], [1.1, 1.1, -.3]],
+            "normals": [[0, 0, -1], [0, 0, 1], [0, 0, 1], [0, 0, -1], [0, 0, -1]], "k": 2,
+            "expected_normal": [0, 0, 1], "component_tolerance": 1e-5},
         "eps": 1e-5,
     }
 
@@ -98,12 +106,19 @@ def main():
     idx, cnt, d2 = O.knn_bruteforce(pts, pts[qsel], 15, eps=1e-5, nthreads=8, want_d2=True)
     nrm, ev = O.normals_from_knn(pts, idx, cnt, want_evals=True)
     rc = O.range_count_bruteforce(pts, pts[qsel], 0.01, nthreads=8)
+    # normal orientation over the whole bunny: 15-NN rows and normals of every point, then the BFS; stored as the
+    # sign flips (1 bit per point) and the number of points reached from the root
+    idx_all, cnt_all = O.knn_bruteforce(pts, pts, 15, eps=1e-5, nthreads=8)[:2]
+    nrm_all = O.normals_from_knn(pts, idx_all, cnt_all)
+    ori, reached = O.propagate_normal_orientations(pts, idx_all, cnt_all, nrm_all)
+    flipped = np.packbits(np.any(np.signbit(ori) != np.signbit(nrm_all), axis=1))
     # the restated octree/kd-tree must agree with brute force here (also asserted in tests/test_oracle.py)
     oi, oc = O.Octree(pts).knn(pts[qsel], 15)
     ki, kc = O.KdTree(pts, compute_max_depth=True).knn(pts[qsel], 15)
     assert (oi == idx).all() and (ki == idx).all()
     np.savez_compressed(os.path.join(HERE, "bunny_k15.npz"), query_index=qsel, knn_idx=idx, knn_cnt=cnt, knn_d2=d2,
-                        normals=nrm, evals=ev, range_count_r001=rc)
+                        normals=nrm, evals=ev, range_count_r001=rc, orientation_flipped=flipped,
+                        orientation_root=np.int64(np.argmax(pts[:, 2])), orientation_reached=np.int64(reached))
     print("wrote fixtures to", HERE)
 
 

@@ -431,3 +431,38 @@ def test_large_k_multipass(pkg, oracle):
     ix = _check_knn_exact(pkg, oracle, pts, None, 48, self_query=True)
     nrm, idx, cnt = ix.normals_knn_self(48, want_knn=True)
     assert _cos_err(nrm, oracle.normals_from_knn(pts, idx, cnt, nthreads=8)).max() <= COS_TOL
+
+
+# ---- normal orientation (propagate_normal_orientations) ---------------------------------------------------------
+def test_normal_orientation_kat_through_the_abi(pkg, kats):
+    """test/algorithm/estimate_normals.cpp:67-155: GPU kNN rows (k = 2) + the ABI's breadth-first pass."""
+    c = kats["normal_orientation"]
+    pts = np.array(c["points"], np.float32)
+    ix = pkg.Index(pts, voxel_grid=c["voxel_grid"])
+    idx, cnt = ix.knn_self(c["k"])[:2]
+    out, reached = pkg.propagate_normal_orientations(pts, idx, np.array(c["normals"], np.float32), cnt)
+    assert reached == len(pts)
+    assert np.all(np.abs(out - np.array(c["expected_normal"], np.float32)) < c["component_tolerance"])
+
+
+def test_bunny_orientation_matches_oracle(pkg, oracle, bunny, bunny_golden):
+    """configs[0] cloud: normals and 15-NN rows from the fused kernel, orientation by the ABI; bit-identical to the
+    oracle's pass over the same rows, and to the committed flip bits wherever the rows equal the oracle's."""
+    ix = pkg.Index(bunny)
+    nrm, idx, cnt = ix.normals_knn_self(15, want_knn=True)
+    out, reached = pkg.propagate_normal_orientations(bunny, idx, nrm, cnt)
+    ref, ref_reached = oracle.propagate_normal_orientations(bunny, idx, cnt, nrm)
+    assert reached == ref_reached == len(bunny)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    oidx, ocnt = oracle.knn_bruteforce(bunny, bunny, 15, nthreads=8)[:2]
+    onrm = oracle.normals_from_knn(bunny, oidx, ocnt)
+    if np.array_equal(oidx, idx) and np.array_equal(onrm.view(np.uint32), nrm.view(np.uint32)):
+        flipped = np.any(np.signbit(out) != np.signbit(nrm), axis=1)
+        assert np.array_equal(np.packbits(flipped), bunny_golden["orientation_flipped"])
+
+
+def test_orientation_rejects_bad_rows(pkg):
+    pts = np.zeros((4, 3), np.float32)
+    rows = np.array([[1], [2], [3], [9]], np.uint32)
+    with pytest.raises(pkg.PcpxError):
+        pkg.propagate_normal_orientations(pts, rows, np.zeros((4, 3), np.float32))
