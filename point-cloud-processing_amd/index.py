@@ -221,6 +221,10 @@ class Index:
         check(self._lib.pcpx_knn_self_dev(self._h, k, eps, first, count, C.c_void_p(d_idx), C.c_void_p(d_cnt),
                                           C.c_void_p(d_d2) if d_d2 else None))
 
+    def knn_batch_dev(self, d_queries, nq, k, eps, d_idx, d_cnt, d_d2=None):
+        """kNN of nq arbitrary device-resident query points (Morton-sorted internally, rows in query order)."""
+        check(self._lib.pcpx_knn_batch_dev(self._h, d_queries, nq, k, eps, d_idx, d_cnt, d_d2))
+
     def normals_knn_self_dev(self, k, eps, d_normals, d_idx=None, d_cnt=None, first=0, count=_capi.UINT64_MAX):
         check(self._lib.pcpx_normals_knn_self_dev(self._h, k, eps, first, count, C.c_void_p(d_normals),
                                                   C.c_void_p(d_idx) if d_idx else None,

@@ -26,6 +26,7 @@ timeout -k 10 500 python3 bench.py --workload uniform_50m_k32_stream --no-cpu-ba
 echo "workloads done"
 # 6. PCIe-inclusive host-pointer ABI timings
 timeout -k 10 300 python3 tools/pcie_inclusive.py > "$out/pcie_inclusive.json" 2>> "$out/bench.err" || { echo "pcie failed"; exit 1; }
+timeout -k 10 300 python3 tools/batch_query_rate.py > "$out/batch_query_rate.json" 2>> "$out/bench.err" || { echo "batch failed"; exit 1; }
 # 7. instruction issue costs
 hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && timeout -k 10 120 /tmp/valu_rate > "$out/valu_issue_rates.txt" 2>&1
 echo "all done"
