@@ -561,6 +561,12 @@ int pcpx_neighbourhoods_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t 
     o.normals = d_opt_normals;
     o.centroids = d_opt_centroids;
     o.meandist = d_opt_mean_dist;
+    if (k > 32) {  // the multi-pass path materialises rows: keep them in index scratch
+        size_t need_idx = (static_cast<size_t>(ix->n_in) * k * sizeof(u32) + 255) / 256 * 256;
+        if ((st = ensure_scratch(*ix, need_idx + static_cast<size_t>(ix->n_in) * sizeof(u32))) != PCPX_OK) return st;
+        o.idx = static_cast<u32*>(ix->d_scratch);
+        o.cnt = reinterpret_cast<u32*>(static_cast<char*>(ix->d_scratch) + need_idx);
+    }
     return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
 }
 

@@ -184,7 +184,7 @@ int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float*
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt);
 int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx);
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
-                   float* d_out, float* d_evals);
+                   float* d_out, float* d_evals, float* d_centroids = nullptr, float* d_meandist = nullptr);
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
 

@@ -1078,7 +1078,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
 // thread i handles neighbourhood row = rowmap ? rowmap[first+i] : first+i
 __global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, const u32* __restrict__ nbr,
                                                  const u32* __restrict__ cnt, const u32* __restrict__ rowmap, u64 first,
-                                                 u64 count, u32 k, float* __restrict__ out, float* __restrict__ evals)
+                                                 u64 count, u32 k, float* __restrict__ out, float* __restrict__ evals,
+                                                 float* __restrict__ centroids, float* __restrict__ meandist)
 {
     u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
@@ -1094,6 +1095,22 @@ __global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, 
     }
     float fn = static_cast<float>(n);
     float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    if (centroids) {  // center_of_geometry of the row: the tangent plane's point
+        centroids[3 * row] = mx;
+        centroids[3 * row + 1] = my;
+        centroids[3 * row + 2] = mz;
+    }
+    if (meandist) {  // average_distances_to_neighbors; the row belongs to indexed point `row` (self queries only)
+        const float qx = xyz[3 * row], qy = xyz[3 * row + 1], qz = xyz[3 * row + 2];
+        float sum = 0.f;
+        for (u32 j = 0; j < n; ++j) {
+            u64 id = nb[j];
+            float dx = xyz[3 * id] - qx, dy = xyz[3 * id + 1] - qy, dz = xyz[3 * id + 2] - qz;
+            sum += sqrtf(sq3(dx, dy, dz));
+        }
+        meandist[row] = sum / fn;
+    }
+    if (!out) return;
     float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
     for (u32 j = 0; j < n; ++j) {
         u64 id = nb[j];
@@ -1335,9 +1352,9 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
                                 const KnnOutputs& o)
 {
     constexpr int KCAP = 32, BUF = buf_rows(KCAP);
-    if (o.centroids || o.meandist) {
-        set_error("pcpx: tangent planes / mean distances are limited to k <= 32");
-        return PCPX_ERR_UNSUPPORTED;
+    if ((o.centroids || o.meandist) && !self) {
+        set_error("pcpx: tangent planes / mean distances are defined for the indexed points only");
+        return PCPX_ERR_INVALID;
     }
     const u32 npass = (k + KCAP - 1) / KCAP;
     const u32 stride = npass * KCAP;
@@ -1383,16 +1400,16 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
     if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
     else k_assemble<false><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
     PCPX_HIP(hipGetLastError());
-    if (o.normals) {
+    if (o.normals || o.centroids || o.meandist) {
         if (!o.idx || !o.cnt) {
-            set_error("pcpx: normals with k > 32 need the neighbour rows as outputs too");
+            set_error("pcpx: per-neighbourhood products with k > 32 need the neighbour rows as outputs too");
             return PCPX_ERR_INVALID;
         }
         // rows are complete in HBM: PCA normal per row (row order: sorted slots -> rows)
         const u32* rowmap = self ? ix.perm() : qv.row;
         return launch_normals(ix, o.idx, o.cnt, rowmap, static_cast<u64>(gf) * GROUP,
                               (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP < nslots ? (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP : nslots,
-                              k, o.normals, nullptr);
+                              k, o.normals, nullptr, o.centroids, o.meandist);
     }
     return PCPX_OK;
 }
@@ -1467,14 +1484,14 @@ int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offs
 }
 
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
-                   float* d_out, float* d_evals)
+                   float* d_out, float* d_evals, float* d_centroids, float* d_meandist)
 {
     if (count == 0) return PCPX_OK;
     ProfileScope prof(ix, PCPX_K_NORMALS);
     hipStream_t s = ix.stream;
     const float* d_xyz = ix.d_xyz;
     k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
-                                                                     d_evals);
+                                                                     d_evals, d_centroids, d_meandist);
     return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);
 }
 

@@ -401,7 +401,8 @@ def test_radix_sort_is_a_stable_sort(pkg, n):
 def test_tangent_planes_and_mean_distances(pkg, oracle, bunny):
     """estimate_tangent_planes (plane = centroid of the k-neighbourhood + PCA normal) and
     average_distances_to_neighbors, fused into the kNN kernel, against the oracle's restatement."""
-    for pts, k in ((bunny, 15), (pkg.synthetic.clustered_cloud(50_000, seed=44), 9)):
+    # k = 24: the KCAP-32 kernel; k = 40: the multi-pass path, where the products come from the finished rows
+    for pts, k in ((bunny, 15), (pkg.synthetic.clustered_cloud(50_000, seed=44), 9), (bunny[::3], 24), (bunny[::5], 40)):
         ix = pkg.Index(pts)
         idx, cnt = ix.knn_self(k)
         cen, nrm = ix.tangent_planes_knn_self(k)
