@@ -1,0 +1,155 @@
+// pcpx_device.h -- device-side helpers shared by the query kernels (kNN, range search, normals): arithmetic of
+// the reference (squared distance, box lower bound), scalar (SMEM) record loads, and the wave-uniform walk
+// over the implicit 4-ary tree.  Included by .hip translation units only.
+#ifndef PCPX_DEVICE_H
+#define PCPX_DEVICE_H
+
+#include "pcpx_internal.h"
+
+#include <cmath>
+#include <limits>
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace pcpx {
+namespace {
+
+#ifndef PCPX_WPB
+#define PCPX_WPB 1
+#endif
+constexpr int WAVES_PER_BLOCK = PCPX_WPB;  // 1: a finished wave frees its LDS at once (no intra-block tail)
+
+__device__ __forceinline__ u32 wave_in_block() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give XCD x the
+// contiguous range of virtual blocks [x*per, (x+1)*per): Morton neighbours then share one L2.
+__device__ __forceinline__ u32 virtual_block()
+{
+    u32 per = gridDim.x >> 3;  // grid is a multiple of 8
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
+
+// squared distance from q to the box (+ poison): equals d2(q, clamp(q, box)) of
+// include/pcp/common/axis_aligned_bounding_box.hpp:138-148 and is a lower bound, in float arithmetic,
+// of sq3(p - q) for every p inside the box; NaN for a padding node.
+__device__ __forceinline__ float box_d2(const NodeBox& b, float qx, float qy, float qz)
+{
+    // (v_med3_f32(q, lo, hi) takes two SGPR operands, which gfx9 VALU encodings do not allow: no cheaper)
+    float dx = fmaxf(fmaxf(b.lo[0] - qx, qx - b.hi[0]), 0.f);
+    float dy = fmaxf(fmaxf(b.lo[1] - qy, qy - b.hi[1]), 0.f);
+    float dz = fmaxf(fmaxf(b.lo[2] - qz, qz - b.hi[2]), 0.f);
+    return sq3(dx, dy, dz) + b.poison;
+}
+
+struct NodeBox4 {
+    NodeBox c[W];
+};
+
+__device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
+// Index records (leaves, node boxes) are immutable while a query kernel runs.  Reading them through
+// constant-address-space pointers makes every wave-uniform read a scalar (SMEM) load unconditionally;
+// through generic pointers hipcc only does that while it can prove no store (or asm with a memory
+// clobber, like append_if) may alias them.
+template <class T>
+__device__ __forceinline__ T load_const(const T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "record size");
+    typedef const __attribute__((address_space(4))) u32* const_u32_ptr;
+    const_u32_ptr c = (const_u32_ptr)(reinterpret_cast<uintptr_t>(p));
+    T out;
+    u32* o = reinterpret_cast<u32*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = c[i];
+    return out;
+}
+
+__device__ __forceinline__ u32 lds_address(const void* p)
+{
+    return static_cast<u32>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS pointer = LDS offset
+}
+
+// ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
+
+// All members are wave-uniform (SGPRs).  next() yields, in Morton order, every leaf whose box is still
+// needed by at least one lane at the time its parent is expanded.  State: bit 4*h + c of `pend` = child c
+// (a node of height h; leaves have height 0) of the current ancestor of height h+1 is still to visit.  A
+// depth-first walk always continues with the LOWEST set bit of pend, so popping is one find-first-set: no
+// per-level loop.  `ploc` is the level-local index of the ancestor of height l+1 (node ids are never
+// stored: heap id = (4^d - 1)/3 + local index at tree level d, and a leaf's local index is its number).
+struct Walker {
+    u64 pend;
+    u32 ploc;
+    int l;
+
+    // first heap id of tree level d >= 1: (4^d - 1) / 3 = 0b0101...01 (d pairs)
+    static __device__ __forceinline__ u32 level_base(int d) { return 0x55555555u >> (32 - 2 * d); }
+
+    // bit c set: child c of the node with local index `loc` at tree level d is needed by some lane
+    template <class Need>
+    __device__ __forceinline__ u32 child_mask(const TreeView& t, int d, u32 loc, Need&& need)
+    {
+        const u32 first_child = level_base(d + 1) + (loc << LOGW);  // heap id of child 0
+        const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
+        u32 m = 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
+        return __builtin_amdgcn_readfirstlane(m);  // keeps the walk state in SGPRs (hipcc may build m with v_cndmask)
+    }
+
+    // returns true if the root itself is the single leaf (depth 0) and is needed
+    template <class Need>
+    __device__ __forceinline__ bool start(const TreeView& t, Need&& need, u32& n_expand)
+    {
+        pend = 0;
+        ploc = 0;
+        l = 0;
+        if (t.nleaves == 0) return false;
+        const NodeBox root = load_const(t.nodes);
+        if (!any_lane(need(root))) return false;
+        if (t.depth == 0) return true;
+        ++n_expand;
+        l = t.depth - 1;
+        pend = static_cast<u64>(child_mask(t, 0, 0u, need)) << (W * l);
+        return false;
+    }
+
+    template <class Need>
+    __device__ __forceinline__ bool next(const TreeView& t, Need&& need, u32& leaf, u32& n_expand)
+    {
+        while (pend != 0) {
+            const int bit = __builtin_ctzll(pend);
+            pend &= ~(1ull << bit);
+            const int h = bit >> LOGW;
+            const u32 loc = ((ploc >> (LOGW * (h - l))) << LOGW) + (static_cast<u32>(bit) & (W - 1u));  // climb h - l levels, step down
+            if (h == 0) {
+                ploc = loc >> LOGW;
+                l = 0;
+                leaf = loc;
+                return true;
+            }
+            ++n_expand;
+            l = h - 1;
+            ploc = loc;
+            pend |= static_cast<u64>(child_mask(t, t.depth - h, loc, need)) << (W * l);
+        }
+        return false;
+    }
+};
+
+inline u32 grid_for_groups(u64 groups)
+{
+    u64 blocks = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    blocks = (blocks + 7) / 8 * 8;
+    return static_cast<u32>(blocks);
+}
+
+inline float sanitize_eps(float eps) { return eps > 0.f ? eps : 0.f; }  // eps <= 0 or NaN: nothing is "equal"
+
+}  // namespace
+}  // namespace pcpx
+
+#endif

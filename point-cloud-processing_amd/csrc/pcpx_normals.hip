@@ -1,0 +1,109 @@
+// pcpx_normals.hip -- pcp::estimate_normal over explicit neighbourhoods (rows of indices, or one point set); the
+// fused form lives in the kNN kernel (pcpx_query.hip), both use the solver of pcpx_eig3.h.
+#include "pcpx_eig3.h"
+
+namespace pcpx {
+
+namespace {
+
+// thread i handles neighbourhood row = rowmap ? rowmap[first+i] : first+i
+__global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, const u32* __restrict__ nbr,
+                                                 const u32* __restrict__ cnt, const u32* __restrict__ rowmap, u64 first,
+                                                 u64 count, u32 k, float* __restrict__ out, float* __restrict__ evals,
+                                                 float* __restrict__ centroids, float* __restrict__ meandist)
+{
+    u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    u64 row = rowmap ? rowmap[first + i] : first + i;
+    u32 n = cnt ? cnt[row] : k;
+    const u32* nb = nbr + row * k;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u32 j = 0; j < n; ++j) {
+        u64 id = nb[j];
+        float x = xyz[3 * id], y = xyz[3 * id + 1], z = xyz[3 * id + 2];
+        if (j == 0) { sx = x; sy = y; sz = z; }
+        else { sx += x; sy += y; sz += z; }
+    }
+    float fn = static_cast<float>(n);
+    float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    if (centroids) {  // center_of_geometry of the row: the tangent plane's point
+        centroids[3 * row] = mx;
+        centroids[3 * row + 1] = my;
+        centroids[3 * row + 2] = mz;
+    }
+    if (meandist) {  // average_distances_to_neighbors; the row belongs to indexed point `row` (self queries only)
+        const float qx = xyz[3 * row], qy = xyz[3 * row + 1], qz = xyz[3 * row + 2];
+        float sum = 0.f;
+        for (u32 j = 0; j < n; ++j) {
+            u64 id = nb[j];
+            float dx = xyz[3 * id] - qx, dy = xyz[3 * id + 1] - qy, dz = xyz[3 * id + 2] - qz;
+            sum += sqrtf(sq3(dx, dy, dz));
+        }
+        meandist[row] = sum / fn;
+    }
+    if (!out) return;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    for (u32 j = 0; j < n; ++j) {
+        u64 id = nb[j];
+        float vx = xyz[3 * id] - mx, vy = xyz[3 * id + 1] - my, vz = xyz[3 * id + 2] - mz;
+        c00 += vx * vx;
+        c10 += vy * vx;
+        c11 += vy * vy;
+        c20 += vz * vx;
+        c21 += vz * vy;
+        c22 += vz * vz;
+    }
+    float nrm[3], ev[3];
+    eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
+    out[3 * row] = nrm[0];
+    out[3 * row + 1] = nrm[1];
+    out[3 * row + 2] = nrm[2];
+    if (evals) {
+        evals[3 * row] = ev[0];
+        evals[3 * row + 1] = ev[1];
+        evals[3 * row + 2] = ev[2];
+    }
+}
+
+// estimate_normal over an explicit point set (m x 3): a single thread, the set is tiny in practice
+__global__ void k_normal_single(const float* __restrict__ xyz, u64 m, float* __restrict__ out3)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u64 j = 0; j < m; ++j) {
+        float x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
+        if (j == 0) { sx = x; sy = y; sz = z; }
+        else { sx += x; sy += y; sz += z; }
+    }
+    float fn = static_cast<float>(m);
+    float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    for (u64 j = 0; j < m; ++j) {
+        float vx = xyz[3 * j] - mx, vy = xyz[3 * j + 1] - my, vz = xyz[3 * j + 2] - mz;
+        c00 += vx * vx; c10 += vy * vx; c11 += vy * vy; c20 += vz * vx; c21 += vz * vy; c22 += vz * vz;
+    }
+    float ev[3];
+    eig3_smallest(c00, c10, c20, c11, c21, c22, out3, ev);
+}
+
+}  // namespace
+
+int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
+                   float* d_out, float* d_evals, float* d_centroids, float* d_meandist)
+{
+    if (count == 0) return PCPX_OK;
+    ProfileScope prof(ix, PCPX_K_NORMALS);
+    hipStream_t s = ix.stream;
+    const float* d_xyz = ix.d_xyz;
+    k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
+                                                                     d_evals, d_centroids, d_meandist);
+    return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);
+}
+
+int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s)
+{
+    k_normal_single<<<1, 64, 0, s>>>(d_xyz, m, d_out3);
+    return check_hip(hipGetLastError(), "k_normal_single launch", __FILE__, __LINE__);
+}
+
+}  // namespace pcpx

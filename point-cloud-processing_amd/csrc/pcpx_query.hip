@@ -29,54 +29,14 @@
 // (include/pcp/common/vector3d_queries.hpp:47-64).  The box lower bound is monotone in float, so
 // pruning never changes the result.  Rows are the exact k nearest in ascending (d2, index) order; if
 // several points tie EXACTLY with the k-th distance, which of them is kept is unspecified -- as in the
-// reference, where it depends on heap order (linked_octree_node.hpp:479-489, linked_kdtree.hpp:483-488).
-#include "pcpx_internal.h"
-
-#include <cmath>
-#include <limits>
-#include <type_traits>
-
-#pragma clang fp contract(off)
+// reference, where it depends on heap order (linked_octree_node.hpp:479-489, linked_kdtree.hpp:483-488).#include "pcpx_device.h"
+#include "pcpx_eig3.h"
 
 namespace pcpx {
 
 namespace {
 
 constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID): larger than every real key, a finite double
-#ifndef PCPX_WPB
-#define PCPX_WPB 1
-#endif
-constexpr int WAVES_PER_BLOCK = PCPX_WPB;  // 1: a finished wave frees its LDS at once (no intra-block tail)
-
-__device__ __forceinline__ u32 wave_in_block() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
-
-// XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give XCD x the
-// contiguous range of virtual blocks [x*per, (x+1)*per): Morton neighbours then share one L2.
-__device__ __forceinline__ u32 virtual_block()
-{
-    u32 per = gridDim.x >> 3;  // grid is a multiple of 8
-    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-}
-
-__device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
-
-// squared distance from q to the box (+ poison): equals d2(q, clamp(q, box)) of
-// include/pcp/common/axis_aligned_bounding_box.hpp:138-148 and is a lower bound, in float arithmetic,
-// of sq3(p - q) for every p inside the box; NaN for a padding node.
-__device__ __forceinline__ float box_d2(const NodeBox& b, float qx, float qy, float qz)
-{
-    // (v_med3_f32(q, lo, hi) takes two SGPR operands, which gfx9 VALU encodings do not allow: no cheaper)
-    float dx = fmaxf(fmaxf(b.lo[0] - qx, qx - b.hi[0]), 0.f);
-    float dy = fmaxf(fmaxf(b.lo[1] - qy, qy - b.hi[1]), 0.f);
-    float dz = fmaxf(fmaxf(b.lo[2] - qz, qz - b.hi[2]), 0.f);
-    return sq3(dx, dy, dz) + b.poison;
-}
-
-struct NodeBox4 {
-    NodeBox c[W];
-};
-
-__device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
 // ---- selection network on 64-bit keys -------------------------------------------------------------
 // Keys are (float32 d2 >= 0 bits) << 32 | u32: as IEEE doubles they are finite, non-negative and
@@ -277,263 +237,6 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
                  : [wa] "+v"(wa), [pos] "+v"(pos)
                  : [d2] "v"(d2), [tau] "v"(tau), [lo] "s"(lo), [m] "v"(m), [eps] "s"(eps), [sv] "s"(saved)
                  : "vcc", "memory");
-}
-
-// Index records (leaves, node boxes) are immutable while a query kernel runs.  Reading them through
-// constant-address-space pointers makes every wave-uniform read a scalar (SMEM) load unconditionally;
-// through generic pointers hipcc only does that while it can prove no store (or asm with a memory
-// clobber, like append_if) may alias them.
-template <class T>
-__device__ __forceinline__ T load_const(const T* p)
-{
-    static_assert(sizeof(T) % 4 == 0, "record size");
-    typedef const __attribute__((address_space(4))) u32* const_u32_ptr;
-    const_u32_ptr c = (const_u32_ptr)(reinterpret_cast<uintptr_t>(p));
-    T out;
-    u32* o = reinterpret_cast<u32*>(&out);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = c[i];
-    return out;
-}
-
-__device__ __forceinline__ u32 lds_address(const void* p)
-{
-    return static_cast<u32>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a generic LDS pointer = LDS offset
-}
-
-// ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
-
-// All members are wave-uniform (SGPRs).  next() yields, in Morton order, every leaf whose box is still
-// needed by at least one lane at the time its parent is expanded.  State: bit 4*h + c of `pend` = child c
-// (a node of height h; leaves have height 0) of the current ancestor of height h+1 is still to visit.  A
-// depth-first walk always continues with the LOWEST set bit of pend, so popping is one find-first-set: no
-// per-level loop.  `ploc` is the level-local index of the ancestor of height l+1 (node ids are never
-// stored: heap id = (4^d - 1)/3 + local index at tree level d, and a leaf's local index is its number).
-struct Walker {
-    u64 pend;
-    u32 ploc;
-    int l;
-
-    // first heap id of tree level d >= 1: (4^d - 1) / 3 = 0b0101...01 (d pairs)
-    static __device__ __forceinline__ u32 level_base(int d) { return 0x55555555u >> (32 - 2 * d); }
-
-    // bit c set: child c of the node with local index `loc` at tree level d is needed by some lane
-    template <class Need>
-    __device__ __forceinline__ u32 child_mask(const TreeView& t, int d, u32 loc, Need&& need)
-    {
-        const u32 first_child = level_base(d + 1) + (loc << LOGW);  // heap id of child 0
-        const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
-        u32 m = 0;
-#pragma unroll
-        for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
-        return __builtin_amdgcn_readfirstlane(m);  // keeps the walk state in SGPRs (hipcc may build m with v_cndmask)
-    }
-
-    // returns true if the root itself is the single leaf (depth 0) and is needed
-    template <class Need>
-    __device__ __forceinline__ bool start(const TreeView& t, Need&& need, u32& n_expand)
-    {
-        pend = 0;
-        ploc = 0;
-        l = 0;
-        if (t.nleaves == 0) return false;
-        const NodeBox root = load_const(t.nodes);
-        if (!any_lane(need(root))) return false;
-        if (t.depth == 0) return true;
-        ++n_expand;
-        l = t.depth - 1;
-        pend = static_cast<u64>(child_mask(t, 0, 0u, need)) << (W * l);
-        return false;
-    }
-
-    template <class Need>
-    __device__ __forceinline__ bool next(const TreeView& t, Need&& need, u32& leaf, u32& n_expand)
-    {
-        while (pend != 0) {
-            const int bit = __builtin_ctzll(pend);
-            pend &= ~(1ull << bit);
-            const int h = bit >> LOGW;
-            const u32 loc = ((ploc >> (LOGW * (h - l))) << LOGW) + (static_cast<u32>(bit) & (W - 1u));  // climb h - l levels, step down
-            if (h == 0) {
-                ploc = loc >> LOGW;
-                l = 0;
-                leaf = loc;
-                return true;
-            }
-            ++n_expand;
-            l = h - 1;
-            ploc = loc;
-            pend |= static_cast<u64>(child_mask(t, t.depth - h, loc, need)) << (W * l);
-        }
-        return false;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// PCA normal of one neighbourhood per thread.
-// Restates pcp::estimate_normal (include/pcp/common/normals/normal_estimation.hpp:41-77): row mean,
-// centred scatter matrix V'V'^T (not divided by n), Eigen 3.3.8 SelfAdjointEigenSolver<Matrix3f>
-// ::compute (scale, closed-form 3x3 tridiagonalisation, implicit-shift QL, ascending sort), column of
-// the smallest eigenvalue with the reference's "last tie wins" ifs.  All in float32 without FMA, in
-// the same operation order as the CPU restatement used by the tests, so results are bit-comparable with it.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void make_givens(float p, float q, float& c, float& s)
-{
-    if (q == 0.f) {
-        c = p < 0.f ? -1.f : 1.f;
-        s = 0.f;
-    } else if (p == 0.f) {
-        c = 0.f;
-        s = q < 0.f ? 1.f : -1.f;
-    } else if (fabsf(p) > fabsf(q)) {
-        float t = q / p;
-        float u = sqrtf(1.f + t * t);
-        if (p < 0.f) u = -u;
-        c = 1.f / u;
-        s = -t * c;
-    } else {
-        float t = p / q;
-        float u = sqrtf(1.f + t * t);
-        if (q < 0.f) u = -u;
-        s = -1.f / u;
-        c = -t * s;
-    }
-}
-
-__device__ __forceinline__ float eig_hypot(float x, float y)
-{
-    float ax = fabsf(x), ay = fabsf(y);
-    float p, qp;
-    if (ax > ay) {
-        p = ax;
-        qp = ay / p;
-    } else {
-        p = ay;
-        qp = ax / p;
-    }
-    if (p == 0.f) return 0.f;
-    return p * sqrtf(1.f + qp * qp);
-}
-
-__device__ void eig3_smallest(float a00, float a10, float a20, float a11, float a21, float a22, float normal[3],
-                              float evals[3])
-{
-    float scale = fmaxf(fmaxf(fmaxf(fabsf(a00), fabsf(a10)), fmaxf(fabsf(a20), fabsf(a11))),
-                        fmaxf(fabsf(a21), fabsf(a22)));
-    if (scale == 0.f) scale = 1.f;
-    a00 /= scale; a10 /= scale; a20 /= scale; a11 /= scale; a21 /= scale; a22 /= scale;
-    float d0, d1, d2, e0, e1;
-    float q00 = 1.f, q10 = 0.f, q20 = 0.f, q01 = 0.f, q11 = 1.f, q21 = 0.f, q02 = 0.f, q12 = 0.f, q22 = 1.f;
-    const float tiny = std::numeric_limits<float>::min();
-    d0 = a00;
-    float v1norm2 = a20 * a20;
-    if (v1norm2 <= tiny) {
-        d1 = a11; d2 = a22; e0 = a10; e1 = a21;
-    } else {
-        float beta = sqrtf(a10 * a10 + v1norm2);
-        float inv_beta = 1.f / beta;
-        float m01 = a10 * inv_beta, m02 = a20 * inv_beta;
-        float q = 2.f * m01 * a21 + m02 * (a22 - a11);
-        d1 = a11 + m02 * q;
-        d2 = a22 - m02 * q;
-        e0 = beta;
-        e1 = a21 - m01 * q;
-        q11 = m01; q21 = m02; q12 = m02; q22 = -m01;
-    }
-    // registers instead of arrays: diag = {d0,d1,d2}, sub = {e0,e1}, Q columns {q?0,q?1,q?2}
-    const float precision = 2.f * std::numeric_limits<float>::epsilon();
-    int end = 2, start = 0, iter = 0;
-    bool converged = true;
-    auto rot_cols01 = [&](float c, float s) {
-        float x, y;
-        x = q00; y = q01; q00 = c * x - s * y; q01 = s * x + c * y;
-        x = q10; y = q11; q10 = c * x - s * y; q11 = s * x + c * y;
-        x = q20; y = q21; q20 = c * x - s * y; q21 = s * x + c * y;
-    };
-    auto rot_cols12 = [&](float c, float s) {
-        float x, y;
-        x = q01; y = q02; q01 = c * x - s * y; q02 = s * x + c * y;
-        x = q11; y = q12; q11 = c * x - s * y; q12 = s * x + c * y;
-        x = q21; y = q22; q21 = c * x - s * y; q22 = s * x + c * y;
-    };
-    while (end > 0) {
-        if (start <= 0 && 0 < end)
-            if (fabsf(e0) <= (fabsf(d0) + fabsf(d1)) * precision || fabsf(e0) <= tiny) e0 = 0.f;
-        if (start <= 1 && 1 < end)
-            if (fabsf(e1) <= (fabsf(d1) + fabsf(d2)) * precision || fabsf(e1) <= tiny) e1 = 0.f;
-        while (end > 0 && (end == 2 ? e1 : e0) == 0.f) end--;
-        if (end <= 0) break;
-        iter++;
-        if (iter > 90) { converged = false; break; }
-        start = end - 1;
-        while (start > 0 && (start == 1 ? e0 : 0.f) != 0.f) start--;
-        // tridiagonal_qr_step(start, end)
-        float dem1 = end == 2 ? d1 : d0, de = end == 2 ? d2 : d1, ee = end == 2 ? e1 : e0;
-        float td = (dem1 - de) * 0.5f;
-        float mu = de;
-        if (td == 0.f) {
-            mu -= fabsf(ee);
-        } else {
-            float e2 = ee * ee;
-            float h = eig_hypot(td, ee);
-            if (e2 == 0.f) mu -= (ee / (td + (td > 0.f ? 1.f : -1.f))) * (ee / h);
-            else mu -= e2 / (td + (td > 0.f ? h : -h));
-        }
-        float x = (start == 0 ? d0 : d1) - mu;
-        float z = start == 0 ? e0 : e1;
-        for (int k = start; k < end; ++k) {
-            float c, s;
-            make_givens(x, z, c, s);
-            float dk = k == 0 ? d0 : d1, dk1 = k == 0 ? d1 : d2, sk = k == 0 ? e0 : e1;
-            float sdk = s * dk + c * sk;
-            float dkp1 = s * sk + c * dk1;
-            float ndk = c * (c * dk - s * sk) - s * (c * sk - s * dk1);
-            float ndk1 = s * sdk + c * dkp1;
-            float nsk = c * sdk - s * dkp1;
-            if (k == 0) { d0 = ndk; d1 = ndk1; e0 = nsk; }
-            else { d1 = ndk; d2 = ndk1; e1 = nsk; }
-            if (k > start) e0 = c * e0 - s * z;  // k == 1, start == 0: sub[k-1] = sub[0]
-            x = nsk;
-            if (k < end - 1) {  // k == 0, end == 2
-                z = -s * e1;
-                e1 = c * e1;
-            }
-            if (k == 0) rot_cols01(c, s);
-            else rot_cols12(c, s);
-        }
-    }
-    if (converged) {
-        // ascending selection sort (first minimum wins), swapping eigenvector columns
-        auto swap01 = [&]() {
-            float t;
-            t = d0; d0 = d1; d1 = t;
-            t = q00; q00 = q01; q01 = t; t = q10; q10 = q11; q11 = t; t = q20; q20 = q21; q21 = t;
-        };
-        auto swap02 = [&]() {
-            float t;
-            t = d0; d0 = d2; d2 = t;
-            t = q00; q00 = q02; q02 = t; t = q10; q10 = q12; q12 = t; t = q20; q20 = q22; q22 = t;
-        };
-        auto swap12 = [&]() {
-            float t;
-            t = d1; d1 = d2; d2 = t;
-            t = q01; q01 = q02; q02 = t; t = q11; q11 = q12; q12 = t; t = q21; q21 = q22; q22 = t;
-        };
-        int kmin = 0;
-        float mv = d0;
-        if (d1 < mv) { mv = d1; kmin = 1; }
-        if (d2 < mv) { mv = d2; kmin = 2; }
-        if (kmin == 1) swap01();
-        else if (kmin == 2) swap02();
-        if (d2 < d1) swap12();
-    }
-    float l0 = d0 * scale, l1 = d1 * scale, l2 = d2 * scale;
-    evals[0] = l0; evals[1] = l1; evals[2] = l2;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (l0 <= l1 && l0 <= l2) { nx = q00; ny = q10; nz = q20; }
-    if (l1 <= l0 && l1 <= l2) { nx = q01; ny = q11; nz = q21; }
-    if (l2 <= l0 && l2 <= l1) { nx = q02; ny = q12; nz = q22; }
-    normal[0] = nx; normal[1] = ny; normal[2] = nz;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,262 +676,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : PCPX
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
-// every point with d2 <= r*r, query included)
-// ------------------------------------------------------------------------------------------------
-template <bool SELF, bool FILL>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
-                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
-                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
-{
-    const u32 lane = threadIdx.x & 63u;
-    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
-    if (g >= group_end) return;
-    const u32 p = g * GROUP + lane;
-    const u32 nq = SELF ? t.n : qv.nq;
-    const bool valid = p < nq;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    u32 row = 0;
-    if (valid) {
-        if (SELF) {
-            const Leaf& lf = t.leaves[p / LEAF];
-            qx = lf.x[p % LEAF];
-            qy = lf.y[p % LEAF];
-            qz = lf.z[p % LEAF];
-            row = lf.id[p % LEAF];
-        } else {
-            qx = qv.qx[p];
-            qy = qv.qy[p];
-            qz = qv.qz[p];
-            row = qv.row[p];
-        }
-    }
-    float r = radius;
-    if (radii && valid) r = radii[row];
-    const float r2 = valid ? r * r : -1.f;  // sphere.hpp:34 radius * radius in float; -1: idle lane
-    u32 cnt = 0;
-    u64 wpos = (FILL && valid) ? offsets[row] : 0;
-    auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
-
-    Walker wk;
-    u32 leaf = 0, nexp = 0;
-    bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
-    if (!more) more = wk.next(t, need, leaf, nexp);
-    while (more) {
-        const Leaf lf = load_const(t.leaves + leaf);
-#pragma unroll
-        for (int j = 0; j < LEAF; ++j) {
-            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-            bool in = sq3(dx, dy, dz) <= r2;
-            if (FILL) {
-                if (in) out_idx[wpos + cnt] = lf.id[j];
-            }
-            cnt += in ? 1u : 0u;
-        }
-        more = wk.next(t, need, leaf, nexp);
-    }
-    if (valid && !FILL) out_cnt[row] = cnt;
-}
-
-// AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:
-// test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
-// (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
-template <bool FILL>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
-                                                    u32* __restrict__ out_cnt, const u64* __restrict__ offsets,
-                                                    u32* __restrict__ out_idx)
-{
-    const u32 lane = threadIdx.x & 63u;
-    const u32 g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
-    const u32 p = g * GROUP + lane;
-    const bool valid = p < nb;
-    // an idle lane gets an inverted box that contains and overlaps nothing
-    float b0 = 1.f, b1 = 1.f, b2 = 1.f, b3 = -1.f, b4 = -1.f, b5 = -1.f;
-    if (valid) {
-        b0 = boxes6[6ull * p]; b1 = boxes6[6ull * p + 1]; b2 = boxes6[6ull * p + 2];
-        b3 = boxes6[6ull * p + 3]; b4 = boxes6[6ull * p + 4]; b5 = boxes6[6ull * p + 5];
-    }
-    u32 cnt = 0;
-    u64 wpos = (FILL && valid) ? offsets[p] : 0;
-    auto need = [&](const NodeBox& n) {
-        bool o = (n.hi[0] >= b0) & (n.hi[1] >= b1) & (n.hi[2] >= b2) & (n.lo[0] <= b3) & (n.lo[1] <= b4) & (n.lo[2] <= b5);
-        return o & (n.poison == 0.f) & valid;
-    };
-    Walker wk;
-    u32 leaf = 0, nexp = 0;
-    bool more = wk.start(t, need, nexp);
-    if (!more) more = wk.next(t, need, leaf, nexp);
-    while (more) {
-        const Leaf lf = load_const(t.leaves + leaf);
-#pragma unroll
-        for (int j = 0; j < LEAF; ++j) {
-            float x = lf.x[j], y = lf.y[j], z = lf.z[j];
-            bool in = valid & (x >= b0) & (y >= b1) & (z >= b2) & (x <= b3) & (y <= b4) & (z <= b5);
-            if (FILL) {
-                if (in) out_idx[wpos + cnt] = lf.id[j];
-            }
-            cnt += in ? 1u : 0u;
-        }
-        more = wk.next(t, need, leaf, nexp);
-    }
-    if (valid && !FILL) out_cnt[p] = cnt;
-}
-
-// thread i handles neighbourhood row = rowmap ? rowmap[first+i] : first+i
-__global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, const u32* __restrict__ nbr,
-                                                 const u32* __restrict__ cnt, const u32* __restrict__ rowmap, u64 first,
-                                                 u64 count, u32 k, float* __restrict__ out, float* __restrict__ evals,
-                                                 float* __restrict__ centroids, float* __restrict__ meandist)
-{
-    u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
-    if (i >= count) return;
-    u64 row = rowmap ? rowmap[first + i] : first + i;
-    u32 n = cnt ? cnt[row] : k;
-    const u32* nb = nbr + row * k;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (u32 j = 0; j < n; ++j) {
-        u64 id = nb[j];
-        float x = xyz[3 * id], y = xyz[3 * id + 1], z = xyz[3 * id + 2];
-        if (j == 0) { sx = x; sy = y; sz = z; }
-        else { sx += x; sy += y; sz += z; }
-    }
-    float fn = static_cast<float>(n);
-    float mx = sx / fn, my = sy / fn, mz = sz / fn;
-    if (centroids) {  // center_of_geometry of the row: the tangent plane's point
-        centroids[3 * row] = mx;
-        centroids[3 * row + 1] = my;
-        centroids[3 * row + 2] = mz;
-    }
-    if (meandist) {  // average_distances_to_neighbors; the row belongs to indexed point `row` (self queries only)
-        const float qx = xyz[3 * row], qy = xyz[3 * row + 1], qz = xyz[3 * row + 2];
-        float sum = 0.f;
-        for (u32 j = 0; j < n; ++j) {
-            u64 id = nb[j];
-            float dx = xyz[3 * id] - qx, dy = xyz[3 * id + 1] - qy, dz = xyz[3 * id + 2] - qz;
-            sum += sqrtf(sq3(dx, dy, dz));
-        }
-        meandist[row] = sum / fn;
-    }
-    if (!out) return;
-    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
-    for (u32 j = 0; j < n; ++j) {
-        u64 id = nb[j];
-        float vx = xyz[3 * id] - mx, vy = xyz[3 * id + 1] - my, vz = xyz[3 * id + 2] - mz;
-        c00 += vx * vx;
-        c10 += vy * vx;
-        c11 += vy * vy;
-        c20 += vz * vx;
-        c21 += vz * vy;
-        c22 += vz * vz;
-    }
-    float nrm[3], ev[3];
-    eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
-    out[3 * row] = nrm[0];
-    out[3 * row + 1] = nrm[1];
-    out[3 * row + 2] = nrm[2];
-    if (evals) {
-        evals[3 * row] = ev[0];
-        evals[3 * row + 1] = ev[1];
-        evals[3 * row + 2] = ev[2];
-    }
-}
-
-// estimate_normal over an explicit point set (m x 3): a single thread, the set is tiny in practice
-__global__ void k_normal_single(const float* __restrict__ xyz, u64 m, float* __restrict__ out3)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (u64 j = 0; j < m; ++j) {
-        float x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
-        if (j == 0) { sx = x; sy = y; sz = z; }
-        else { sx += x; sy += y; sz += z; }
-    }
-    float fn = static_cast<float>(m);
-    float mx = sx / fn, my = sy / fn, mz = sz / fn;
-    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
-    for (u64 j = 0; j < m; ++j) {
-        float vx = xyz[3 * j] - mx, vy = xyz[3 * j + 1] - my, vz = xyz[3 * j + 2] - mz;
-        c00 += vx * vx; c10 += vy * vx; c11 += vy * vy; c20 += vz * vx; c21 += vz * vy; c22 += vz * vz;
-    }
-    float ev[3];
-    eig3_smallest(c00, c10, c20, c11, c21, c22, out3, ev);
-}
-
-// ------------------------------------------------------------------------------------------------
-// arbitrary query batches: Morton-sort the queries on the index's grid, seed each group at the
-// 64-point chunk where its first query would sit in the sorted cloud
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 spread21(u32 v)
-{
-    u64 x = v & 0x1FFFFFu;
-    x = (x | (x << 32)) & 0x001F00000000FFFFull;
-    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
-    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
-    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
-__device__ __forceinline__ u32 quant21(float v, float lo, float hi)
-{
-    float ext = hi - lo;
-    float t = ext > 0.f ? (v - lo) / ext : 0.f;
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    u32 q = static_cast<u32>(t * 2097152.f);
-    return q > 2097151u ? 2097151u : q;
-}
-
-__global__ __launch_bounds__(256) void k_query_codes(const float* __restrict__ q, u32 nq, const float* __restrict__ box6,
-                                                     u64* __restrict__ codes, u32* __restrict__ vals)
-{
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    float x = q[3ull * i], y = q[3ull * i + 1], z = q[3ull * i + 2];
-    codes[i] = (spread21(quant21(x, box6[0], box6[3])) << 2) | (spread21(quant21(y, box6[1], box6[4])) << 1) |
-               spread21(quant21(z, box6[2], box6[5]));
-    vals[i] = i;
-}
-
-__global__ __launch_bounds__(256) void k_query_gather(const float* __restrict__ q, const u32* __restrict__ order, u32 nq,
-                                                      float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz)
-{
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    u64 o = order[i];
-    qx[i] = q[3 * o];
-    qy[i] = q[3 * o + 1];
-    qz[i] = q[3 * o + 2];
-}
-
-__global__ __launch_bounds__(256) void k_query_seeds(const u64* __restrict__ qcodes, u32 nq, const u64* __restrict__ pcodes,
-                                                     u32 n, u32 nleaves, u32* __restrict__ seed, u32 ngroups)
-{
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups) return;
-    u32 mid = g * GROUP + GROUP / 2;
-    if (mid >= nq) mid = nq - 1;
-    u64 c = qcodes[mid] >> MORTON_SORT_FIRST_BIT;  // the codes are ordered by these bits only
-    u32 lo = 0, hi = n;  // lower_bound over the sorted point codes
-    while (lo < hi) {
-        u32 m = lo + ((hi - lo) >> 1);
-        if ((pcodes[m] >> MORTON_SORT_FIRST_BIT) < c) lo = m + 1;
-        else hi = m;
-    }
-    u32 chunk = lo / GROUP;
-    u32 s0 = chunk * LEAVES_PER_GROUP;
-    if (s0 >= nleaves) s0 = nleaves > LEAVES_PER_GROUP ? ((nleaves - 1) / LEAVES_PER_GROUP) * LEAVES_PER_GROUP : 0;
-    seed[g] = s0;
-}
-
-inline u32 grid_for_groups(u64 groups)
-{
-    u64 blocks = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    blocks = (blocks + 7) / 8 * 8;
-    return static_cast<u32>(blocks);
-}
-
-inline float sanitize_eps(float eps) { return eps > 0.f ? eps : 0.f; }  // eps <= 0 or NaN: nothing is "equal"
-
 // zeroed work-queue counters for one persistent launch (stream-ordered)
 int prepare_queue(Index& ix)
 {
@@ -1252,46 +699,6 @@ u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups
 }
 
 }  // namespace
-
-int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
-{
-    if (nq >= 0xFFFFFFFEull) {
-        set_error("pcpx: nq = %llu does not fit 32-bit rows", static_cast<unsigned long long>(nq));
-        return PCPX_ERR_UNSUPPORTED;
-    }
-    hipStream_t s = ix.stream;
-    ProfileScope prof(ix, PCPX_K_QUERY_PREP);
-    u32 n32 = static_cast<u32>(nq);
-    u64 ngroups = (nq + GROUP - 1) / GROUP;
-    size_t tb = 0;
-    int st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, nq, s);
-    if (st != PCPX_OK) return st;
-    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    size_t o_codes0 = 0, o_codes1 = o_codes0 + al(nq * 8), o_vals0 = o_codes1 + al(nq * 8), o_vals1 = o_vals0 + al(nq * 4),
-           o_qx = o_vals1 + al(nq * 4), o_qy = o_qx + al(nq * 4), o_qz = o_qy + al(nq * 4), o_seed = o_qz + al(nq * 4),
-           o_tmp = o_seed + al(ngroups * 4), total = o_tmp + al(tb);
-    if ((st = ensure_scratch(ix, total)) != PCPX_OK) return st;
-    char* base = static_cast<char*>(ix.d_scratch);
-    u64* codes0 = reinterpret_cast<u64*>(base + o_codes0);
-    u64* codes1 = reinterpret_cast<u64*>(base + o_codes1);
-    u32* vals0 = reinterpret_cast<u32*>(base + o_vals0);
-    u32* vals1 = reinterpret_cast<u32*>(base + o_vals1);
-    float* qx = reinterpret_cast<float*>(base + o_qx);
-    float* qy = reinterpret_cast<float*>(base + o_qy);
-    float* qz = reinterpret_cast<float*>(base + o_qz);
-    u32* seed = reinterpret_cast<u32*>(base + o_seed);
-    if (nq > 0) {
-        const float* d_box = reinterpret_cast<const float*>(ix.d_scalars + 8);
-        k_query_codes<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, n32, d_box, codes0, vals0);
-        if ((st = sort_pairs_u64(base + o_tmp, tb, codes0, codes1, vals0, vals1, nq, s, MORTON_SORT_FIRST_BIT)) != PCPX_OK) return st;
-        k_query_gather<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, vals1, n32, qx, qy, qz);
-        k_query_seeds<<<static_cast<u32>((ngroups + 255) / 256), 256, 0, s>>>(
-            codes1, n32, ix.sorted_codes(), static_cast<u32>(ix.n), ix.nleaves, seed, static_cast<u32>(ngroups));
-        PCPX_HIP(hipGetLastError());
-    }
-    qv = QueryView{qx, qy, qz, vals1, seed, n32};
-    return PCPX_OK;
-}
 
 template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, const KnnOutputs& o)
@@ -1438,67 +845,6 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
     k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
         ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), KnnOutputs{}, MultiPass{}, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
-}
-
-int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
-                       const float* d_radii, u32* d_out_cnt)
-{
-    if (group_count == 0) return PCPX_OK;
-    u32 grid = grid_for_groups(group_count);
-    u32 gf = static_cast<u32>(group_first), ge = static_cast<u32>(group_first + group_count);
-    ProfileScope prof(ix, PCPX_K_RANGE);
-    if (self)
-        k_range<true, false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
-    else
-        k_range<false, false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
-    return check_hip(hipGetLastError(), "k_range launch", __FILE__, __LINE__);
-}
-
-int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,
-                      u32* d_out_idx)
-{
-    u64 groups = (static_cast<u64>(qv.nq) + GROUP - 1) / GROUP;
-    if (groups == 0) return PCPX_OK;
-    ProfileScope prof(ix, PCPX_K_RANGE);
-    k_range<false, true><<<grid_for_groups(groups), 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
-                                                                           d_radii, nullptr, d_offsets, d_out_idx);
-    return check_hip(hipGetLastError(), "k_range fill launch", __FILE__, __LINE__);
-}
-
-int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt)
-{
-    if (nb == 0) return PCPX_OK;
-    u32 grid = static_cast<u32>((nb + 64 * WAVES_PER_BLOCK - 1) / (64 * WAVES_PER_BLOCK));
-    ProfileScope prof(ix, PCPX_K_RANGE);
-    k_range_aabb<false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), d_out_cnt, nullptr, nullptr);
-    return check_hip(hipGetLastError(), "k_range_aabb launch", __FILE__, __LINE__);
-}
-
-int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx)
-{
-    if (nb == 0) return PCPX_OK;
-    u32 grid = static_cast<u32>((nb + 64 * WAVES_PER_BLOCK - 1) / (64 * WAVES_PER_BLOCK));
-    ProfileScope prof(ix, PCPX_K_RANGE);
-    k_range_aabb<true><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), nullptr, d_offsets, d_out_idx);
-    return check_hip(hipGetLastError(), "k_range_aabb fill launch", __FILE__, __LINE__);
-}
-
-int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
-                   float* d_out, float* d_evals, float* d_centroids, float* d_meandist)
-{
-    if (count == 0) return PCPX_OK;
-    ProfileScope prof(ix, PCPX_K_NORMALS);
-    hipStream_t s = ix.stream;
-    const float* d_xyz = ix.d_xyz;
-    k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
-                                                                     d_evals, d_centroids, d_meandist);
-    return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);
-}
-
-int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s)
-{
-    k_normal_single<<<1, 64, 0, s>>>(d_xyz, m, d_out3);
-    return check_hip(hipGetLastError(), "k_normal_single launch", __FILE__, __LINE__);
 }
 
 }  // namespace pcpx

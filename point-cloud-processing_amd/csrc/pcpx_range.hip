@@ -1,0 +1,156 @@
+// pcpx_range.hip -- radius search kernels (sphere and axis-aligned box ranges) for gfx950: the same wave-uniform
+// walk as the kNN kernel (pcpx_device.h), one lane = one range, count or CSR fill.
+#include "pcpx_device.h"
+
+namespace pcpx {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
+// every point with d2 <= r*r, query included)
+// ------------------------------------------------------------------------------------------------
+template <bool SELF, bool FILL>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
+                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
+                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
+    if (g >= group_end) return;
+    const u32 p = g * GROUP + lane;
+    const u32 nq = SELF ? t.n : qv.nq;
+    const bool valid = p < nq;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    u32 row = 0;
+    if (valid) {
+        if (SELF) {
+            const Leaf& lf = t.leaves[p / LEAF];
+            qx = lf.x[p % LEAF];
+            qy = lf.y[p % LEAF];
+            qz = lf.z[p % LEAF];
+            row = lf.id[p % LEAF];
+        } else {
+            qx = qv.qx[p];
+            qy = qv.qy[p];
+            qz = qv.qz[p];
+            row = qv.row[p];
+        }
+    }
+    float r = radius;
+    if (radii && valid) r = radii[row];
+    const float r2 = valid ? r * r : -1.f;  // sphere.hpp:34 radius * radius in float; -1: idle lane
+    u32 cnt = 0;
+    u64 wpos = (FILL && valid) ? offsets[row] : 0;
+    auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
+
+    Walker wk;
+    u32 leaf = 0, nexp = 0;
+    bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
+    if (!more) more = wk.next(t, need, leaf, nexp);
+    while (more) {
+        const Leaf lf = load_const(t.leaves + leaf);
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+            bool in = sq3(dx, dy, dz) <= r2;
+            if (FILL) {
+                if (in) out_idx[wpos + cnt] = lf.id[j];
+            }
+            cnt += in ? 1u : 0u;
+        }
+        more = wk.next(t, need, leaf, nexp);
+    }
+    if (valid && !FILL) out_cnt[row] = cnt;
+}
+
+// AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:
+// test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
+// (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
+template <bool FILL>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t, const float* __restrict__ boxes6, u32 nb,
+                                                    u32* __restrict__ out_cnt, const u64* __restrict__ offsets,
+                                                    u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const u32 p = g * GROUP + lane;
+    const bool valid = p < nb;
+    // an idle lane gets an inverted box that contains and overlaps nothing
+    float b0 = 1.f, b1 = 1.f, b2 = 1.f, b3 = -1.f, b4 = -1.f, b5 = -1.f;
+    if (valid) {
+        b0 = boxes6[6ull * p]; b1 = boxes6[6ull * p + 1]; b2 = boxes6[6ull * p + 2];
+        b3 = boxes6[6ull * p + 3]; b4 = boxes6[6ull * p + 4]; b5 = boxes6[6ull * p + 5];
+    }
+    u32 cnt = 0;
+    u64 wpos = (FILL && valid) ? offsets[p] : 0;
+    auto need = [&](const NodeBox& n) {
+        bool o = (n.hi[0] >= b0) & (n.hi[1] >= b1) & (n.hi[2] >= b2) & (n.lo[0] <= b3) & (n.lo[1] <= b4) & (n.lo[2] <= b5);
+        return o & (n.poison == 0.f) & valid;
+    };
+    Walker wk;
+    u32 leaf = 0, nexp = 0;
+    bool more = wk.start(t, need, nexp);
+    if (!more) more = wk.next(t, need, leaf, nexp);
+    while (more) {
+        const Leaf lf = load_const(t.leaves + leaf);
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float x = lf.x[j], y = lf.y[j], z = lf.z[j];
+            bool in = valid & (x >= b0) & (y >= b1) & (z >= b2) & (x <= b3) & (y <= b4) & (z <= b5);
+            if (FILL) {
+                if (in) out_idx[wpos + cnt] = lf.id[j];
+            }
+            cnt += in ? 1u : 0u;
+        }
+        more = wk.next(t, need, leaf, nexp);
+    }
+    if (valid && !FILL) out_cnt[p] = cnt;
+}
+
+}  // namespace
+
+int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
+                       const float* d_radii, u32* d_out_cnt)
+{
+    if (group_count == 0) return PCPX_OK;
+    u32 grid = grid_for_groups(group_count);
+    u32 gf = static_cast<u32>(group_first), ge = static_cast<u32>(group_first + group_count);
+    ProfileScope prof(ix, PCPX_K_RANGE);
+    if (self)
+        k_range<true, false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
+    else
+        k_range<false, false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, gf, ge, radius, d_radii, d_out_cnt, nullptr, nullptr);
+    return check_hip(hipGetLastError(), "k_range launch", __FILE__, __LINE__);
+}
+
+int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,
+                      u32* d_out_idx)
+{
+    u64 groups = (static_cast<u64>(qv.nq) + GROUP - 1) / GROUP;
+    if (groups == 0) return PCPX_OK;
+    ProfileScope prof(ix, PCPX_K_RANGE);
+    k_range<false, true><<<grid_for_groups(groups), 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
+                                                                           d_radii, nullptr, d_offsets, d_out_idx);
+    return check_hip(hipGetLastError(), "k_range fill launch", __FILE__, __LINE__);
+}
+
+int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt)
+{
+    if (nb == 0) return PCPX_OK;
+    u32 grid = static_cast<u32>((nb + 64 * WAVES_PER_BLOCK - 1) / (64 * WAVES_PER_BLOCK));
+    ProfileScope prof(ix, PCPX_K_RANGE);
+    k_range_aabb<false><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), d_out_cnt, nullptr, nullptr);
+    return check_hip(hipGetLastError(), "k_range_aabb launch", __FILE__, __LINE__);
+}
+
+int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx)
+{
+    if (nb == 0) return PCPX_OK;
+    u32 grid = static_cast<u32>((nb + 64 * WAVES_PER_BLOCK - 1) / (64 * WAVES_PER_BLOCK));
+    ProfileScope prof(ix, PCPX_K_RANGE);
+    k_range_aabb<true><<<grid, 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), d_boxes6, static_cast<u32>(nb), nullptr, d_offsets, d_out_idx);
+    return check_hip(hipGetLastError(), "k_range_aabb fill launch", __FILE__, __LINE__);
+}
+
+}  // namespace pcpx

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/kres2.sh file.hip [pattern]  -- per-kernel register/scratch/occupancy summary
+# usage: tools/kres2.sh point-cloud-processing_amd/csrc/pcpx_query.hip [pattern]  -- per-kernel register/scratch/occupancy summary
 f=$1; pat=${2:-.}
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -I/root/repo/include -c "$f" -o /tmp/kres2.o -Rpass-analysis=kernel-resource-usage > /tmp/kres2.log 2>&1
 python3 - "$pat" <<'PY'
