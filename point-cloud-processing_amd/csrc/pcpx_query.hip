@@ -15,7 +15,7 @@
 //     new keys in registers (bitonic network whose compare-exchange is v_min_f64 / v_max_f64: every key
 //     is the bit pattern of a finite non-negative double) and merges them with the best-list, which
 //     tightens tau = d2 of the k-th best.
-//   * Walk rounds: the first walk searches no farther than 1.25 x the wave's median seeded tau; a lane
+//   * Walk rounds: the first walk searches no farther than 1.375 x the wave's median seeded tau; a lane
 //     whose k-th distance ends up beyond that cap goes round again with a 4x larger one (shell accept).
 //   * Persistent waves pull query groups from 8 work queues (one per XCD-sized eighth of the Morton order).
 //   * The search is seeded with the 64 points of the query group itself (for arbitrary queries: the
@@ -253,7 +253,7 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 // 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
 // The cap only steers the work, never the result (a lane that fails the cap goes round again).
 #ifndef PCPX_CAP_MULT
-#define PCPX_CAP_MULT 1.25f  // measured, 10 M points, Mq/s uniform / clustered: 4: 1022 / 891, 2: 1048 / 957, 1.5: 1062 / 958, 1.25: 1079 / 960, 1: 1097 / 943
+#define PCPX_CAP_MULT 1.375f  // measured, 10 M points, 2 extra seed leaves, Mq/s uniform / clustered: 1: 1131 / 960, 1.25: 1175 / 1035, 1.375: 1168 / 1053, 1.5: 1164 / 1057, 1.75: 1156 / 1063
 #endif
 #ifndef PCPX_CAP_GROW
 #define PCPX_CAP_GROW 4.f  // radius^2 growth per further round
@@ -352,6 +352,15 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     else s0 = qv.seed[g];
     s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
     if (s0 > s1) s0 = s1;
+#ifndef PCPX_SEED_EXTRA
+#define PCPX_SEED_EXTRA 2  // leaves before and after the group's own chunk that are also processed before the walk: they are
+                           // Morton neighbours the walk would visit anyway, and seeing them first tightens tau sooner
+                           // (Mq/s uniform / clustered, cap x1.25: 0: 1144 / 1014, 1: 1160 / 1035, 2: 1174 / 1032, 4: 1173 / 1030, 8: 1155 / 1005)
+#endif
+    if (PCPX_SEED_EXTRA > 0) {
+        s0 = s0 > PCPX_SEED_EXTRA ? s0 - PCPX_SEED_EXTRA : 0u;
+        s1 = s1 + PCPX_SEED_EXTRA < t.nleaves ? s1 + PCPX_SEED_EXTRA : t.nleaves;
+    }
 
     // Single loop, single back-edge: each iteration fetches the next leaf (seed chunk first, then the
     // tree walk), runs the one compaction site if needed, then the one candidate site.
@@ -359,7 +368,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     wk.pend = 0;
     wk.ploc = 0;
     wk.l = 0;
-    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = PCPX_CAP_MULT (1.25) x the
+    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = PCPX_CAP_MULT (1.375) x the
     // wave's median seeded tau: a lane whose 64-point seed chunk lies across a Morton-curve jump starts with a
     // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
     // 7 ms groups against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all
