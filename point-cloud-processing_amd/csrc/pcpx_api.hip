@@ -688,7 +688,18 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_sta
     const size_t cap = 16 + 5 * 65536;  // 16 counters + 5-word records of up to 65536 persistent waves
     if ((st = ds.alloc(cap * sizeof(u64))) != PCPX_OK) return st;
     PCPX_HIP(hipMemsetAsync(ds.p, 0, cap * sizeof(u64), ix->stream));
-    if ((st = launch_knn_stats(*ix, k, eps, ds.as<unsigned long long>())) != PCPX_OK) return st;
+    // capacity bit 63 set: "floor" mode -- start every lane from its true k-th distance (taken from a normal run first)
+    const bool floor_mode = (capacity >> 63) != 0;
+    capacity &= ~(1ull << 63);
+    DevBuf known;
+    if (floor_mode) {
+        if ((st = known.alloc(static_cast<size_t>(ix->n_in) * k * sizeof(float))) != PCPX_OK) return st;
+        QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+        KnnOutputs o;
+        o.d2 = known.as<float>();
+        if ((st = launch_knn(*ix, qv, true, 0, (ix->n + GROUP - 1) / GROUP, k, eps, o)) != PCPX_OK) return st;
+    }
+    if ((st = launch_knn_stats(*ix, k, eps, ds.as<unsigned long long>(), floor_mode ? known.as<float>() : nullptr)) != PCPX_OK) return st;
     const size_t ncopy = capacity < cap ? capacity : cap;
     PCPX_HIP(hipMemcpyAsync(out_stats, ds.p, ncopy * sizeof(u64), hipMemcpyDeviceToHost, ix->stream));
     PCPX_HIP(hipStreamSynchronize(ix->stream));

@@ -176,7 +176,7 @@ int ensure_scratch(Index& ix, size_t bytes);
 // kNN + whatever per-neighbourhood products are requested (any pointer may be nullptr); all fused in k_knn
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
                const KnnOutputs& o);
-int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats);
+int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, const float* d_known_d2 = nullptr);
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
                        const float* d_radii, u32* d_out_cnt);
 int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,

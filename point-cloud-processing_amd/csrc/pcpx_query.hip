@@ -338,6 +338,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     for (int j = 0; j < KCAP; ++j) best[j] = (j < KCAP - static_cast<int>(k)) ? 0ull : PAD_KEY;
     const float inf = std::numeric_limits<float>::infinity();
     float tau = valid ? inf : -1.f;  // -1: an idle lane never accepts a candidate nor needs a node
+    // diagnostic build only: o.d2 holds the FINAL rows of an earlier run; starting from the true k-th distance
+    // measures how much of the walk is spent before tau has tightened (the floor any visiting order can reach)
+    float tau_known = inf;
+    if (STATS && o.d2 && valid && SELF) tau_known = o.d2[static_cast<u64>(t.leaves[p / LEAF].id[p % LEAF]) * k + (k - 1)];
     bool active = valid;             // lanes still searching (the second walk round keeps only the failed ones)
     int cnt = 0;
     const u32 col_addr = lds_address(col);  // byte address of row 0 of this lane's column
@@ -406,6 +410,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
+            if (STATS) tau = fminf(tau, tau_known);
             wa = col_addr + (static_cast<u32>(cnt) << 9);
             if (STATS) {
                 ++st_compact;
@@ -561,7 +566,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             u64 key = best[s];
             bool ok = key != PAD_KEY;
             if (o.idx) o.idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
-            if (o.d2) o.d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
+            if (o.d2 && !STATS) o.d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
             found += ok ? 1u : 0u;
             okmask |= ok ? (1u << s) : 0u;
         }
@@ -841,7 +846,7 @@ int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 g
 }
 
 // instrumented self-kNN (k <= 16): traversal statistics summed over all waves into d_stats[8]
-int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
+int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, const float* d_known_d2)
 {
     constexpr int KCAP = 16, BUF = buf_rows(KCAP);
     u64 groups = (ix.n + GROUP - 1) / GROUP;
@@ -852,7 +857,8 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats)
     if (st != PCPX_OK) return st;
     u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WAVES_PER_BLOCK, lds, groups);
     k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), KnnOutputs{}, MultiPass{}, ix.d_queue, d_stats);
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps),
+        KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 

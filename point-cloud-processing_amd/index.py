@@ -236,10 +236,11 @@ class Index:
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 
-    def debug_knn_stats(self, k, eps=1e-5, want_waves=False):
+    def debug_knn_stats(self, k, eps=1e-5, want_waves=False, floor=False):
+        """floor=True: every lane starts from its true k-th distance (what a perfect visiting order could reach)."""
         cap = 16 + 5 * 65536
         out = (C.c_uint64 * cap)()
-        check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out, cap))
+        check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out, cap | ((1 << 63) if floor else 0)))
         names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves", "second_round_groups",
                  "cycles_walk", "cycles_compact", "cycles_leaf", "cycles_search_loop", "cycles_group"]
         d = {n: int(out[i]) for i, n in enumerate(names)}

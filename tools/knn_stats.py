@@ -8,12 +8,13 @@ kind = sys.argv[2] if len(sys.argv) > 2 else "uniform"
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 pts = pkg.synthetic.uniform_cloud(n, 43) if kind == "uniform" else pkg.synthetic.clustered_cloud(n, 44)
 ix = pkg.Index(pts)
-st = ix.debug_knn_stats(k)
+floor = len(sys.argv) > 4 and sys.argv[4] == "floor"
+st = ix.debug_knn_stats(k, floor=floor)
 w = st["waves"]
 tot = max(1, st["cycles_group"])
 phases = {a[7:]: round(st[a] / tot, 4) for a in st if a.startswith("cycles_") and a != "cycles_group"}
 phases["epilogue"] = round(1.0 - st["cycles_search_loop"] / tot, 4)
 phases["seed_cap_control"] = round((st["cycles_search_loop"] - st["cycles_walk"] - st["cycles_compact"] - st["cycles_leaf"]) / tot, 4)
-print(json.dumps({"n": n, "kind": kind, "k": k, **st, "per_group": {a: round(st[a] / w, 2) for a in st if a != "waves"},
+print(json.dumps({"n": n, "kind": kind, "k": k, "floor_mode": floor, **st, "per_group": {a: round(st[a] / w, 2) for a in st if a != "waves"},
                   "appended_per_query": round(st["appended"] / n, 2),
                   "share_of_group_cycles (diagnostic build, wave-resident time incl. waiting for the other waves)": phases}))
