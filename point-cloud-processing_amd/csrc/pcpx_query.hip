@@ -303,7 +303,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
-    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0;
+    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0;
     // [7] shader cycles in the walker (pop + node expansions), [8] in compactions, [9] in leaf candidates,
     // [10] in the whole search loop, [11] whole group incl. the epilogue (id gather, tie repair, stores, fused normal)
     unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0;
@@ -414,6 +414,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             wa = col_addr + (static_cast<u32>(cnt) << 9);
             if (STATS) {
                 ++st_compact;
+                if (!walking) ++st_seed_compact;
                 // the clock read must not be scheduled ahead of the merge network: make it depend on tau
                 asm volatile("" ::"v"(tau));
                 tc_compact += __builtin_amdgcn_s_memtime() - tc_mark;
@@ -472,6 +473,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             // drained: seed chunk -> capped tree walk -> (rarely) uncapped walk of the failed lanes -> finished
             if (!walking) {
                 walking = true;
+                if (STATS) st_seed_app = st_app;
                 cap = wave_radius_cap(tau, valid, lane);
                 tau = active ? fminf(tau, cap) : -1.f;
                 bool root_leaf = wk.start(t, need, st_expand);
@@ -506,13 +508,19 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     }
 
     if (STATS) {
-        u32 app = st_app;
+        if (!walking) st_seed_app = st_app;  // (a group whose walk never starts: everything was seed work)
+        u32 app = st_app, sapp = st_seed_app;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) app += __shfl_xor(app, off);
+        for (int off = 32; off > 0; off >>= 1) {
+            app += __shfl_xor(app, off);
+            sapp += __shfl_xor(sapp, off);
+        }
         if (lane == 0) {
             atomicAdd(&stats[0], static_cast<unsigned long long>(st_leaves));
             atomicAdd(&stats[1], static_cast<unsigned long long>(st_expand));
             atomicAdd(&stats[2], static_cast<unsigned long long>(st_compact));
+            atomicAdd(&stats[12], static_cast<unsigned long long>(st_seed_compact));
+            atomicAdd(&stats[13], static_cast<unsigned long long>(sapp));
             atomicAdd(&stats[3], static_cast<unsigned long long>(app));
             atomicAdd(&stats[4], 1ull);
             atomicAdd(&stats[5], static_cast<unsigned long long>(s1 - s0));
