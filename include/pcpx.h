@@ -161,6 +161,20 @@ int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint3
                                        const uint32_t* opt_knn_count, uint32_t k, float* normals,
                                        uint64_t* opt_out_reached);
 
+/* The same on the device, with the same result: a level-synchronous search in which every newly reached vertex
+ * is claimed by its earliest (frontier position, edge index) -- the order the reference's queue would have
+ * produced -- so the flips are bit-identical with the host form.  All arrays are device arrays; synchronises
+ * `stream` once per BFS level.  opt_out_levels (may be NULL) receives the depth of the search. */
+int pcpx_propagate_normal_orientations_dev(const float* d_xyz, uint64_t n, const uint32_t* d_knn_idx,
+                                           const uint32_t* d_opt_knn_count, uint32_t k, float* d_normals, int device,
+                                           void* stream, uint64_t* opt_out_reached, uint32_t* opt_out_levels);
+/* estimate_normals + propagate_normal_orientations of every indexed point in one call (examples/
+ * normals_estimation.cpp:86-117): fused kNN + PCA normals, then the device orientation pass over the rows, which
+ * never leave the GPU unless asked for (opt_out_idx n x k, opt_out_count n).  PCPX_ERR_UNSUPPORTED if points were
+ * dropped by an explicit voxel grid (they have no neighbourhood). */
+int pcpx_oriented_normals_knn_self(pcpx_index* idx, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
+                                   uint32_t* opt_out_count, uint64_t* opt_out_reached);
+
 /* estimate_normal over explicit neighbourhoods: row q = nbr_idx[q*k .. q*k+count[q]) indexes the
  * index's points.  opt_out_evals (nq x 3, ascending eigenvalues) may be NULL. */
 int pcpx_normals_from_knn(pcpx_index* idx, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq,

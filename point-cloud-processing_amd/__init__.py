@@ -5,7 +5,7 @@ package does not load it, using any compute entry point does and fails loudly if
 """
 from . import ply, synthetic  # noqa: F401
 from .index import (Index, LinkedKdTree, LinkedOctree, PcpxError, bounding_box, device_count,  # noqa: F401
-                    estimate_normal, estimate_normals, propagate_normal_orientations, shard_range)
+                    estimate_normal, estimate_normals, propagate_normal_orientations, propagate_normal_orientations_dev, shard_range)
 
 __all__ = ["Index", "LinkedOctree", "LinkedKdTree", "PcpxError", "bounding_box", "device_count", "estimate_normal",
-           "estimate_normals", "propagate_normal_orientations", "shard_range", "ply", "synthetic"]
+           "estimate_normals", "propagate_normal_orientations", "propagate_normal_orientations_dev", "shard_range", "ply", "synthetic"]

@@ -75,6 +75,9 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p]),
     "pcpx_propagate_normal_orientations": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                                      u64p]),
+    "pcpx_propagate_normal_orientations_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                         C.c_int, C.c_void_p, u64p, C.POINTER(C.c_uint32)]),
+    "pcpx_oriented_normals_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, u64p]),
     "pcpx_normals_from_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                         C.c_void_p]),
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),

@@ -774,6 +774,48 @@ int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint3
     return PCPX_OK;
 }
 
+int pcpx_propagate_normal_orientations_dev(const float* d_xyz, uint64_t n, const uint32_t* d_knn_idx,
+                                           const uint32_t* d_opt_knn_count, uint32_t k, float* d_normals, int device, void* stream,
+                                           uint64_t* opt_out_reached, uint32_t* opt_out_levels)
+{
+    int st = select_device(device);
+    if (st != PCPX_OK) return st;
+    if (n > 0 && (!d_xyz || !d_normals || (k > 0 && !d_knn_idx))) {
+        set_error("pcpx_propagate_normal_orientations_dev: null argument");
+        return PCPX_ERR_INVALID;
+    }
+    return orient_normals_device(d_xyz, n, d_knn_idx, d_opt_knn_count, k, d_normals, static_cast<hipStream_t>(stream),
+                                 opt_out_reached, opt_out_levels);
+}
+
+int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
+                                   uint32_t* opt_out_count, uint64_t* opt_out_reached)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!out_normals || k == 0) return PCPX_ERR_INVALID;
+    if (ix->n != ix->n_in) {
+        set_error("pcpx_oriented_normals_knn_self: %llu of %llu points lie outside the voxel grid and have no neighbourhood",
+                  static_cast<unsigned long long>(ix->n_in - ix->n), static_cast<unsigned long long>(ix->n_in));
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    const u64 rows = ix->n_in;
+    DevBuf dn, di, dc;
+    if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK || (st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK ||
+        (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK)
+        return st;
+    if ((st = pcpx_normals_knn_self_dev(h, k, eps, 0, UINT64_MAX, dn.as<float>(), di.as<u32>(), dc.as<u32>())) != PCPX_OK) return st;
+    if ((st = orient_normals_device(ix->d_xyz, rows, di.as<u32>(), dc.as<u32>(), k, dn.as<float>(), ix->stream, opt_out_reached,
+                                    nullptr)) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    if (opt_out_idx) PCPX_HIP(hipMemcpyAsync(opt_out_idx, di.p, rows * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    if (opt_out_count) PCPX_HIP(hipMemcpyAsync(opt_out_count, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
 int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
                           uint32_t* out_vals)
 {

@@ -172,6 +172,10 @@ int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, cons
                    hipStream_t s, int first_bit = 0);
 int ensure_scratch(Index& ix, size_t bytes);
 
+// orient.hip: propagate_normal_orientations on the device (rows, counts, coordinates, normals are device arrays)
+int orient_normals_device(const float* d_xyz, u64 n, const u32* d_nbr, const u32* d_cnt, u32 k, float* d_normals, hipStream_t s,
+                          u64* out_reached, u32* out_levels);
+
 // query.hip
 // kNN + whatever per-neighbourhood products are requested (any pointer may be nullptr); all fused in k_knn
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,

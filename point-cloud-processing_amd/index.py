@@ -179,6 +179,18 @@ class Index:
         check(self._lib.pcpx_normals_knn_self(self._h, k, eps, _vp(nrm), _vp(idx), _vp(cnt)))
         return (nrm, idx, cnt) if want_knn else nrm
 
+    def oriented_normals_knn_self(self, k, eps=1e-5, want_knn=False):
+        """estimate_normals followed by propagate_normal_orientations, both on the GPU (the rows stay there).
+        Returns normals (and rows, counts if want_knn) plus the number of points reached from the root."""
+        n = self.n_in
+        nrm = np.empty((n, 3), np.float32)
+        idx = np.empty((n, k), np.uint32) if want_knn else None
+        cnt = np.empty(n, np.uint32) if want_knn else None
+        reached = C.c_uint64(0)
+        check(self._lib.pcpx_oriented_normals_knn_self(self._h, k, eps, _vp(nrm), _vp(idx) if want_knn else None,
+                                                       _vp(cnt) if want_knn else None, C.byref(reached)))
+        return (nrm, idx, cnt, int(reached.value)) if want_knn else (nrm, int(reached.value))
+
     def tangent_planes_knn_self(self, k, eps=1e-5):
         """pcp::algorithm::estimate_tangent_planes: (centroids, normals) of every point's k-neighbourhood."""
         cen = np.empty((self.n_in, 3), np.float32)
@@ -300,6 +312,15 @@ def estimate_normals(tree, k, eps=1e-5):
     """pcp::algorithm::estimate_normals with knn_map = tree.nearest_neighbours(point, k): one normal
     per indexed point (examples/simple_example.cpp:83-99)."""
     return tree.normals_knn_self(k, eps)
+
+
+def propagate_normal_orientations_dev(d_xyz, n, d_knn_idx, d_knn_count, k, d_normals, device=0, stream=None):
+    """Device-pointer form (level-synchronous search on the GPU, same flips as the host form); returns
+    (vertices reached, BFS depth).  Normals are updated in place."""
+    reached, levels = C.c_uint64(0), C.c_uint32(0)
+    check(_capi.load().pcpx_propagate_normal_orientations_dev(d_xyz, n, d_knn_idx, d_knn_count, k, d_normals, device, stream,
+                                                              C.byref(reached), C.byref(levels)))
+    return int(reached.value), int(levels.value)
 
 
 def propagate_normal_orientations(points, knn_idx, normals, knn_count=None):

@@ -467,3 +467,55 @@ def test_orientation_rejects_bad_rows(pkg):
     rows = np.array([[1], [2], [3], [9]], np.uint32)
     with pytest.raises(pkg.PcpxError):
         pkg.propagate_normal_orientations(pts, rows, np.zeros((4, 3), np.float32))
+
+
+def _host_orientation(pkg, pts, k):
+    ix = pkg.Index(pts)
+    nrm, idx, cnt = ix.normals_knn_self(k, want_knn=True)
+    out, reached = pkg.propagate_normal_orientations(pts, idx, nrm, cnt)
+    return ix, nrm, idx, cnt, out, reached
+
+
+@pytest.mark.parametrize("case", ["bunny", "clustered", "uniform", "tiny"])
+def test_device_orientation_equals_the_sequential_search(pkg, bunny, case):
+    """The level-synchronous GPU search must reproduce the reference's queue order: bit-identical flips."""
+    pts, k = {"bunny": (bunny, 15), "clustered": (pkg.synthetic.clustered_cloud(50_000, seed=44), 9),
+              "uniform": (pkg.synthetic.uniform_cloud(200_000, 5), 15), "tiny": (pkg.synthetic.uniform_cloud(10, 3), 15)}[case]
+    ix, nrm, idx, cnt, host, host_reached = _host_orientation(pkg, pts, k)
+    dev, didx, dcnt, reached = ix.oriented_normals_knn_self(k, want_knn=True)
+    assert np.array_equal(didx, idx) and np.array_equal(dcnt, cnt)
+    assert reached == host_reached
+    assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
+    only_normals, reached2 = ix.oriented_normals_knn_self(k)
+    assert reached2 == reached and np.array_equal(only_normals.view(np.uint32), host.view(np.uint32))
+
+
+def test_device_orientation_on_a_disconnected_graph(pkg):
+    """Two far clusters, small k: the search cannot leave the root's cluster; the other normals stay as estimated."""
+    a = pkg.synthetic.uniform_cloud(3000, 1) * 0.1
+    b = pkg.synthetic.uniform_cloud(2000, 2) * 0.1 + np.float32(5.0)
+    pts = np.concatenate([a, b]).astype(np.float32)
+    ix, nrm, idx, cnt, host, host_reached = _host_orientation(pkg, pts, 6)
+    dev, reached = ix.oriented_normals_knn_self(6)
+    assert reached == host_reached and 0 < reached <= 2000  # the root (largest z) lies in cluster b
+    assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
+    assert np.array_equal(dev[:3000].view(np.uint32), nrm[:3000].view(np.uint32))
+
+
+def test_device_orientation_kat_and_bad_rows(pkg, kats):
+    torch = pytest.importorskip("torch")
+    c = kats["normal_orientation"]
+    pts = np.array(c["points"], np.float32)
+    ix = pkg.Index(pts, voxel_grid=c["voxel_grid"])
+    idx, cnt = ix.knn_self(c["k"])[:2]
+    dev = torch.device("cuda", 0)
+    d_pts, d_idx = torch.from_numpy(pts).to(dev), torch.from_numpy(idx.astype(np.int32)).to(dev)
+    d_cnt, d_nrm = torch.from_numpy(cnt.astype(np.int32)).to(dev), torch.tensor(c["normals"], dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    reached, levels = pkg.propagate_normal_orientations_dev(d_pts.data_ptr(), len(pts), d_idx.data_ptr(), d_cnt.data_ptr(), c["k"],
+                                                             d_nrm.data_ptr())
+    assert reached == len(pts) and levels >= 2
+    assert np.all(np.abs(d_nrm.cpu().numpy() - np.array(c["expected_normal"], np.float32)) < c["component_tolerance"])
+    d_bad = torch.full((len(pts), c["k"]), 99, dtype=torch.int32, device=dev)
+    with pytest.raises(pkg.PcpxError):
+        pkg.propagate_normal_orientations_dev(d_pts.data_ptr(), len(pts), d_bad.data_ptr(), d_cnt.data_ptr(), c["k"], d_nrm.data_ptr())
