@@ -10,9 +10,10 @@
 //
 // propagate_normal_orientations (:187-302) keeps the reference's signature and result: a breadth-first
 // propagation over the directed kNN graph.  The visit order decides which parent orients a vertex, so the
-// search itself runs on the host like the reference's; what the GPU contributes is the graph -- with a
-// pcp::gpu::knn_map_t / self_knn_map_t all neighbour rows come from ONE batched launch instead of one
-// tree query per vertex.
+// search runs on the host like the reference's for arbitrary callables; with a pcp::gpu::knn_map_t all
+// neighbour rows come from ONE batched launch instead of one tree query per vertex, and with a
+// self_knn_map_t (range = the container's own sequence, ids = positions) the whole pass runs on the GPU as
+// a level-synchronous search that reproduces the sequential visit order (csrc/pcpx_orient.hip).
 #ifndef PCP_ALGORITHM_ESTIMATE_NORMALS_HPP
 #define PCP_ALGORITHM_ESTIMATE_NORMALS_HPP
 
@@ -24,6 +25,7 @@
 #include "pcp/gpu/device_index.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <iterator>
 #include <stdexcept>
@@ -194,13 +196,41 @@ void propagate_normal_orientations(ForwardIter1 begin, ForwardIter1 end, IndexMa
     std::size_t const n = vertices.size();
     if (n == 0) return;
 
+    // ---- whole pass on the GPU when the range is the container's own sequence and ids are positions ----
+    if constexpr (gpu::is_self_knn_map<knn_type>::value)
+    {
+        if (n != knn_map.tree->size())
+            throw std::invalid_argument("self_knn_map: the range must be the container's own element sequence");
+        bool ids_are_positions = true;
+        for (std::size_t i = 0; i < n && ids_are_positions; ++i) ids_are_positions = static_cast<std::size_t>(index_map(vertices[i])) == i;
+        // the device search compares z of the indexed coordinates; point_map must describe the same points
+        if (ids_are_positions)
+        {
+            std::vector<float> nrm(3 * n);
+            for (std::size_t i = 0; i < n; ++i)
+            {
+                auto const nn = normal_map(vertices[i]);
+                nrm[3 * i] = static_cast<float>(nn.x());
+                nrm[3 * i + 1] = static_cast<float>(nn.y());
+                nrm[3 * i + 2] = static_cast<float>(nn.z());
+            }
+            std::vector<float> const before = nrm;
+            knn_map.tree->index().orient_normals_self(static_cast<std::uint32_t>(knn_map.k), knn_map.eps, nrm);
+            for (std::size_t i = 0; i < n; ++i)  // report what the search changed (the root's (0,0,1) and every flip)
+                if (nrm[3 * i] != before[3 * i] || nrm[3 * i + 1] != before[3 * i + 1] || nrm[3 * i + 2] != before[3 * i + 2] ||
+                    std::signbit(nrm[3 * i]) != std::signbit(before[3 * i]) || std::signbit(nrm[3 * i + 1]) != std::signbit(before[3 * i + 1]) ||
+                    std::signbit(nrm[3 * i + 2]) != std::signbit(before[3 * i + 2]))
+                    op(vertices[i], normal_type{static_cast<scalar_type>(nrm[3 * i]), static_cast<scalar_type>(nrm[3 * i + 1]),
+                                                static_cast<scalar_type>(nrm[3 * i + 2])});
+            return;
+        }
+    }
+
     // ---- the graph: out-edges of vertex i = ids of its neighbours, CSR ----
     std::vector<std::size_t> first(n + 1, 0);
     std::vector<std::size_t> target;
     if constexpr (gpu::is_self_knn_map<knn_type>::value)
     {
-        if (n != knn_map.tree->size())
-            throw std::invalid_argument("self_knn_map: the range must be the container's own element sequence");
         auto const rows = knn_map.tree->index().knn_self(static_cast<std::uint32_t>(knn_map.k), knn_map.eps, n);
         target.reserve(n * knn_map.k);
         for (std::size_t i = 0; i < n; ++i)

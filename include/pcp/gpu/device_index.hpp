@@ -157,6 +157,13 @@ class device_index_t
         if (rows) check(pcpx_mean_knn_distance_self(h_, k, eps, m.data()), "pcpx_mean_knn_distance_self");
         return m;
     }
+    // propagate_normal_orientations over the index's own kNN graph, all on the GPU; normals: rows x 3, in place
+    std::uint64_t orient_normals_self(std::uint32_t k, float eps, std::vector<float>& normals) const
+    {
+        std::uint64_t reached = 0;
+        if (!normals.empty()) check(pcpx_orient_normals_knn_self(h_, k, eps, normals.data(), &reached), "pcpx_orient_normals_knn_self");
+        return reached;
+    }
     std::vector<float> normals_from_knn(knn_result_t const& r) const
     {
         std::vector<float> nrm(r.count.size() * 3, 0.f);

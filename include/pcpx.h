@@ -175,6 +175,10 @@ int pcpx_propagate_normal_orientations_dev(const float* d_xyz, uint64_t n, const
 int pcpx_oriented_normals_knn_self(pcpx_index* idx, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
                                    uint32_t* opt_out_count, uint64_t* opt_out_reached);
 
+/* The orientation pass alone for normals the caller already has (host array n x 3, input order, updated in place):
+ * the k nearest neighbours of every indexed point are computed on the GPU and never copied out. */
+int pcpx_orient_normals_knn_self(pcpx_index* idx, uint32_t k, float eps, float* normals, uint64_t* opt_out_reached);
+
 /* estimate_normal over explicit neighbourhoods: row q = nbr_idx[q*k .. q*k+count[q]) indexes the
  * index's points.  opt_out_evals (nq x 3, ascending eigenvalues) may be NULL. */
 int pcpx_normals_from_knn(pcpx_index* idx, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq,

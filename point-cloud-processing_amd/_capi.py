@@ -77,6 +77,7 @@ SIGNATURES = {
                                                      u64p]),
     "pcpx_propagate_normal_orientations_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                                          C.c_int, C.c_void_p, u64p, C.POINTER(C.c_uint32)]),
+    "pcpx_orient_normals_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, u64p]),
     "pcpx_oriented_normals_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, u64p]),
     "pcpx_normals_from_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                         C.c_void_p]),

@@ -816,6 +816,32 @@ int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* 
     return PCPX_OK;
 }
 
+int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* normals, uint64_t* opt_out_reached)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    int st = use(ix);
+    if (st != PCPX_OK) return st;
+    if (!normals || k == 0) return PCPX_ERR_INVALID;
+    if (ix->n != ix->n_in) {
+        set_error("pcpx_orient_normals_knn_self: %llu of %llu points lie outside the voxel grid and have no neighbourhood",
+                  static_cast<unsigned long long>(ix->n_in - ix->n), static_cast<unsigned long long>(ix->n_in));
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    const u64 rows = ix->n_in;
+    DevBuf dn, di, dc;
+    if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK || (st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK ||
+        (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(dn.p, normals, rows * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    if ((st = pcpx_knn_self_dev(h, k, eps, 0, UINT64_MAX, di.as<u32>(), dc.as<u32>(), nullptr)) != PCPX_OK) return st;
+    if ((st = orient_normals_device(ix->d_xyz, rows, di.as<u32>(), dc.as<u32>(), k, dn.as<float>(), ix->stream, opt_out_reached,
+                                    nullptr)) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(normals, dn.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
 int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
                           uint32_t* out_vals)
 {

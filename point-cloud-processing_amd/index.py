@@ -191,6 +191,15 @@ class Index:
                                                        _vp(cnt) if want_knn else None, C.byref(reached)))
         return (nrm, idx, cnt, int(reached.value)) if want_knn else (nrm, int(reached.value))
 
+    def orient_normals_knn_self(self, normals, k, eps=1e-5):
+        """propagate_normal_orientations for normals the caller has (n x 3, input order); kNN graph built on the GPU."""
+        out = np.array(normals, dtype=np.float32, order="C", copy=True).reshape(-1, 3)
+        if out.shape[0] != self.n_in:
+            raise ValueError("normals must be n x 3")
+        reached = C.c_uint64(0)
+        check(self._lib.pcpx_orient_normals_knn_self(self._h, k, eps, _vp(out), C.byref(reached)))
+        return out, int(reached.value)
+
     def tangent_planes_knn_self(self, k, eps=1e-5):
         """pcp::algorithm::estimate_tangent_planes: (centroids, normals) of every point's k-neighbourhood."""
         cen = np.empty((self.n_in, 3), np.float32)

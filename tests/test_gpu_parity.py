@@ -519,3 +519,16 @@ def test_device_orientation_kat_and_bad_rows(pkg, kats):
     d_bad = torch.full((len(pts), c["k"]), 99, dtype=torch.int32, device=dev)
     with pytest.raises(pkg.PcpxError):
         pkg.propagate_normal_orientations_dev(d_pts.data_ptr(), len(pts), d_bad.data_ptr(), d_cnt.data_ptr(), c["k"], d_nrm.data_ptr())
+
+
+def test_orientation_of_caller_normals(pkg, bunny):
+    """pcpx_orient_normals_knn_self: arbitrary (here random unit) normals, graph built on the GPU."""
+    rng = np.random.default_rng(11)
+    nrm = rng.normal(size=bunny.shape).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    ix = pkg.Index(bunny)
+    idx, cnt = ix.knn_self(10)[:2]
+    host, host_reached = pkg.propagate_normal_orientations(bunny, idx, nrm, cnt)
+    dev, reached = ix.orient_normals_knn_self(nrm, 10)
+    assert reached == host_reached
+    assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
