@@ -164,7 +164,7 @@ int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint3
 /* The same on the device, with the same result: a level-synchronous search in which every newly reached vertex
  * is claimed by its earliest (frontier position, edge index) -- the order the reference's queue would have
  * produced -- so the flips are bit-identical with the host form.  All arrays are device arrays; synchronises
- * `stream` once per BFS level.  opt_out_levels (may be NULL) receives the depth of the search. */
+ * `stream` once per 8 BFS levels.  opt_out_levels (may be NULL) receives the depth of the search. */
 int pcpx_propagate_normal_orientations_dev(const float* d_xyz, uint64_t n, const uint32_t* d_knn_idx,
                                            const uint32_t* d_opt_knn_count, uint32_t k, float* d_normals, int device,
                                            void* stream, uint64_t* opt_out_reached, uint32_t* opt_out_levels);

@@ -86,10 +86,13 @@ __global__ void k_orient_start(const float* __restrict__ xyz, u32* __restrict__ 
     normals[3ull * r + 2] = 1.f;
 }
 
-__global__ __launch_bounds__(OB) void k_orient_claim(const u32* __restrict__ frontier, u32 fsize, const u32* __restrict__ nbr,
-                                                     const u32* __restrict__ cnt, u32 k, const u32* __restrict__ level,
-                                                     u64* __restrict__ claim)
+// The frontier size lives in device memory (fsize_dev): several levels are enqueued per host synchronisation, and a
+// level whose frontier turned out empty is a no-op.
+__global__ __launch_bounds__(OB) void k_orient_claim(const u32* __restrict__ frontier, const u32* __restrict__ fsize_dev,
+                                                     const u32* __restrict__ nbr, const u32* __restrict__ cnt, u32 k,
+                                                     const u32* __restrict__ level, u64* __restrict__ claim)
 {
+    const u32 fsize = *fsize_dev;
     for (u32 p = blockIdx.x * OB + threadIdx.x; p < fsize; p += gridDim.x * OB) {
         const u32 u = frontier[p];
         const u32 c = cnt ? cnt[u] : k;
@@ -101,11 +104,12 @@ __global__ __launch_bounds__(OB) void k_orient_claim(const u32* __restrict__ fro
     }
 }
 
-__global__ __launch_bounds__(OB) void k_orient_resolve(const u32* __restrict__ frontier, u32 fsize, const u32* __restrict__ nbr,
-                                                       const u32* __restrict__ cnt, u32 k, u32* __restrict__ level,
-                                                       const u64* __restrict__ claim, u32 next_level, float* __restrict__ normals,
-                                                       u32* __restrict__ wins)
+__global__ __launch_bounds__(OB) void k_orient_resolve(const u32* __restrict__ frontier, const u32* __restrict__ fsize_dev,
+                                                       const u32* __restrict__ nbr, const u32* __restrict__ cnt, u32 k,
+                                                       u32* __restrict__ level, const u64* __restrict__ claim, u32 next_level,
+                                                       float* __restrict__ normals, u32* __restrict__ wins)
 {
+    const u32 fsize = *fsize_dev;
     for (u32 p = blockIdx.x * OB + threadIdx.x; p < fsize; p += gridDim.x * OB) {
         const u32 u = frontier[p];
         const u32 c = cnt ? cnt[u] : k;
@@ -136,38 +140,47 @@ __global__ __launch_bounds__(OB) void k_orient_resolve(const u32* __restrict__ f
 }
 
 // ---- exclusive prefix sum of u32 (tile sums, one block over the tile sums, add back) --------------------
-__global__ __launch_bounds__(OB) void k_scan_tiles(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __restrict__ tile_sum)
+__global__ __launch_bounds__(OB) void k_scan_tiles(const u32* __restrict__ in, const u32* __restrict__ n_dev, u32* __restrict__ out,
+                                                   u32* __restrict__ tile_sum)
 {
     __shared__ u32 part[OB];
-    const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    u32 v[SCAN_ITEMS], s = 0;
+    const u32 n = *n_dev;
+    const u32 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform trip count
+        const u32 base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+        u32 v[SCAN_ITEMS], s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0u;
-        s += v[i];
-    }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < OB; off <<= 1) {  // Hillis-Steele over the 256 thread sums
-        u32 t = threadIdx.x >= static_cast<u32>(off) ? part[threadIdx.x - off] : 0u;
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            v[i] = base + i < n ? in[base + i] : 0u;
+            s += v[i];
+        }
+        part[threadIdx.x] = s;
         __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    u32 run = part[threadIdx.x] - s;  // exclusive
+        for (int off = 1; off < OB; off <<= 1) {  // Hillis-Steele over the 256 thread sums
+            u32 t = threadIdx.x >= static_cast<u32>(off) ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        u32 run = part[threadIdx.x] - s;  // exclusive
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            if (base + i < n) out[base + i] = run;
+            run += v[i];
+        }
+        if (threadIdx.x == OB - 1) tile_sum[tile] = part[OB - 1];
+        __syncthreads();
     }
-    if (threadIdx.x == OB - 1) tile_sum[blockIdx.x] = part[OB - 1];
 }
 
-// one block: exclusive scan of the tile sums in place; grand total to *total
-__global__ __launch_bounds__(OB) void k_scan_tile_sums(u32* __restrict__ tile_sum, u32 ntiles, u32* __restrict__ total)
+// one block: exclusive scan of the tile sums in place; the grand total is the next frontier's size.  Also keeps
+// the running totals of the search: counters[0] += vertices discovered, counters[1] += 1 for a non-empty level.
+__global__ __launch_bounds__(OB) void k_scan_tile_sums(u32* __restrict__ tile_sum, const u32* __restrict__ n_dev,
+                                                       u32* __restrict__ total, unsigned long long* __restrict__ counters)
 {
     __shared__ u32 part[OB];
     __shared__ u32 carry;
+    const u32 ntiles = (*n_dev + SCAN_TILE - 1) / SCAN_TILE;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (u32 base = 0; base < ntiles; base += OB) {
@@ -186,14 +199,20 @@ __global__ __launch_bounds__(OB) void k_scan_tile_sums(u32* __restrict__ tile_su
         if (threadIdx.x == 0) carry += part[OB - 1];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) {
+        *total = carry;
+        counters[0] += carry;
+        counters[1] += *n_dev > 0 ? 1ull : 0ull;
+    }
 }
 
-__global__ __launch_bounds__(OB) void k_orient_emit(const u32* __restrict__ frontier, u32 fsize, const u32* __restrict__ nbr,
-                                                    const u32* __restrict__ cnt, u32 k, const u32* __restrict__ level,
-                                                    const u64* __restrict__ claim, u32 next_level, const u32* __restrict__ offs,
-                                                    const u32* __restrict__ tile_sum, u32* __restrict__ next_frontier)
+__global__ __launch_bounds__(OB) void k_orient_emit(const u32* __restrict__ frontier, const u32* __restrict__ fsize_dev,
+                                                    const u32* __restrict__ nbr, const u32* __restrict__ cnt, u32 k,
+                                                    const u32* __restrict__ level, const u64* __restrict__ claim, u32 next_level,
+                                                    const u32* __restrict__ offs, const u32* __restrict__ tile_sum,
+                                                    u32* __restrict__ next_frontier)
 {
+    const u32 fsize = *fsize_dev;
     for (u32 p = blockIdx.x * OB + threadIdx.x; p < fsize; p += gridDim.x * OB) {
         const u32 u = frontier[p];
         const u32 c = cnt ? cnt[u] : k;
@@ -261,11 +280,11 @@ int orient_normals_device(const float* d_xyz, u64 n, const u32* d_nbr, const u32
     u32* wins = reinterpret_cast<u32*>(base + o_wins);
     u32* offs = reinterpret_cast<u32*>(base + o_offs);
     u32* tiles = reinterpret_cast<u32*>(base + o_tiles);
-    u32* scal = reinterpret_cast<u32*>(base + o_scal);  // [0] max z key, [1] root, [2] next frontier size, [3] bad rows
+    u32* scal = reinterpret_cast<u32*>(base + o_scal);  // [0] max z key, [1] root, [3] bad rows, [4..5] frontier sizes, [8..11] counters
 
     PCPX_HIP(hipMemsetAsync(claim, 0xFF, n * 8, s));
     PCPX_HIP(hipMemsetAsync(level, 0xFF, n * 4, s));
-    PCPX_HIP(hipMemsetAsync(scal, 0, 16, s));
+    PCPX_HIP(hipMemsetAsync(scal, 0, 64, s));
     PCPX_HIP(hipMemsetAsync(scal + 1, 0xFF, 4, s));
     k_orient_validate<<<blocks_for(n), OB, 0, s>>>(d_nbr, d_cnt, n, k, scal + 3);
     u32 bad = 0;
@@ -280,26 +299,37 @@ int orient_normals_device(const float* d_xyz, u64 n, const u32* d_nbr, const u32
     k_orient_start<<<1, 64, 0, s>>>(d_xyz, scal + 1, level, fr[0], d_normals);
     PCPX_HIP(hipGetLastError());
 
-    u32 fsize = 1, depth = 0;
-    u64 reached = 1;
-    int cur = 0;
-    while (fsize > 0) {
-        const u32 fb = blocks_for(fsize);
-        const u32 ft = (fsize + SCAN_TILE - 1) / SCAN_TILE;
-        k_orient_claim<<<fb, OB, 0, s>>>(fr[cur], fsize, d_nbr, d_cnt, k, level, claim);
-        k_orient_resolve<<<fb, OB, 0, s>>>(fr[cur], fsize, d_nbr, d_cnt, k, level, claim, depth + 1, d_normals, wins);
-        k_scan_tiles<<<ft, OB, 0, s>>>(wins, fsize, offs, tiles);
-        k_scan_tile_sums<<<1, OB, 0, s>>>(tiles, ft, scal + 2);
-        k_orient_emit<<<fb, OB, 0, s>>>(fr[cur], fsize, d_nbr, d_cnt, k, level, claim, depth + 1, offs, tiles, fr[cur ^ 1]);
+    // fs[0], fs[1]: frontier sizes of even / odd levels; counters: {vertices discovered, non-empty levels}
+    u32* fs = scal + 4;
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(scal + 8);
+    const u32 one = 1;
+    PCPX_HIP(hipMemcpyAsync(fs, &one, sizeof(u32), hipMemcpyHostToDevice, s));
+    const u32 grid = blocks_for(n, 2048);
+    constexpr u32 LEVELS_PER_SYNC = 8;  // an empty frontier makes the remaining levels of a batch no-ops
+    u32 depth = 0;
+    for (;;) {
+        for (u32 i = 0; i < LEVELS_PER_SYNC; ++i, ++depth) {
+            const int cur = depth & 1;
+            k_orient_claim<<<grid, OB, 0, s>>>(fr[cur], fs + cur, d_nbr, d_cnt, k, level, claim);
+            k_orient_resolve<<<grid, OB, 0, s>>>(fr[cur], fs + cur, d_nbr, d_cnt, k, level, claim, depth + 1, d_normals, wins);
+            k_scan_tiles<<<grid, OB, 0, s>>>(wins, fs + cur, offs, tiles);
+            k_scan_tile_sums<<<1, OB, 0, s>>>(tiles, fs + cur, fs + (cur ^ 1), counters);
+            k_orient_emit<<<grid, OB, 0, s>>>(fr[cur], fs + cur, d_nbr, d_cnt, k, level, claim, depth + 1, offs, tiles, fr[cur ^ 1]);
+        }
         u32 next = 0;
-        PCPX_HIP(hipMemcpyAsync(&next, scal + 2, sizeof(u32), hipMemcpyDeviceToHost, s));
+        PCPX_HIP(hipMemcpyAsync(&next, fs + (depth & 1), sizeof(u32), hipMemcpyDeviceToHost, s));
         PCPX_HIP(hipStreamSynchronize(s));
         PCPX_HIP(hipGetLastError());
-        fsize = next;
-        reached += next;
-        cur ^= 1;
-        ++depth;
+        if (next == 0) break;
+        if (depth > n32 + LEVELS_PER_SYNC) {  // cannot happen: every level settles at least one vertex
+            set_error("pcpx: orientation search did not terminate");
+            return PCPX_ERR_DEVICE;
+        }
     }
+    unsigned long long totals[2] = {0, 0};
+    PCPX_HIP(hipMemcpy(totals, counters, sizeof(totals), hipMemcpyDeviceToHost));
+    const u64 reached = 1 + totals[0];
+    depth = static_cast<u32>(totals[1]);
     if (out_reached) *out_reached = reached;
     if (out_levels) *out_levels = depth;
     return PCPX_OK;
