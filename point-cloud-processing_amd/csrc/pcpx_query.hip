@@ -173,18 +173,16 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
         for (int j = 0; j < 8; ++j) lo8[j] = nw[j];
         bitonic_sort<8>(lo8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) nw[j] = lo8[j];
-#pragma unroll
-        for (int j = 8; j < 16; ++j) nw[j] = PAD_KEY;
+        for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], lo8[j]);  // the other 8 would be min(., PAD)
     } else {
 #pragma unroll
         for (int j = 8; j < 16; ++j) nw[j] = j < BUF ? col[j * 64] : PAD_KEY;
         static_for<8, BUF>([&](auto J) { nw[J] = pad_from<J>(nw[J], cnt); });
         bitonic_sort<16>(nw);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
     }
     cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
     bitonic_merge<KCAP>(best);
 }
 
