@@ -99,7 +99,14 @@ def cpu_baseline(pts, k, budget_s=12.0):
                       "(capacity 32, depth 21), %d threads; octree build %.1f s not included" % (sample, n, k, n, threads, build_s)}
 
 
-def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profile):
+def _reduce(torch, dist, value, op, dev, rehearse):
+    """All-reduce one number over the ranks (RCCL on the device; CPU tensor over gloo in the one-GPU rehearsal)."""
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if rehearse else dev)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
+def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profile, rehearse=False):
     kind, n, seed, k = WORKLOADS[name]
     dev = torch.device("cuda", torch.cuda.current_device())
     pts = make_cloud(pkg, kind, n, seed)
@@ -114,7 +121,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     d_box = torch.empty(6, dtype=torch.float32, device=dev)
     capi.check(lib.pcpx_bounding_box_dev(d_pts.data_ptr() + 12 * lo, hi - lo, dev.index, stream, d_box.data_ptr()))
     torch.cuda.current_stream().synchronize()
-    d_box = mg.global_grid(d_box, dist, world)  # the one collective: 24 B per rank over RCCL
+    d_box = mg.global_grid(d_box.cpu() if rehearse else d_box, dist, world)  # the one collective: 24 B per rank over RCCL
     grid = d_box.cpu().numpy()
 
     torch.cuda.synchronize()
@@ -126,7 +133,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     first, count = mg.query_shard(n, rank, world)
 
     d_idx = torch.empty((n, k), dtype=torch.int32, device=dev)
-    d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)  # rows outside this rank's shard stay 0
     d_nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
 
     streaming = name in STREAMING
@@ -162,10 +169,10 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ix.profile_end() if want_profile else None
+    complete = int((d_cnt == k).sum().item())  # rows this rank filled with k neighbours
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = _reduce(torch, dist, elapsed, dist.ReduceOp.MAX, dev, rehearse)
+        complete = int(_reduce(torch, dist, complete, dist.ReduceOp.SUM, dev, rehearse))
 
     # rebuild cost (same grid), for the "incl. build" figure
     torch.cuda.synchronize()
@@ -190,7 +197,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
 
     res = {"n": n, "k": k, "elapsed": elapsed, "range_ms": range_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
            "mqps": n * steps / elapsed / 1e6, "first_build_ms": first_build_ms, "rebuild_ms": rebuild_ms,
-           "profile": prof, "shard": (first, count), "pts": pts,
+           "profile": prof, "shard": (first, count), "pts": pts, "complete": complete,
            "min_count": int(d_cnt.min().item()) if world == 1 else None}
     ix.close()
     return res
@@ -219,13 +226,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the pcpx hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # PCPX_BENCH_REHEARSE=1: run the N > 1 code path on ONE GPU (all ranks on device 0, collectives over gloo) --
+    # a functional rehearsal of sharding and reduction for tests, not a measurement
+    rehearse = os.environ.get("PCPX_BENCH_REHEARSE") == "1"
+    torch.cuda.set_device(0 if rehearse else local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
-    main_res = run_workload(pkg, torch, dist, args.workload, rank, world, args.steps, args.warmup, want_profile=True)
+    main_res = run_workload(pkg, torch, dist, args.workload, rank, world, args.steps, args.warmup, want_profile=True,
+                            rehearse=rehearse)
     n, k = main_res["n"], main_res["k"]
 
     extra = {"index_build_ms_first": round(main_res["first_build_ms"], 3),
@@ -234,6 +248,9 @@ def main():
              "shard_of_rank0": list(main_res["shard"])}
     if main_res["min_count"] is not None:
         extra["min_neighbours_found"] = main_res["min_count"]
+    extra["rows_with_k_neighbours_all_ranks"] = main_res["complete"]  # = points when the shards cover the cloud exactly once
+    if rehearse:
+        extra["rehearsal"] = "one GPU, gloo: functional check of the N > 1 path, not a measurement"
     if main_res.get("range_ms"):
         extra["config3_range_count_r0.01_ms"] = round(main_res["range_ms"], 3)
         extra["config3_range_count_r0.01_mqps"] = round(n / main_res["range_ms"] / 1e3, 1)
