@@ -282,6 +282,15 @@ def main():
                     roofline["hbm_measured_frac"] = round(roofline["traffic"] / avg_s / HBM_PEAK, 5)
             except Exception:
                 pass
+        model_file = os.path.join(ROOT, "profiles", "r01_valu_issue_model.json")
+        if os.path.exists(model_file) and world == 1:
+            try:
+                m = json.load(open(model_file))
+                if m.get("workload") == args.workload:  # the bound that matters: share of SIMD cycles spent issuing VALU
+                    roofline["valu_issue_frac_model"] = round(m["valu_issue_cycles_per_group_total"] * (q_per_launch / 64) /
+                                                              (avg_s * 2.4e9 * 1024), 3)
+            except Exception:
+                pass
         nl, nms = prof["normals"]
         if nl:
             extra["k_normals_avg_launch_ms"] = round(nms / nl, 4)

@@ -45,4 +45,5 @@ if os.path.exists(pmc):
             "k_knn_hbm_bytes_per_launch": int((2 * f + w) * 1024),
             "k_knn_hbm_bytes_per_launch_uncorrected": int((f + w) * 1024),
             "algorithmic_bytes_per_launch": 84 * 10_000_000}, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
+subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_issue_model.py"), tag], check=False)
 print("copied into", dst)
