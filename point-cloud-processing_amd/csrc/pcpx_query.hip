@@ -380,6 +380,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     float cap = inf;       // wave-uniform; inf = no cap
     float lo_d2 = -1.f;    // wave-uniform; second round accepts only d2 > lo_d2
     bool second_round = false;
+    u32 rounds = 0;
     u32 seedcur = s0;
     bool walking = false;
     bool running = true;
@@ -488,8 +489,12 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                     const NodeBox root = load_const(t.nodes);
                     const float ex = root.hi[0] - root.lo[0], ey = root.hi[1] - root.lo[1], ez = root.hi[2] - root.lo[2];
                     const float diag2 = sq3(ex, ey, ez);
-                    cap = cap * PCPX_CAP_GROW;
-                    if (!(cap < diag2 * 4.f)) cap = inf;  // covers the whole cloud from any query inside 2x its box: last round
+                    // next radius^2; the last round is uncapped: when the cap covers the whole cloud from any query inside
+                    // 2x its box, when it cannot grow (a cap of 0: more than half of the sampled lanes sit on >= k coincident
+                    // points and eps is 0), or after 12 rounds
+                    const float grown = cap * PCPX_CAP_GROW;
+                    ++rounds;
+                    cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
                     active = failed;
                     tau = active ? fminf(kth, cap) : -1.f;
                     cnt = 0;

@@ -532,3 +532,20 @@ def test_orientation_of_caller_normals(pkg, bunny):
     dev, reached = ix.orient_normals_knn_self(nrm, 10)
     assert reached == host_reached
     assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
+
+
+def test_zero_radius_cap_terminates(pkg, oracle):
+    """eps = 0 and many coincident points: most lanes of a wave have k neighbours at distance 0, so the first-round
+    radius cap of the wave is 0 and cannot grow by multiplication -- the lanes without enough duplicates must still
+    finish (found by tools/fuzz_parity.py: the kernel used to loop forever here)."""
+    rng = np.random.default_rng(4)
+    base = rng.random((300, 3), dtype=np.float32)
+    pts = np.concatenate([np.repeat(base, 20, axis=0), rng.random((1000, 3), dtype=np.float32)]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ix = pkg.Index(pts)
+    for k in (15, 19, 24):
+        idx, cnt = ix.knn_self(k, eps=0.0)[:2]
+        sel = rng.choice(len(pts), 400, replace=False)
+        oi, oc = oracle.knn_bruteforce(pts, pts[sel], k, eps=0.0, nthreads=8)[:2]
+        ok, why = knn_rows_equivalent(pts, pts[sel], idx[sel], cnt[sel], oi, oc)
+        assert ok, why
