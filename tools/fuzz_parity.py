@@ -66,6 +66,42 @@ while time.time() < t_end:
             orc = O.range_count_bruteforce(pts, pts[sel], r, nthreads=8)
             if not np.array_equal(rc[sel], orc):
                 raise AssertionError("range_count_self differs")
+        # sphere / box lists against a float32 numpy restatement of contains() (sphere.hpp:27-35: d2 <= r*r;
+        # axis_aligned_bounding_box.hpp:111-125: inclusive)
+        m = min(len(sel), 40)
+        centers = q[:m]
+        if r <= 1.0:
+            off, out = ix.range_sphere(centers, r)
+            r2 = np.float32(r) * np.float32(r)
+            for i in range(m):
+                d = pts - centers[i]
+                d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+                want = np.flatnonzero(d2 <= r2)
+                got = np.sort(out[int(off[i]):int(off[i + 1])])
+                if not np.array_equal(got, want):
+                    raise AssertionError("range_sphere list %d differs (%d vs %d)" % (i, len(got), len(want)))
+        half = np.abs(rng.standard_normal((m, 3)).astype(np.float32)) * np.float32(0.05 * max(1e-6, float(np.ptp(pts, 0).max())))
+        boxes = np.concatenate([centers - half, centers + half], axis=1).astype(np.float32)
+        off, out = ix.range_aabb(boxes)
+        for i in range(m):
+            inside = np.all((pts >= boxes[i, :3]) & (pts <= boxes[i, 3:]), axis=1)
+            got = np.sort(out[int(off[i]):int(off[i + 1])])
+            if not np.array_equal(got, np.flatnonzero(inside)):
+                raise AssertionError("range_aabb list %d differs" % i)
+        if n >= 3:  # tangent planes and mean neighbour distances for any k
+            cen, pn = ix.tangent_planes_knn_self(k, eps)
+            md = ix.mean_knn_distance_self(k, eps)
+            if not np.array_equal(cen[sel].view(np.uint32), O.centroids_from_knn(pts, idx[sel], cnt[sel]).view(np.uint32)):
+                raise AssertionError("centroids differ")
+            if not np.array_equal(md[sel].view(np.uint32), O.mean_dist_from_knn(pts, pts[sel], idx[sel], cnt[sel]).view(np.uint32)):
+                raise AssertionError("mean neighbour distances differ")
+        if n >= 2 and rng.random() < 0.5:  # device orientation == sequential search on the same rows
+            nrm0, idx0, cnt0 = ix.normals_knn_self(k, eps, want_knn=True)
+            nrm0 = np.nan_to_num(nrm0)
+            host, hreach = pkg.propagate_normal_orientations(pts, idx0, nrm0, cnt0)
+            dev, dreach = ix.orient_normals_knn_self(nrm0, k, eps)
+            if dreach != hreach or not np.array_equal(dev.view(np.uint32), host.view(np.uint32)):
+                raise AssertionError("device orientation differs from the sequential search")
         if k <= 32 and n >= 3:
             nrm = ix.normals_knn_self(k, eps)
             onrm = O.normals_from_knn(pts, idx[sel], cnt[sel])
