@@ -537,7 +537,7 @@ def test_orientation_of_caller_normals(pkg, bunny):
 def test_zero_radius_cap_terminates(pkg, oracle):
     """eps = 0 and many coincident points: most lanes of a wave have k neighbours at distance 0, so the first-round
     radius cap of the wave is 0 and cannot grow by multiplication -- the lanes without enough duplicates must still
-    finish (found by tools/fuzz_parity.py: the kernel used to loop forever here)."""
+    finish (found by tests/fuzz_parity.py: the kernel used to loop forever here)."""
     rng = np.random.default_rng(4)
     base = rng.random((300, 3), dtype=np.float32)
     pts = np.concatenate([np.repeat(base, 20, axis=0), rng.random((1000, 3), dtype=np.float32)]).astype(np.float32)
@@ -549,3 +549,11 @@ def test_zero_radius_cap_terminates(pkg, oracle):
         oi, oc = oracle.knn_bruteforce(pts, pts[sel], k, eps=0.0, nthreads=8)[:2]
         ok, why = knn_rows_equivalent(pts, pts[sel], idx[sel], cnt[sel], oi, oc)
         assert ok, why
+
+
+def test_short_randomised_parity_run():
+    """tests/fuzz_parity.py for a few seconds with a fixed seed (its long runs are done by hand: DESIGN.md section 2)."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "8", "99"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
