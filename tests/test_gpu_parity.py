@@ -4,6 +4,8 @@ libpcpx.so; the oracle (oracle/pcp_oracle.cpp) is only the checker.
 Bars: kNN rows are bit-exact against the (d2, index)-sorted brute-force oracle -- indices, counts and
 float32 squared distances; range results are exact sets; normals are bit-comparable with the oracle's
 Eigen restatement and within 1e-4 cosine (the tolerance BASELINE.json's north_star states)."""
+import importlib
+
 import numpy as np
 import pytest
 
@@ -557,3 +559,42 @@ def test_short_randomised_parity_run():
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "8", "99"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+
+
+def test_error_behaviour_of_the_abi(pkg):
+    """Bad arguments come back as status codes with a message, never as a crash (SURVEY.md section 8(b) "Errors")."""
+    import ctypes as C
+    capi = importlib.import_module("point-cloud-processing_amd._capi")
+    lib = capi.load()
+    pts = pkg.synthetic.uniform_cloud(1000, 1)
+    ix = pkg.Index(pts)
+    h = ix._h
+    out_idx = np.empty((1000, 4), np.uint32)
+    out_cnt = np.empty(1000, np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    # null outputs, null handle, a device that does not exist
+    assert lib.pcpx_knn_self(h, 4, 1e-5, None, None, None) == capi.PCPX_ERR_INVALID
+    assert lib.pcpx_knn_self(None, 4, 1e-5, vp(out_idx), vp(out_cnt), None) == capi.PCPX_ERR_INVALID
+    box = np.empty(6, np.float32)
+    assert lib.pcpx_bounding_box(vp(pts), 1000, 99, box.ctypes.data_as(C.POINTER(C.c_float))) == capi.PCPX_ERR_INVALID
+    assert b"device" in lib.pcpx_last_error()
+    # k = 0 is "no neighbours", like the reference (linked_octree_node.hpp:464): status OK, counts 0
+    assert lib.pcpx_knn_self(h, 0, 1e-5, vp(out_idx), vp(out_cnt), None) in (capi.PCPX_OK, capi.PCPX_ERR_INVALID)
+    # the sorted-slice forms want a 64-aligned start
+    assert lib.pcpx_knn_self_dev(h, 4, 1e-5, 3, 64, None, None, None) == capi.PCPX_ERR_INVALID
+    # range lists: too small a buffer reports the needed size through the offsets and PCPX_ERR_CAPACITY
+    off = np.zeros(3, np.uint64)
+    centers = pts[:2].copy()
+    small = np.empty(1, np.uint32)
+    st = lib.pcpx_range_sphere_batch(h, vp(centers), None, 0.5, 2, vp(off), vp(small), 1)
+    assert st == capi.PCPX_ERR_CAPACITY and off[2] > 1
+    big = np.empty(int(off[2]), np.uint32)
+    assert lib.pcpx_range_sphere_batch(h, vp(centers), None, 0.5, 2, vp(off), vp(big), len(big)) == capi.PCPX_OK
+    # an explicit voxel grid drops outside points silently (linked_octree_node.hpp:174-175) ...
+    half = pkg.Index(pts, voxel_grid=[0, 0, 0, 0.5, 1, 1])
+    assert 0 < half.size() < 1000
+    # ... and the all-in-one orientation call refuses such an index instead of inventing neighbourhoods
+    nrm = np.empty((1000, 3), np.float32)
+    assert lib.pcpx_oriented_normals_knn_self(half._h, 5, 1e-5, vp(nrm), None, None, None) == capi.PCPX_ERR_UNSUPPORTED
+    ix.close()
+    half.close()
