@@ -268,6 +268,34 @@ static void normal_scenarios()
             for (auto const& nn : normals) REQUIRE(pcp::common::are_vectors_equal(nn, expected));
         }
     }
+    // average distance to neighbours KAT (test/algorithm/average_distance_to_neighbors.cpp:7-83): mu = 16/12 d
+    {
+        float const d = 0.1f;
+        std::vector<point_t> pc = {{0.f, 0.f, 0.f}, {0.f, 0.f, d}, {0.f, 0.f, -d}, {1.f, 0.f, 0.f}, {1.f, d, 0.f}, {1.f, -d, 0.f},
+                                   {0.f, 1.f, 0.f}, {d, 1.f, 0.f}, {-d, 1.f, 0.f}, {0.f, 0.f, 1.f}, {d, 0.f, 1.f}, {-d, 0.f, 1.f}};
+        auto const cmap = [](point_t const& p) { return std::array<float, 3u>{p.x(), p.y(), p.z()}; };
+        pcp::basic_linked_kdtree_t<point_t, 3u, decltype(cmap)> kd{pc.begin(), pc.end(), cmap};
+        auto const knn2 = [&](point_t const& p) { return kd.nearest_neighbours(p, 2u); };
+        float const mu = pcp::algorithm::average_distance_to_neighbors(pc.begin(), pc.end(), point_map, knn2);
+        REQUIRE(pcp::common::floating_point_equals(mu, (16.f / 12.f) * d));
+    }
+    // kd bounding box KATs (test/common/aabb.cpp:7-186)
+    {
+        auto const cmap = [](point_t const& p) { return std::array<float, 3u>{p.x(), p.y(), p.z()}; };
+        std::vector<point_t> neg = {{-.1f, -.1f, -.1f}, {-.2f, -.2f, -.2f}, {-2.f, -2.f, -2.f}, {-2.2f, -2.2f, -2.2f}};
+        auto it = neg.begin();
+        auto const box = pcp::kd_bounding_box<float, 3u, decltype(cmap), decltype(it)>(neg.begin(), neg.end(), cmap);
+        REQUIRE(!box.contains({2.1f, 2.1f, 2.1f}));
+        REQUIRE(box.contains({-.1f, -.1f, -.1f}));
+        REQUIRE(!box.contains({0.f, 0.f, 0.f}));
+        auto const near1 = box.nearest_point_from({-3.f, -3.f, -3.f});
+        auto const near2 = box.nearest_point_from({0.f, 0.f, 0.f});
+        for (int a = 0; a < 3; ++a)
+        {
+            REQUIRE(pcp::common::floating_point_equals(near1[a], -2.2f));
+            REQUIRE(pcp::common::floating_point_equals(near2[a], -.1f));
+        }
+    }
     // point views and index elements as Element types (examples/simple_example.cpp, examples/normals_estimation.cpp)
     std::vector<pcp::point_view_t> views;
     for (auto& p : cloud) views.push_back(pcp::point_view_t{&p});

@@ -85,6 +85,29 @@ def kats():
             "points": [[-1., -1., -.1], [-.9, -1., .2], [.9, .9, .1], [1.1, 1.1, -.2], [1.1, 1.1, -.3]],
             "normals": [[0, 0, -1], [0, 0, 1], [0, 0, 1], [0, 0, -1], [0, 0, -1]], "k": 2,
             "expected_normal": [0, 0, 1], "component_tolerance": 1e-5},
+        "mean_neighbour_distance": {
+            "source": "test/algorithm/average_distance_to_neighbors.cpp:7-83 (4 clusters of 3 collinear points at spacing d = 0.1, "
+                      "k = 2 through a kd-tree; expected mu = 16/12 * d within 1e-5)",
+            "d": 0.1, "k": 2,
+            "points": [[0, 0, 0], [0, 0, .1], [0, 0, -.1], [1, 0, 0], [1, .1, 0], [1, -.1, 0],
+                       [0, 1, 0], [.1, 1, 0], [-.1, 1, 0], [0, 0, 1], [.1, 0, 1], [-.1, 0, 1]],
+            "expected_mean": 16.0 / 12.0 * 0.1, "tolerance": 1e-5},
+        "aabb": {
+            "source": "test/common/aabb.cpp:7-186 (kd_bounding_box of three small clouds; contains() is inclusive, "
+                      "nearest_point_from() clamps; 1e-5 per component)",
+            "cases": [
+                {"points": [[-.1, -.1, -.1], [-.2, -.2, -.2], [-2., -2., -2.], [-2.2, -2.2, -2.2]],
+                 "contains": [[[2.1, 2.1, 2.1], False], [[-.1, -.1, -.1], True], [[0, 0, 0], False]],
+                 "nearest": [[[-3, -3, -3], [-2.2, -2.2, -2.2]], [[0, 0, 0], [-.1, -.1, -.1]]]},
+                {"points": [[.1, .1, .1], [.2, .2, .2], [2., 2., 2.], [2.2, 2.2, 2.2]],
+                 "contains": [[[2.3, 2.3, 2.3], False], [[.1, .1, .1], True], [[0, 0, 0], False]],
+                 "nearest": [[[3, 3, 3], [2.2, 2.2, 2.2]], [[0, 0, 0], [.1, .1, .1]]]},
+                {"points": [[.1, .1, .1], [2.1, .3, .3], [2.3, 2.1, .5], [.3, 2.3, .7], [.5, .5, 2.1], [2.5, .7, 2.3], [2.7, 2.5, 2.5],
+                            [.7, 2.7, 2.7], [.2, .2, .2], [2.2, .4, .4], [2.4, 2.2, .6], [.4, 2.4, .8], [.6, .6, 2.2], [2.6, .8, 2.4],
+                            [2.8, 2.6, 2.6], [.8, 2.8, 2.8]],
+                 "contains": [[[2.1, -.1, 1.], False], [[.1, .4, .3], True], [[.1, .3, 3.], False], [[.1, .1, 2.8], True]],
+                 "nearest": [[[-1, .1, .1], [.1, .1, .1]], [[-1, .1, 4.], [.1, .1, 2.8]], [[2., -1.1, .1], [2., .1, .1]],
+                             [[-1, 4.1, -.1], [.1, 2.8, .1]]]}]},
         "eps": 1e-5,
     }
 

@@ -598,3 +598,26 @@ def test_error_behaviour_of_the_abi(pkg):
     assert lib.pcpx_oriented_normals_knn_self(half._h, 5, 1e-5, vp(nrm), None, None, None) == capi.PCPX_ERR_UNSUPPORTED
     ix.close()
     half.close()
+
+
+def test_aabb_and_mean_distance_kats(pkg, kats):
+    """test/common/aabb.cpp and test/algorithm/average_distance_to_neighbors.cpp through the ABI."""
+    tol = kats["eps"]
+    for case in kats["aabb"]["cases"]:
+        pts = np.array(case["points"], np.float32)
+        b = pkg.bounding_box(pts)
+        assert np.array_equal(b[:3], pts.min(0)) and np.array_equal(b[3:], pts.max(0))
+        ix = pkg.Index(pts)
+        assert np.array_equal(ix.bbox(), b)
+        # bounds are inclusive (axis_aligned_bounding_box.hpp:111-125): the box range over the bounding box is everything
+        assert len(ix.range_aabb(b[None, :])[1]) == len(pts)
+        for q, inside in case["contains"]:
+            q = np.array(q, np.float32)
+            assert bool(np.all((q >= b[:3]) & (q <= b[3:]))) == inside
+        for q, want in case["nearest"]:
+            assert np.all(np.abs(np.clip(np.array(q, np.float32), b[:3], b[3:]) - np.array(want, np.float32)) < tol)
+    c = kats["mean_neighbour_distance"]
+    pts = np.array(c["points"], np.float32)
+    means = pkg.Index(pts).mean_knn_distance_self(c["k"])
+    mu = np.float32(means.sum(dtype=np.float32) / np.float32(len(pts)))
+    assert abs(float(mu) - c["expected_mean"]) < c["tolerance"]

@@ -123,6 +123,31 @@ def test_bunny_orientation_golden(oracle, bunny, bunny_golden):
     assert (dots < -0.5).mean() < 0.01
 
 
+def test_aabb_kats(oracle, kats):
+    """test/common/aabb.cpp: box of the points, inclusive containment, clamp as the nearest point."""
+    tol = kats["eps"]
+    for case in kats["aabb"]["cases"]:
+        pts = np.array(case["points"], np.float32)
+        b = oracle.bbox(pts)
+        assert np.array_equal(b[:3], pts.min(0)) and np.array_equal(b[3:], pts.max(0))
+        for q, inside in case["contains"]:
+            q = np.array(q, np.float32)
+            assert bool(np.all((q >= b[:3]) & (q <= b[3:]))) == inside
+        for q, want in case["nearest"]:
+            got = np.clip(np.array(q, np.float32), b[:3], b[3:])
+            assert np.all(np.abs(got - np.array(want, np.float32)) < tol)
+
+
+def test_mean_neighbour_distance_kat(oracle, kats):
+    """test/algorithm/average_distance_to_neighbors.cpp through the restated kd-tree, octree and brute force."""
+    c = kats["mean_neighbour_distance"]
+    pts = np.array(c["points"], np.float32)
+    for idx, cnt in (oracle.KdTree(pts).knn(pts, c["k"]), oracle.Octree(pts).knn(pts, c["k"]), oracle.knn_bruteforce(pts, pts, c["k"])[:2]):
+        means = oracle.mean_dist_from_knn(pts, pts, idx, cnt)
+        mu = np.float32(means.sum(dtype=np.float32) / np.float32(len(pts)))
+        assert abs(float(mu) - c["expected_mean"]) < c["tolerance"]
+
+
 def test_bbox_matches_numpy(oracle):
     rng = np.random.default_rng(5)
     x = rng.normal(size=(1000, 3)).astype(np.float32)
