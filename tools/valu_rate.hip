@@ -106,6 +106,9 @@ KERNEL32(k_min3_u32, EACH8("v_min3_u32", "%8, %9"))
 KERNEL32(k_add_u32, EACH8("v_add_u32", "%8"))
 KERNEL32(k_lshl_add, EACH8("v_lshl_add_u32", "%8, %9"))
 
+KERNEL32(k_fmac_f32, EACH8("v_fmac_f32_e32", "%8"))
+KERNEL32(k_fma_f32, EACH8("v_fma_f32", "%8, %9"))
+KERNEL32(k_max_f32, EACH8("v_max_f32_e32", "%8"))
 KERNEL32(k_cmp_f32, REP8("v_cmp_le_f32 vcc, %0, %8\n"))
 KERNEL32(k_mov_b32, "v_mov_b32 %0, %8\nv_mov_b32 %1, %8\nv_mov_b32 %2, %8\nv_mov_b32 %3, %8\nv_mov_b32 %4, %8\nv_mov_b32 %5, "
                     "%8\nv_mov_b32 %6, %8\nv_mov_b32 %7, %8\n")
@@ -293,6 +296,7 @@ int main()
     const Case cases[] = {
         {"v_mul_f32", k_mul_f32, 32},       {"v_add_f32", k_add_f32, 32},       {"v_max3_f32", k_max3_f32, 32},
         {"v_med3_f32", k_med3_f32, 32},     {"v_cndmask_b32", k_cndmask, 32},   {"v_cmp_le_f32", k_cmp_f32, 32},
+        {"v_fmac_f32 (VOP2)", k_fmac_f32, 32}, {"v_fma_f32 (VOP3)", k_fma_f32, 32}, {"v_max_f32 (VOP2)", k_max_f32, 32},
         {"v_cndmask e64 sgpr", k_cndmask_sgpr, 32}, {"v_cndmask vcc set", k_cndmask_vcc_set, 32},
         {"v_cndmask fresh dst", k_cndmask_fresh_dst, 32},
         {"v_bfi_b32", k_bfi, 32}, {"v_or_b32", k_or, 32}, {"v_ashrrev_i32", k_ashr, 32}, {"v_min_u32", k_min_u32, 32},
