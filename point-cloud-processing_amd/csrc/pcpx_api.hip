@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -216,6 +217,7 @@ int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_b
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !xyz) return PCPX_ERR_INVALID;
     DevBuf staged;
     if (n > 0) {
@@ -232,6 +234,7 @@ int pcpx_index_rebuild_dev(pcpx_index* h, const float* d_xyz, uint64_t n, const 
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !d_xyz) return PCPX_ERR_INVALID;
     return build_index(*ix, d_xyz, n, params);
 }
@@ -255,6 +258,7 @@ int pcpx_index_synchronize(pcpx_index* h)
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     PCPX_HIP(hipStreamSynchronize(ix->stream));
     return PCPX_OK;
 }
@@ -294,6 +298,7 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (k == 0) return PCPX_OK;  // linked_octree_node.hpp:464: k == 0 -> {}
     if (!d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
     if (sorted_first % GROUP != 0) {
@@ -315,6 +320,7 @@ int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint3
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     if (k == 0) {
@@ -344,6 +350,7 @@ int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (k == 0 || nq == 0) return PCPX_OK;
     if (!d_q_xyz || !d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
     QueryView qv;
@@ -361,6 +368,7 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
     if (!q_xyz || !out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
     if (k == 0) {
@@ -389,6 +397,7 @@ int pcpx_range_count_self_dev(pcpx_index* h, float radius, uint64_t sorted_first
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!d_out_count) return PCPX_ERR_INVALID;
     if (sorted_first % GROUP != 0) {
         set_error("pcpx_range_count_self_dev: sorted_first must be a multiple of %d", GROUP);
@@ -405,6 +414,7 @@ int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_count) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dc;
@@ -421,6 +431,7 @@ int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
     if (!q_xyz || !out_count) return PCPX_ERR_INVALID;
     DevBuf dq, dc;
@@ -442,6 +453,7 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_offsets || (nq > 0 && !q_xyz)) return PCPX_ERR_INVALID;
     if (nq == 0) {
         out_offsets[0] = 0;
@@ -484,6 +496,7 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_offsets || (nb > 0 && !boxes6)) return PCPX_ERR_INVALID;
     if (nb == 0) {
         out_offsets[0] = 0;
@@ -520,6 +533,7 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!d_out_normals || k == 0) return PCPX_ERR_INVALID;
     if (sorted_first % GROUP != 0) {
         set_error("pcpx_normals_knn_self_dev: sorted_first must be a multiple of %d", GROUP);
@@ -549,6 +563,7 @@ int pcpx_neighbourhoods_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t 
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (k == 0 || (!d_opt_normals && !d_opt_centroids && !d_opt_mean_dist)) return PCPX_ERR_INVALID;
     if (sorted_first % GROUP != 0) {
         set_error("pcpx_neighbourhoods_self_dev: sorted_first must be a multiple of %d", GROUP);
@@ -575,6 +590,7 @@ int pcpx_tangent_planes_knn_self(pcpx_index* h, uint32_t k, float eps, float* ou
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_centroids || !out_normals || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dc, dn;
@@ -594,6 +610,7 @@ int pcpx_mean_knn_distance_self(pcpx_index* h, uint32_t k, float eps, float* out
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_mean_dist || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dm;
@@ -611,6 +628,7 @@ int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_norma
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dn, di, dc;
@@ -635,6 +653,7 @@ int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
     if (!nbr_idx || !count || !out_normals || k == 0) return PCPX_ERR_INVALID;
     for (u64 q = 0; q < nq; ++q) {
@@ -683,6 +702,7 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_sta
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_stats || capacity < 16 || k == 0 || k > 16) return PCPX_ERR_INVALID;
     DevBuf ds;
     const size_t cap = 16 + 5 * 65536;  // 16 counters + 5-word records of up to 65536 persistent waves
@@ -794,6 +814,7 @@ int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* 
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
     if (ix->n != ix->n_in) {
         set_error("pcpx_oriented_normals_knn_self: %llu of %llu points lie outside the voxel grid and have no neighbourhood",
@@ -821,6 +842,7 @@ int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* no
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!normals || k == 0) return PCPX_ERR_INVALID;
     if (ix->n != ix->n_in) {
         set_error("pcpx_orient_normals_knn_self: %llu of %llu points lie outside the voxel grid and have no neighbourhood",
@@ -872,6 +894,7 @@ int pcpx_profile_begin(pcpx_index* h)
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     for (auto& iv : ix->intervals) {
         (void)hipEventDestroy(iv.a);
         (void)hipEventDestroy(iv.b);
@@ -886,6 +909,7 @@ int pcpx_profile_end(pcpx_index* h, pcpx_profile* out)
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out) return PCPX_ERR_INVALID;
     ix->profiling = false;
     std::memset(out, 0, sizeof(*out));

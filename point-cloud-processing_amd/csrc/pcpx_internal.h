@@ -14,6 +14,8 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -90,6 +92,10 @@ struct QueryView {
 };
 
 struct Index {
+    // Entry points that take a handle hold this for their duration: the reference's containers are queried
+    // concurrently from PSTL worker threads (estimate_normals.hpp:92), and the handle's scratch buffers, work
+    // queue and stream are shared state.  Recursive: some entry points are built from others.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -13,6 +13,7 @@
 #include <execution>
 #include <iterator>
 #include <random>
+#include <thread>
 #include <vector>
 
 static int g_failures = 0;
@@ -295,6 +296,29 @@ static void normal_scenarios()
             REQUIRE(pcp::common::floating_point_equals(near1[a], -2.2f));
             REQUIRE(pcp::common::floating_point_equals(near2[a], -.1f));
         }
+    }
+    // queries are const and re-entrant in the reference (PSTL workers call nearest_neighbours concurrently,
+    // include/pcp/algorithm/estimate_normals.hpp:92): four host threads on one container must get what one gets
+    {
+        std::vector<std::vector<std::vector<point_t>>> per_thread(4);
+        std::vector<std::thread> workers;
+        for (int w = 0; w < 4; ++w)
+            workers.emplace_back([&, w]() {
+                for (std::size_t i = static_cast<std::size_t>(w); i < 120; i += 4)
+                {
+                    per_thread[static_cast<std::size_t>(w)].push_back(octree.nearest_neighbours(cloud[i], k, point_map));
+                    (void)octree.range_search(pcp::sphere_t<point_t>{cloud[i], 1.5f}, point_map);
+                }
+            });
+        for (auto& t : workers) t.join();
+        for (int w = 0; w < 4; ++w)
+            for (std::size_t j = 0; j < per_thread[static_cast<std::size_t>(w)].size(); ++j)
+            {
+                auto const expect = octree.nearest_neighbours(cloud[static_cast<std::size_t>(w) + 4 * j], k, point_map);
+                auto const& got   = per_thread[static_cast<std::size_t>(w)][j];
+                REQUIRE(got.size() == expect.size());
+                for (std::size_t a = 0; a < got.size(); ++a) REQUIRE(pcp::common::are_vectors_equal(got[a], expect[a]));
+            }
     }
     // point views and index elements as Element types (examples/simple_example.cpp, examples/normals_estimation.cpp)
     std::vector<pcp::point_view_t> views;
