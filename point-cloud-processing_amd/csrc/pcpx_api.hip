@@ -72,6 +72,21 @@ int select_device(int device)
     return PCPX_OK;
 }
 
+// extern "C" entry points that allocate host memory run their body through this: nothing may be thrown across the ABI
+template <class Body>
+int no_throw(const char* what, Body&& body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", what);
+        return PCPX_ERR_ALLOC;
+    } catch (...) {
+        set_error("%s: unexpected host exception", what);
+        return PCPX_ERR_INVALID;
+    }
+}
+
 int use(Index* ix)
 {
     if (!ix) {
@@ -450,6 +465,7 @@ int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float
 int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radii, float radius, uint64_t nq,
                             uint64_t* out_offsets, uint32_t* out_idx, uint64_t idx_capacity)
 {
+    return no_throw("pcpx_range_sphere_batch", [&]() -> int {
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
@@ -488,11 +504,13 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
     PCPX_HIP(hipMemcpyAsync(out_idx, dout.p, total * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
     PCPX_HIP(hipStreamSynchronize(ix->stream));
     return PCPX_OK;
+    });
 }
 
 int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint64_t* out_offsets, uint32_t* out_idx,
                           uint64_t idx_capacity)
 {
+    return no_throw("pcpx_range_aabb_batch", [&]() -> int {
     Index* ix = reinterpret_cast<Index*>(h);
     int st = use(ix);
     if (st != PCPX_OK) return st;
@@ -524,6 +542,7 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
     PCPX_HIP(hipMemcpyAsync(out_idx, dout.p, total * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
     PCPX_HIP(hipStreamSynchronize(ix->stream));
     return PCPX_OK;
+    });
 }
 
 // ---- normals -------------------------------------------------------------------------------------
@@ -729,6 +748,7 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_sta
 int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint32_t* knn_idx, const uint32_t* opt_knn_count,
                                        uint32_t k, float* normals, uint64_t* opt_out_reached)
 {
+    return no_throw("pcpx_propagate_normal_orientations", [&]() -> int {
     if (opt_out_reached) *opt_out_reached = 0;
     if (n == 0) return PCPX_OK;
     if (!xyz || !normals || (k > 0 && !knn_idx)) {
@@ -792,6 +812,7 @@ int pcpx_propagate_normal_orientations(const float* xyz, uint64_t n, const uint3
         *opt_out_reached = reached;
     }
     return PCPX_OK;
+    });
 }
 
 int pcpx_propagate_normal_orientations_dev(const float* d_xyz, uint64_t n, const uint32_t* d_knn_idx,
