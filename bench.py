@@ -45,6 +45,7 @@ WORKLOADS = {
     "uniform_10m_k15": ("uniform", 10_000_000, 43, 15),
     "uniform_1m_k15": ("uniform", 1_000_000, 42, 15),
     "clustered_10m_k15": ("clustered", 10_000_000, 44, 15),
+    "uniform_10m_k8": ("uniform", 10_000_000, 43, 8),
     "uniform_50m_k32_stream": ("uniform", 50_000_000, 45, 32),
     "uniform_10m_k32_stream": ("uniform", 10_000_000, 45, 32),
 }

@@ -126,7 +126,10 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 #ifndef PCPX_BUF32
 #define PCPX_BUF32 16
 #endif
-__host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 16 ? PCPX_BUF16 : PCPX_BUF32; }
+#ifndef PCPX_BUF8
+#define PCPX_BUF8 9    // k <= 8: 10 rows x 512 B = 5 KB per wave, 7 waves/SIMD (10 M uniform, k = 8, Mq/s: 12 rows/6 waves 1400, 10/7 1461, 9/7 1478, 8/7 1429, 8/8 925 (spills); the k <= 16 kernel does 1337)
+#endif
+__host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 8 ? PCPX_BUF8 : kcap <= 16 ? PCPX_BUF16 : PCPX_BUF32; }
 
 // Fold this lane's buffered keys (cnt <= BUF <= 16) into its sorted best-list.  All LDS traffic is
 // unconditional (stale slots are masked to PAD_KEY in registers): no exec games.  The new keys are sorted
@@ -162,7 +165,8 @@ __device__ __forceinline__ void static_for(F&& f)
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
-    static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 16, "rows");
+    static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 8, "rows");
+    constexpr int TOP = KCAP < 16 ? KCAP : 16;  // the KCAP smallest of best[] and the new keys are among the TOP smallest new ones
     u64 nw[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
@@ -180,7 +184,7 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
         static_for<8, BUF>([&](auto J) { nw[J] = pad_from<J>(nw[J], cnt); });
         bitonic_sort<16>(nw);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+        for (int j = 0; j < TOP; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
     }
     cnt = 0;
     bitonic_merge<KCAP>(best);
@@ -240,6 +244,9 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 // ------------------------------------------------------------------------------------------------
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
+#ifndef PCPX_MINW8
+#define PCPX_MINW8 7   // k <= 8 kernel: <= 72 VGPRs = 7 waves/SIMD
+#endif
 #ifndef PCPX_MINW32
 #define PCPX_MINW32 4  // k <= 32 kernel: <= 128 VGPRs = 4 waves/SIMD
 #endif
@@ -651,7 +658,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
 template <int KCAP, bool SELF, bool STATS, bool MULTI = false>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
     TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, KnnOutputs o, MultiPass mp,
     u32* __restrict__ queue, unsigned long long* __restrict__ stats)
 {
@@ -851,6 +858,7 @@ int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 g
 {
     if (group_count == 0) return PCPX_OK;
     eps = sanitize_eps(eps);
+    if (k <= 8) return launch_knn_t<8>(ix, qv, self, group_first, group_count, k, eps, o);
     if (k <= 16) return launch_knn_t<16>(ix, qv, self, group_first, group_count, k, eps, o);
     if (k <= 32) return launch_knn_t<32>(ix, qv, self, group_first, group_count, k, eps, o);
     return launch_knn_multipass(ix, qv, self, group_first, group_count, k, eps, o);
