@@ -15,6 +15,7 @@ cp("bench.json", "bench.json")
 cp("bench_under_rocprofv3.json", "bench_under_rocprofv3.json")
 for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stats_clustered.json", "knn_phase_stats_clustered.json"),
                   ("bench_clustered_10m_k15.json", "bench_clustered_10m_k15.json"),
+                  ("bench_uniform_10m_k8.json", "bench_uniform_10m_k8.json"),
                   ("bench_c5_50m_k32_stream.json", "bench_c5_50m_k32_stream.json"), ("pcie_inclusive.json", "pcie_inclusive.json"),
                   ("batch_query_rate.json", "batch_query_rate.json"),
                   ("valu_issue_rates.txt", "valu_issue_rates.txt")):

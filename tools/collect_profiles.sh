@@ -22,6 +22,7 @@ timeout -k 10 200 python3 tools/knn_stats.py 1e7 clustered 15 > "$out/stats_clus
 echo "stats done"
 # 5. other workloads: configs[3]'s cloud on one GPU, configs[4] streaming
 timeout -k 10 300 python3 bench.py --workload clustered_10m_k15 --no-cpu-baseline --no-extra > "$out/bench_clustered_10m_k15.json" 2>> "$out/bench.err" &&
+timeout -k 10 300 python3 bench.py --workload uniform_10m_k8 --no-cpu-baseline --no-extra > "$out/bench_uniform_10m_k8.json" 2>> "$out/bench.err" &&
 timeout -k 10 500 python3 bench.py --workload uniform_50m_k32_stream --no-cpu-baseline --no-extra --steps 5 > "$out/bench_c5_50m_k32_stream.json" 2>> "$out/bench.err" || { echo "workloads failed"; exit 1; }
 echo "workloads done"
 # 6. PCIe-inclusive host-pointer ABI timings
