@@ -121,10 +121,16 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 // Rows of the per-lane append buffer.  A leaf may append LEAF keys, so a compaction runs whenever a
 // lane holds more than BUF - LEAF keys; fewer rows = less LDS per wave = more resident waves.
 #ifndef PCPX_BUF16
-#define PCPX_BUF16 14  // measured on MI355X (10 M uniform, k=15, 5 waves/SIMD): 20 rows 688, 15 rows 758, 14 rows 793, 13 rows 785, 12 rows 771 Mq/s
+#define PCPX_BUF16 11  // 12 rows x 512 B = 6 KB per wave = 6 waves/SIMD.  Measured on MI355X (10 M uniform / clustered, k=15, 6 waves/SIMD, chunk-of-8 compaction): 9 rows 1182 / 1068, 10: 1221 / 1099, 11: 1250 / 1125, 12 (only 5 waves fit): 1200 / 1078; with 16-key compaction at 5 waves/SIMD 14 rows were best (1171)
 #endif
 #ifndef PCPX_BUF32
 #define PCPX_BUF32 16
+#endif
+#ifndef PCPX_COMPACT_BY8
+#define PCPX_COMPACT_BY8 1     // k <= 16 kernel: compaction in chunks of 8 keys (80 VGPRs, 6 waves/SIMD): 1171 -> 1250 Mq/s
+#endif
+#ifndef PCPX_COMPACT_BY8_32
+#define PCPX_COMPACT_BY8_32 0  // k <= 32 kernel: measured worse (720 vs 735 Mq/s; 5 waves/SIMD spill 308 B: 692)
 #endif
 #ifndef PCPX_BUF8
 #define PCPX_BUF8 9    // k <= 8: 10 rows x 512 B = 5 KB per wave, 7 waves/SIMD (10 M uniform, k = 8, Mq/s: 12 rows/6 waves 1400, 10/7 1461, 9/7 1478, 8/7 1429, 8/8 925 (spills); the k <= 16 kernel does 1337)
@@ -160,6 +166,35 @@ __device__ __forceinline__ void static_for(F&& f)
         f(std::integral_constant<int, J0>{});
         static_for<J0 + 1, J1>(f);
     }
+}
+
+// The same in chunks of 8 keys: rows 0..7, then (only if some lane holds more than 8) rows 8..BUF-1 -- never more than
+// 8 new keys live beside best[], which is what lets the k <= 16 kernel fit 80 VGPRs (6 waves/SIMD).
+template <int KCAP, int BUF>
+__device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
+{
+    static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 8, "rows");
+    {
+        u64 nw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
+        static_for<0, 8>([&](auto J) { nw[J] = pad_from<J>(nw[J], cnt); });
+        bitonic_sort<8>(nw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+        bitonic_merge<KCAP>(best);
+    }
+    if (BUF > 8 && any_lane(cnt > 8)) {
+        u64 nw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nw[j] = 8 + j < BUF ? col[(8 + j) * 64] : PAD_KEY;
+        static_for<8, BUF>([&](auto J) { nw[J - 8] = pad_from<J>(nw[J - 8], cnt); });
+        bitonic_sort<8>(nw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+        bitonic_merge<KCAP>(best);
+    }
+    cnt = 0;
 }
 
 template <int KCAP, int BUF>
@@ -251,8 +286,8 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 #define PCPX_MINW32 4  // k <= 32 kernel: <= 128 VGPRs = 4 waves/SIMD
 #endif
 #ifndef PCPX_MINW
-#define PCPX_MINW 5  // k <= 16 kernel: <= 96 VGPRs = 5 waves/SIMD (measured 758 vs 725 Mq/s at 4 waves/SIMD); asking for 6
-                     // (<= 80 VGPRs) makes hipcc spill 172 B/lane to scratch and is 2x slower
+#define PCPX_MINW 6  // k <= 16 kernel: <= 80 VGPRs = 6 waves/SIMD, possible since the compaction works in chunks of 8 keys (with the 16-key
+                     // compaction 80 VGPRs meant 140 B/lane of scratch and -8 %)
 #endif
 // PCPX_CAP_MULT x the median of the finite seeded taus of a sample of the wave's valid lanes (every fourth lane:
 // 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
@@ -413,7 +448,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (trig) {
             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
             if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
-            compact<KCAP, BUF>(best, col, cnt);
+            if (PCPX_COMPACT_BY8 && (KCAP == 16 || (KCAP == 32 && PCPX_COMPACT_BY8_32))) compact_by8<KCAP, BUF>(best, col, cnt);
+            else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
             if (STATS) tau = fminf(tau, tau_known);
