@@ -121,7 +121,7 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 // Rows of the per-lane append buffer.  A leaf may append LEAF keys, so a compaction runs whenever a
 // lane holds more than BUF - LEAF keys; fewer rows = less LDS per wave = more resident waves.
 #ifndef PCPX_BUF16
-#define PCPX_BUF16 11  // 12 rows x 512 B = 6 KB per wave = 6 waves/SIMD.  Measured on MI355X (10 M uniform / clustered, k=15, 6 waves/SIMD, chunk-of-8 compaction): 9 rows 1182 / 1068, 10: 1221 / 1099, 11: 1250 / 1125, 12 (only 5 waves fit): 1200 / 1078; with 16-key compaction at 5 waves/SIMD 14 rows were best (1171)
+#define PCPX_BUF16 10  // 10 rows x 512 B = 5 KB per wave = 7 waves/SIMD.  Measured on MI355X (10 M uniform / clustered, k=15, chunk-of-8 compaction, no trash row): 6 waves/SIMD 12 rows 1268 / 1135, 7 waves 11 rows 1263 / 1130, 7 waves 10 rows 1281 / 1150, 7 waves 9 rows 1236 / 1110
 #endif
 #ifndef PCPX_BUF32
 #define PCPX_BUF32 16
@@ -135,6 +135,12 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 #ifndef PCPX_BUF8
 #define PCPX_BUF8 9    // k <= 8: 10 rows x 512 B = 5 KB per wave, 7 waves/SIMD (10 M uniform, k = 8, Mq/s: 12 rows/6 waves 1400, 10/7 1461, 9/7 1478, 8/7 1429, 8/8 925 (spills); the k <= 16 kernel does 1337)
 #endif
+#ifndef PCPX_ASM_ACCEPT
+#define PCPX_ASM_ACCEPT 1
+#endif
+// rows of LDS per wave: the C++ accept path (multi-pass kernels only) stores rejected keys to a trash row, row BUF;
+// the exec-masked path stores nothing for a rejected candidate
+__host__ __device__ constexpr int lds_rows(int buf, bool multi) { return buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0); }
 __host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 8 ? PCPX_BUF8 : kcap <= 16 ? PCPX_BUF16 : PCPX_BUF32; }
 
 // Fold this lane's buffered keys (cnt <= BUF <= 16) into its sorted best-list.  All LDS traffic is
@@ -231,9 +237,6 @@ __device__ __forceinline__ void compact(u64 (&best)[KCAP], u64* __restrict__ col
 // write and the address bump simply run under the narrowed EXEC; EXEC is restored before leaving.
 // The C++ equivalent (two compares, three selects, address math, count) costs 9 VALU per candidate.
 // gfx9 v_cmpx also writes VCC.  No wait states are needed between the VALU EXEC write and the DS issue.
-#ifndef PCPX_ASM_ACCEPT
-#define PCPX_ASM_ACCEPT 1
-#endif
 // (tried: jumping over the eps test / LDS write / address bump with s_cbranch_execz when no lane is within tau
 // of a point: the branch costs more than the skipped issue slots, 998 vs 1048 Mq/s)
 __device__ __forceinline__ u64 save_exec()
@@ -286,8 +289,8 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 #define PCPX_MINW32 4  // k <= 32 kernel: <= 128 VGPRs = 4 waves/SIMD
 #endif
 #ifndef PCPX_MINW
-#define PCPX_MINW 6  // k <= 16 kernel: <= 80 VGPRs = 6 waves/SIMD, possible since the compaction works in chunks of 8 keys (with the 16-key
-                     // compaction 80 VGPRs meant 140 B/lane of scratch and -8 %)
+#define PCPX_MINW 7  // k <= 16 kernel: <= 72 VGPRs = 7 waves/SIMD, possible since the compaction works in chunks of 8 keys (with the 16-key
+                     // compaction even 80 VGPRs meant 140 B/lane of scratch and -8 %)
 #endif
 // PCPX_CAP_MULT x the median of the finite seeded taus of a sample of the wave's valid lanes (every fourth lane:
 // 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     extern __shared__ u64 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = wave_in_block();
-    u64* col = lds + static_cast<size_t>(wib) * (BUF + 1) * 64 + lane;
+    u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI) * 64 + lane;
     const u32 ngroups = group_end - group_first;
     const u32 per = (ngroups + 7u) >> 3;
     const u32 home = blockIdx.x & 7u;
@@ -772,7 +775,7 @@ template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, const KnnOutputs& o)
 {
     constexpr int BUF = buf_rows(KCAP);
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false) * 64 * sizeof(u64);
     u32 grid = grid_for_groups(gcount);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     int st = prepare_queue(ix);
@@ -851,7 +854,7 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
     }
     u64* keys = ix.d_multi;
     u64* lo[2] = {ix.d_multi + nslots * stride, ix.d_multi + nslots * stride + nslots};
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, true) * 64 * sizeof(u64);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false, true>)
                           : reinterpret_cast<const void*>(k_knn<KCAP, false, false, true>);
@@ -906,7 +909,7 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     constexpr int KCAP = 16, BUF = buf_rows(KCAP);
     u64 groups = (ix.n + GROUP - 1) / GROUP;
     if (groups == 0) return PCPX_OK;
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * (BUF + 1) * 64 * sizeof(u64);
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false) * 64 * sizeof(u64);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
