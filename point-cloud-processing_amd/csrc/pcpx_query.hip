@@ -133,7 +133,7 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 #define PCPX_COMPACT_BY8_32 0  // k <= 32 kernel: measured worse (720 vs 735 Mq/s; 5 waves/SIMD spill 308 B: 692)
 #endif
 #ifndef PCPX_BUF8
-#define PCPX_BUF8 9    // k <= 8: 10 rows x 512 B = 5 KB per wave, 7 waves/SIMD (10 M uniform, k = 8, Mq/s: 12 rows/6 waves 1400, 10/7 1461, 9/7 1478, 8/7 1429, 8/8 925 (spills); the k <= 16 kernel does 1337)
+#define PCPX_BUF8 10   // k <= 8: 10 rows x 512 B = 5 KB per wave, 8 waves/SIMD (10 M uniform, k = 8, Mq/s, chunk-of-8 compaction: 7 waves 9 rows 1506, 7/10 1530, 8/9 1553, 8/10 1581; the k <= 16 kernel of the time did 1337)
 #endif
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
@@ -283,7 +283,7 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 // kNN (+ fused PCA normals)
 // ------------------------------------------------------------------------------------------------
 #ifndef PCPX_MINW8
-#define PCPX_MINW8 7   // k <= 8 kernel: <= 72 VGPRs = 7 waves/SIMD
+#define PCPX_MINW8 8   // k <= 8 kernel: 63 VGPRs = 8 waves/SIMD
 #endif
 #ifndef PCPX_MINW32
 #define PCPX_MINW32 4  // k <= 32 kernel: <= 128 VGPRs = 4 waves/SIMD
@@ -451,7 +451,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (trig) {
             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
             if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
-            if (PCPX_COMPACT_BY8 && (KCAP == 16 || (KCAP == 32 && PCPX_COMPACT_BY8_32))) compact_by8<KCAP, BUF>(best, col, cnt);
+            if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (KCAP == 32 && PCPX_COMPACT_BY8_32))) compact_by8<KCAP, BUF>(best, col, cnt);
             else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
