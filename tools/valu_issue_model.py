@@ -18,7 +18,7 @@ compact_short = chunk          # no lane holds more than 8 keys
 compact_full = 2 * chunk       # rows 8..BUF-1 as a second chunk
 leaves = st["leaves"] + st["seed_leaves"]
 steps = leaves + st["expansions"]
-short_share = 0.75  # share of compactions in which no lane holds more than 8 keys (the trigger is "more than 3")
+short_share = 0.85  # share of compactions in which no lane holds more than 8 keys (the trigger is "more than 2")
 parts = {
     "leaf_candidates": leaves * 8 * candidate,
     "box_tests": st["expansions"] * 4 * box,
