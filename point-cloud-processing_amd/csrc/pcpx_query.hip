@@ -342,7 +342,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                                           const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
                                           u64* __restrict__ col, const u32 lane)
 {
-    constexpr int BUF = buf_rows(KCAP);  // usable rows; row BUF is the trash row
+    constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
