@@ -180,7 +180,8 @@ template <int KCAP, int BUF>
 __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
     static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 8, "rows");
-    {
+    {   // (tried: a third tier that reads and sorts only 4 keys when no lane holds more -- 47 % of the compactions: the
+        // extra path costs the k <= 16 kernel 20 B/lane more scratch, 1275 -> 1235 Mq/s; k <= 8: +1 %)
         u64 nw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
@@ -346,7 +347,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
-    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0;
+    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0, st_c3 = 0, st_c4 = 0;
     // [7] shader cycles in the walker (pop + node expansions), [8] in compactions, [9] in leaf candidates,
     // [10] in the whole search loop, [11] whole group incl. the epilogue (id gather, tie repair, stores, fused normal)
     unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0;
@@ -451,6 +452,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (trig) {
             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
             if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
+            if (STATS) {  // how full is the fullest lane when a compaction runs?
+                st_c3 += any_lane(cnt > 3) ? 0u : 1u;
+                st_c4 += any_lane(cnt > 4) ? 0u : 1u;
+            }
             if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (KCAP == 32 && PCPX_COMPACT_BY8_32))) compact_by8<KCAP, BUF>(best, col, cnt);
             else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
@@ -570,6 +575,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             atomicAdd(&stats[2], static_cast<unsigned long long>(st_compact));
             atomicAdd(&stats[12], static_cast<unsigned long long>(st_seed_compact));
             atomicAdd(&stats[13], static_cast<unsigned long long>(sapp));
+            atomicAdd(&stats[14], static_cast<unsigned long long>(st_c3));
+            atomicAdd(&stats[15], static_cast<unsigned long long>(st_c4));
             atomicAdd(&stats[3], static_cast<unsigned long long>(app));
             atomicAdd(&stats[4], 1ull);
             atomicAdd(&stats[5], static_cast<unsigned long long>(s1 - s0));
