@@ -390,7 +390,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     int cnt = 0;
     const u32 col_addr = lds_address(col);  // byte address of row 0 of this lane's column
     u32 wa = col_addr;                      // byte address of the next free row (PCPX_ASM_ACCEPT)
-    const u32 wa_full = col_addr + (static_cast<u32>(BUF - LEAF) << 9);  // beyond this a leaf might not fit
+    // a lane's column starts at lds_row0 + 8 * lane (< lds_row0 + 512), so "more than c keys buffered" is a comparison of
+    // wa with a wave-uniform bound: no per-lane threshold register
+    const u32 lds_row0 = __builtin_amdgcn_readfirstlane(col_addr) - 8u * __builtin_amdgcn_readfirstlane(lane);
+    const u32 wa_full = lds_row0 + (static_cast<u32>(BUF - LEAF + 1) << 9);  // wa >= this: a leaf might not fit any more
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
 
@@ -448,7 +451,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         // path keeps only the write address `wa`, the other paths only `cnt`.
         constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;
         if (!fast) wa = col_addr + (static_cast<u32>(cnt) << 9);
-        bool trig = have ? any_lane(wa > wa_full) : any_lane(wa != col_addr);
+        bool trig = have ? any_lane(wa >= wa_full) : any_lane(wa >= lds_row0 + 512u);
         if (trig) {
             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
             if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
