@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run on the GPU box: random cloud shapes, sizes, k, eps, radii; the product (through the Python mirror of
 the C ABI) against the oracle's brute force on a sample of queries, tie-aware.  Test infrastructure (uses the oracle); the fixed
-cases live in tests/test_gpu_parity.py, this looks for what they miss.   usage: python tests/fuzz_parity.py [seconds] [seed]   (tests/test_gpu_parity.py runs it for a few seconds)"""
+cases live in tests/test_gpu_parity.py, this looks for what they miss.   usage: python tests/fuzz_parity.py [seconds] [seed] [big]   (tests/test_gpu_parity.py runs it for a few seconds)"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,9 @@ from oracle import pcp_oracle as O
 O.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+SIZES = [1, 2, 7, 8, 9, 63, 64, 65, 100, 513, 4096, 30000, 200000]
+if len(sys.argv) > 3 and sys.argv[3] == "big":  # deeper trees, many resident waves' worth of groups
+    SIZES = [1_000_000, 2_500_000, 5_000_000]
 rng = np.random.default_rng(seed)
 
 
@@ -39,7 +42,7 @@ def cloud(n):
 t_end = time.time() + budget
 cases = fails = 0
 while time.time() < t_end:
-    n = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 100, 513, 4096, 30000, 200000]))
+    n = int(rng.choice(SIZES))
     pts, kind = cloud(n)
     n = len(pts)
     k = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 31, 32, 33, 40, 70]))
