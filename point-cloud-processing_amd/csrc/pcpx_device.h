@@ -94,10 +94,17 @@ struct Walker {
     {
         const u32 first_child = level_base(d + 1) + (loc << LOGW);  // heap id of child 0
         const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
+        // the mask is built on the scalar unit (left to itself hipcc makes it a vector value: v_cndmask, three v_or and a
+        // v_readfirstlane per expansion; the vector ALU is the saturated unit, the scalar one is not)
         u32 m = 0;
 #pragma unroll
-        for (int c = 0; c < W; ++c) m |= any_lane(need(cb.c[c])) ? (1u << c) : 0u;
-        return __builtin_amdgcn_readfirstlane(m);  // keeps the walk state in SGPRs (hipcc may build m with v_cndmask)
+        for (int c = 0; c < W; ++c) {
+            const u64 lanes = __builtin_amdgcn_ballot_w64(need(cb.c[c]));
+            u32 bit;
+            asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(bit) : "s"(lanes), "n"(1 << c) : "scc");
+            m |= bit;
+        }
+        return m;
     }
 
     // returns true if the root itself is the single leaf (depth 0) and is needed
