@@ -176,6 +176,9 @@ __device__ __forceinline__ void static_for(F&& f)
 
 // The same in chunks of 8 keys: rows 0..7, then (only if some lane holds more than 8) rows 8..BUF-1 -- never more than
 // 8 new keys live beside best[], which is what lets the k <= 16 kernel fit 80 VGPRs (6 waves/SIMD).
+// Invariant of the chunked path: every buffer slot that holds no key holds PAD_KEY (k_knn fills the rows once per
+// wave, a compaction writes PAD_KEY back into the rows it has read) -- so rows are read unconditionally and need no
+// masking by cnt: 8 LDS writes per chunk instead of 32 VALU instructions, and the vector ALU is the saturated unit.
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
 {
@@ -185,7 +188,8 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         u64 nw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
-        static_for<0, 8>([&](auto J) { nw[J] = pad_from<J>(nw[J], cnt); });
+#pragma unroll
+        for (int j = 0; j < 8; ++j) col[j * 64] = PAD_KEY;
         bitonic_sort<8>(nw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
@@ -195,7 +199,8 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         u64 nw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) nw[j] = 8 + j < BUF ? col[(8 + j) * 64] : PAD_KEY;
-        static_for<8, BUF>([&](auto J) { nw[J - 8] = pad_from<J>(nw[J - 8], cnt); });
+#pragma unroll
+        for (int j = 8; j < BUF; ++j) col[j * 64] = PAD_KEY;
         bitonic_sort<8>(nw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
@@ -716,6 +721,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = wave_in_block();
     u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI) * 64 + lane;
+    if (PCPX_COMPACT_BY8 && !MULTI && KCAP <= 16) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
+#pragma unroll
+        for (int j = 0; j < BUF; ++j) col[j * 64] = PAD_KEY;
+    }
     const u32 ngroups = group_end - group_first;
     const u32 per = (ngroups + 7u) >> 3;
     const u32 home = blockIdx.x & 7u;
