@@ -13,7 +13,7 @@ SIMPLE, THREE_OP, CMP, F64 = 2.4, 4.4, 4.1, 4.2  # cycles per wave-instruction p
 candidate = 8 * SIMPLE + THREE_OP + 2 * CMP + 2 * SIMPLE      # distance (8) + v_max3 + 2 v_cmpx + address and position bumps
 box = 14 * SIMPLE + 3 * THREE_OP + CMP                        # 6 sub, 3 mul, 3 add, poison add, ... + 3 v_max3 + v_cmp (16 VALU)
 ce = 2 * F64                                                  # compare-exchange = v_min_f64 + v_max_f64
-chunk = (24 + 32) * ce + 8 * F64 + 8 * (3 * SIMPLE + F64) + 30   # one chunk of 8 keys: sort 8, 8 mins, merge 16, 8 slot masks, overhead
+chunk = (24 + 32) * ce + 8 * F64 + 30   # one chunk of 8 keys: sort 8, 8 mins, merge 16, overhead (empty slots hold PAD_KEY: no masks)
 compact_short = chunk          # no lane holds more than 8 keys
 compact_full = 2 * chunk       # rows 8..BUF-1 as a second chunk
 leaves = st["leaves"] + st["seed_leaves"]
