@@ -71,6 +71,10 @@ struct self_knn_map_t
     Tree const* tree;
     std::size_t k;
     float eps = 1e-5f;
+
+    // per element it is an ordinary KnnMap (reference traits/knn_map.hpp:22-45); algorithm::estimate_normals never
+    // calls this: it recognises the type and runs the whole range as one fused launch
+    std::vector<element_type> operator()(element_type const& e) const { return tree->nearest_neighbours_of(e, k, eps); }
 };
 template <class Tree>
 self_knn_map_t<Tree> self_knn_map(Tree const& tree, std::size_t k, float eps = 1e-5f)

@@ -11,5 +11,6 @@
 #include "pcp/common/points/point_view.hpp"
 #include "pcp/common/points/vertex.hpp"
 #include "pcp/common/sphere.hpp"
+#include "pcp/common/vector3d.hpp"
 #include "pcp/common/vector3d_queries.hpp"
 #endif

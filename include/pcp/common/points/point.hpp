@@ -4,6 +4,8 @@
 #ifndef PCP_COMMON_POINTS_POINT_HPP
 #define PCP_COMMON_POINTS_POINT_HPP
 
+#include "pcp/common/vector3d.hpp"
+
 #include <utility>
 
 namespace pcp {
@@ -37,6 +39,12 @@ class basic_point_t
     self_type operator+(Vector3d const& v) const noexcept
     {
         return {c_[0] + v.x(), c_[1] + v.y(), c_[2] + v.z()};
+    }
+    // displacement between two points (reference point.hpp:73-80): point - point view = vector
+    template <class PointView, class Vector3d = common::basic_vector3d_t<coordinate_type>>
+    Vector3d operator-(PointView const& other) const noexcept
+    {
+        return Vector3d{c_[0] - other.x(), c_[1] - other.y(), c_[2] - other.z()};
     }
     self_type operator-() const noexcept { return {-c_[0], -c_[1], -c_[2]}; }
 

@@ -104,6 +104,11 @@ class basic_linked_kdtree_t
         return nearest_neighbours(coordinate_map_(element_target), k, eps);
     }
 
+    std::vector<element_type> nearest_neighbours_of(element_type const& e, std::size_t k, double eps = 1e-5) const
+    {
+        return nearest_neighbours(e, k, static_cast<coordinate_type>(eps));
+    }
+
     template <class Range>
     std::vector<element_type> range_search(Range const& range) const
     {

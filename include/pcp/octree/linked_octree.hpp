@@ -23,8 +23,10 @@
 #include "pcp/common/sphere.hpp"
 #include "pcp/gpu/device_index.hpp"
 
+#include <array>
 #include <cassert>
 #include <cstdint>
+#include <functional>
 #include <iterator>
 #include <limits>
 #include <memory>
@@ -125,6 +127,11 @@ class basic_linked_octree_t
     {
         auto const p = point_view(e);
         if (!params_.voxel_grid.contains(p)) return false;
+        if (!point_of_)  // remembered for nearest_neighbours_of (the callable is copied, like the elements)
+            point_of_ = [point_view](element_type const& el) {
+                auto const q = point_view(el);
+                return std::array<float, 3>{static_cast<float>(q.x()), static_cast<float>(q.y()), static_cast<float>(q.z())};
+            };
         elements_.push_back(e);
         xyz_.push_back(static_cast<float>(p.x()));
         xyz_.push_back(static_cast<float>(p.y()));
@@ -143,6 +150,16 @@ class basic_linked_octree_t
         if (k == 0 || elements_.empty()) return {};
         float const q[3] = {static_cast<float>(target.x()), static_cast<float>(target.y()), static_cast<float>(target.z())};
         auto const r = index().knn(q, 1, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+        return gather(r.idx.data(), r.count[0]);
+    }
+
+    // k nearest neighbours of one of the container's own elements, located through the point-view map the
+    // elements were inserted with (what pcp::gpu::self_knn_map_t calls per element)
+    std::vector<element_type> nearest_neighbours_of(element_type const& e, std::size_t k, double eps = 1e-5) const
+    {
+        if (k == 0 || elements_.empty() || !point_of_) return {};
+        auto const q = point_of_(e);
+        auto const r = index().knn(q.data(), 1, static_cast<std::uint32_t>(k), static_cast<float>(eps));
         return gather(r.idx.data(), r.count[0]);
     }
 
@@ -251,6 +268,7 @@ class basic_linked_octree_t
     params_type params_{};
     std::vector<element_type> elements_;
     std::vector<float> xyz_;
+    std::function<std::array<float, 3>(element_type const&)> point_of_;
     mutable gpu::device_index_t index_;
     mutable bool dirty_ = true;
     mutable std::unique_ptr<std::mutex> mutex_ = std::make_unique<std::mutex>();

@@ -3,6 +3,7 @@
 #define PCP_PCP_HPP
 #include "pcp/algorithm/algorithm.hpp"
 #include "pcp/common/common.hpp"
+#include "pcp/io/io.hpp"
 #include "pcp/kdtree/kdtree.hpp"
 #include "pcp/octree/octree.hpp"
 #endif

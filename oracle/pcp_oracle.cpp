@@ -415,6 +415,14 @@ inline float eig_hypot(float x, float y)
     return p * std::sqrt(1.f + qp * qp);
 }
 
+// which paths the last eig3_tridiag_ql call of this thread took (tests use it to prove a known-answer case really
+// exercises the Householder step and the QR iteration, not just the already-tridiagonal shortcut)
+struct EigTrace {
+    int householder = 0;  // 1: the general tridiagonalisation branch (a20 != 0)
+    int qr_steps = 0;     // implicit symmetric QR steps taken
+};
+thread_local EigTrace g_eig_trace;
+
 // SelfAdjointEigenSolver<Matrix3f>::compute(A, ComputeEigenvectors), reading the lower triangle.
 // evals ascending, evecs column-major: Q[r + 3*c] = component r of eigenvector c.
 void eig3_tridiag_ql(float const C[3][3], float evals[3], float Q[9])
@@ -431,6 +439,8 @@ void eig3_tridiag_ql(float const C[3][3], float evals[3], float Q[9])
     float const tol = std::numeric_limits<float>::min();
     diag[0] = a00;
     float const v1norm2 = a20 * a20;
+    g_eig_trace.householder = v1norm2 <= tol ? 0 : 1;
+    g_eig_trace.qr_steps = 0;
     if (v1norm2 <= tol) {
         diag[1] = a11;
         diag[2] = a22;
@@ -470,6 +480,7 @@ void eig3_tridiag_ql(float const C[3][3], float evals[3], float Q[9])
         if (end <= 0) break;
         iter++;
         if (iter > 30 * n) { converged = false; break; }
+        g_eig_trace.qr_steps = iter;
         start = end - 1;
         while (start > 0 && sub[start - 1] != 0.f) start--;
 
@@ -741,6 +752,13 @@ u64 orc_kdtree_range_aabb(void* h, float const* b6, u32* out, u64 cap)
 void orc_estimate_normal(float const* xyz, u32 const* idx, u64 n, float out[3], float* evals3)
 {
     estimate_normal(reinterpret_cast<P3 const*>(xyz), idx, n, out, evals3);
+}
+// the same, also reporting which solver paths ran: trace2 = {general tridiagonalisation taken, QR steps}
+void orc_estimate_normal_traced(float const* xyz, u64 n, float out[3], float* evals3, int* trace2)
+{
+    estimate_normal(reinterpret_cast<P3 const*>(xyz), nullptr, n, out, evals3);
+    trace2[0] = g_eig_trace.householder;
+    trace2[1] = g_eig_trace.qr_steps;
 }
 // normals from precomputed neighbour lists (nq x k, counts) -- the op the GPU normals kernel mirrors
 void orc_normals_from_knn(float const* xyz, u32 const* nbr, u32 const* cnt, u64 nq, u32 k, float* out_normals,

@@ -185,6 +185,16 @@ def estimate_normal(points, want_evals=False):
     return (out, ev) if want_evals else out
 
 
+def estimate_normal_traced(points):
+    """estimate_normal plus which solver paths ran: (normal, eigenvalues, general tridiagonalisation taken, QR steps)."""
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros(3, np.float32)
+    ev = np.zeros(3, np.float32)
+    tr = (C.c_int * 2)()
+    lib().orc_estimate_normal_traced(_p(pts, _f32p), C.c_uint64(len(pts)), _p(out, _f32p), _p(ev, _f32p), tr)
+    return out, ev, bool(tr[0]), int(tr[1])
+
+
 def normals_from_knn(xyz, nbr, cnt, nthreads=1, want_evals=False):
     xyz = _f32(xyz).reshape(-1, 3)
     nbr = np.ascontiguousarray(nbr, np.uint32)

@@ -72,6 +72,44 @@ int select_device(int device)
     return PCPX_OK;
 }
 
+// Every entry point makes its device current for its own duration only: the caller's thread gets its previous
+// current device back on return (a torch caller on cuda:1 must not find itself on cuda:0 after a pcpx call).
+struct DeviceScope {
+    int prev = -1;
+    void remember()
+    {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            prev = -1;
+            (void)hipGetLastError();
+        }
+    }
+    int select(int device)
+    {
+        remember();
+        int st = select_device(device);
+        if (prev == device) prev = -1;  // nothing to restore
+        return st;
+    }
+    int use(Index* ix)
+    {
+        if (!ix) {
+            set_error("pcpx: null index handle");
+            return PCPX_ERR_INVALID;
+        }
+        remember();
+        if (prev == ix->device) {
+            prev = -1;
+            return PCPX_OK;
+        }
+        PCPX_HIP(hipSetDevice(ix->device));
+        return PCPX_OK;
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 // extern "C" entry points that allocate host memory run their body through this: nothing may be thrown across the ABI
 template <class Body>
 int no_throw(const char* what, Body&& body)
@@ -87,16 +125,6 @@ int no_throw(const char* what, Body&& body)
     }
 }
 
-int use(Index* ix)
-{
-    if (!ix) {
-        set_error("pcpx: null index handle");
-        return PCPX_ERR_INVALID;
-    }
-    PCPX_HIP(hipSetDevice(ix->device));
-    return PCPX_OK;
-}
-
 void slice_to_groups(const Index& ix, u64 sorted_first, u64 sorted_count, u64& gfirst, u64& gcount)
 {
     u64 n = ix.n;
@@ -110,8 +138,9 @@ void slice_to_groups(const Index& ix, u64 sorted_first, u64 sorted_count, u64& g
 void free_index(Index* ix)
 {
     if (!ix) return;
-    (void)hipSetDevice(ix->device);
-    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    DeviceScope dscope;
+    (void)dscope.use(ix);
+    (void)hipStreamSynchronize(ix->stream);  // (nullptr = the legacy default stream)
     for (auto& iv : ix->intervals) {
         (void)hipEventDestroy(iv.a);
         (void)hipEventDestroy(iv.b);
@@ -178,14 +207,18 @@ static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_bui
         return PCPX_ERR_INVALID;
     }
     *out = nullptr;
-    int st = select_device(device);
+    DeviceScope dscope;
+    int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     Index* ix = new (std::nothrow) Index();
     if (!ix) return PCPX_ERR_ALLOC;
     ix->device = device;
-    if (stream) {
+    if (on_device) {
+        // device-pointer form: work is enqueued on the CALLER's stream; NULL is the legacy default stream, which is
+        // ordered against the caller's other default-stream work (a private stream would not be)
         ix->stream = static_cast<hipStream_t>(stream);
     } else {
+        // host-pointer form: synchronous calls, so a private stream (no ordering against the caller's streams needed)
         hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete ix;
@@ -230,7 +263,8 @@ int pcpx_index_create_dev(const float* d_xyz, uint64_t n, const pcpx_build_param
 int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_build_params* params)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !xyz) return PCPX_ERR_INVALID;
@@ -247,7 +281,8 @@ int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_b
 int pcpx_index_rebuild_dev(pcpx_index* h, const float* d_xyz, uint64_t n, const pcpx_build_params* params)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !d_xyz) return PCPX_ERR_INVALID;
@@ -271,7 +306,8 @@ int pcpx_index_bbox(pcpx_index* h, float out6[6])
 int pcpx_index_synchronize(pcpx_index* h)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     PCPX_HIP(hipStreamSynchronize(ix->stream));
@@ -280,7 +316,8 @@ int pcpx_index_synchronize(pcpx_index* h)
 
 int pcpx_bounding_box_dev(const float* d_xyz, uint64_t n, int device, void* stream, float* d_out6)
 {
-    int st = select_device(device);
+    DeviceScope dscope;
+    int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (!d_out6 || (n > 0 && !d_xyz)) return PCPX_ERR_INVALID;
     // d_out6 must have room for the 6 floats; the encoded scratch is a temporary
@@ -294,7 +331,8 @@ int pcpx_bounding_box_dev(const float* d_xyz, uint64_t n, int device, void* stre
 }
 int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6])
 {
-    int st = select_device(device);
+    DeviceScope dscope;
+    int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (!out6 || (n > 0 && !xyz)) return PCPX_ERR_INVALID;
     DevBuf pts, box;
@@ -311,7 +349,8 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
                       uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (k == 0) return PCPX_OK;  // linked_octree_node.hpp:464: k == 0 -> {}
@@ -333,7 +372,8 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
 int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count, float* out_d2)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
@@ -363,7 +403,8 @@ int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_
                        uint32_t* d_out_count, float* d_out_d2)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (k == 0 || nq == 0) return PCPX_OK;
@@ -381,7 +422,8 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
                    uint32_t* out_count, float* out_d2)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
@@ -410,7 +452,8 @@ int pcpx_range_count_self_dev(pcpx_index* h, float radius, uint64_t sorted_first
                               uint32_t* d_out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!d_out_count) return PCPX_ERR_INVALID;
@@ -427,7 +470,8 @@ int pcpx_range_count_self_dev(pcpx_index* h, float radius, uint64_t sorted_first
 int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_count) return PCPX_ERR_INVALID;
@@ -444,7 +488,8 @@ int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
 int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float radius, uint32_t* out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
@@ -467,7 +512,8 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
 {
     return no_throw("pcpx_range_sphere_batch", [&]() -> int {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_offsets || (nq > 0 && !q_xyz)) return PCPX_ERR_INVALID;
@@ -512,7 +558,8 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
 {
     return no_throw("pcpx_range_aabb_batch", [&]() -> int {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_offsets || (nb > 0 && !boxes6)) return PCPX_ERR_INVALID;
@@ -550,7 +597,8 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
                               float* d_out_normals, uint32_t* d_opt_out_idx, uint32_t* d_opt_out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!d_out_normals || k == 0) return PCPX_ERR_INVALID;
@@ -580,7 +628,8 @@ int pcpx_neighbourhoods_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t 
                                  float* d_opt_normals, float* d_opt_centroids, float* d_opt_mean_dist)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (k == 0 || (!d_opt_normals && !d_opt_centroids && !d_opt_mean_dist)) return PCPX_ERR_INVALID;
@@ -607,7 +656,8 @@ int pcpx_neighbourhoods_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t 
 int pcpx_tangent_planes_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_centroids, float* out_normals)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_centroids || !out_normals || k == 0) return PCPX_ERR_INVALID;
@@ -627,7 +677,8 @@ int pcpx_tangent_planes_knn_self(pcpx_index* h, uint32_t k, float eps, float* ou
 int pcpx_mean_knn_distance_self(pcpx_index* h, uint32_t k, float eps, float* out_mean_dist)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_mean_dist || k == 0) return PCPX_ERR_INVALID;
@@ -645,7 +696,8 @@ int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_norma
                           uint32_t* opt_out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
@@ -670,7 +722,8 @@ int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t
                           float* out_normals, float* opt_out_evals)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
@@ -704,7 +757,8 @@ int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t
 
 int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_normal[3])
 {
-    int st = select_device(device);
+    DeviceScope dscope;
+    int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (!out_normal || (m > 0 && !xyz)) return PCPX_ERR_INVALID;
     DevBuf dp, dn;
@@ -719,7 +773,8 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
 int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_stats, uint64_t capacity)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_stats || capacity < 16 || k == 0 || k > 16) return PCPX_ERR_INVALID;
@@ -819,7 +874,8 @@ int pcpx_propagate_normal_orientations_dev(const float* d_xyz, uint64_t n, const
                                            const uint32_t* d_opt_knn_count, uint32_t k, float* d_normals, int device, void* stream,
                                            uint64_t* opt_out_reached, uint32_t* opt_out_levels)
 {
-    int st = select_device(device);
+    DeviceScope dscope;
+    int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (n > 0 && (!d_xyz || !d_normals || (k > 0 && !d_knn_idx))) {
         set_error("pcpx_propagate_normal_orientations_dev: null argument");
@@ -833,7 +889,8 @@ int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* 
                                    uint32_t* opt_out_count, uint64_t* opt_out_reached)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
@@ -861,7 +918,8 @@ int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* 
 int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* normals, uint64_t* opt_out_reached)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!normals || k == 0) return PCPX_ERR_INVALID;
@@ -888,7 +946,8 @@ int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* no
 int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
                           uint32_t* out_vals)
 {
-    int st = select_device(device);
+    DeviceScope dscope;
+    int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (n > 0 && (!keys || !vals || !out_keys || !out_vals)) return PCPX_ERR_INVALID;
     size_t tb = 0;
@@ -913,7 +972,8 @@ int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n
 int pcpx_profile_begin(pcpx_index* h)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     for (auto& iv : ix->intervals) {
@@ -928,7 +988,8 @@ int pcpx_profile_begin(pcpx_index* h)
 int pcpx_profile_end(pcpx_index* h, pcpx_profile* out)
 {
     Index* ix = reinterpret_cast<Index*>(h);
-    int st = use(ix);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out) return PCPX_ERR_INVALID;

@@ -219,14 +219,12 @@ inline int depth_for(u64 nleaves)
 template <class T>
 int dev_alloc(T*& p, size_t count)
 {
-    if (p) {
-        (void)hipFree(p);
-        p = nullptr;
-    }
+    p = nullptr;
     if (count == 0) count = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     if (e != hipSuccess) {
         p = nullptr;
+        (void)hipGetLastError();
         set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
         return PCPX_ERR_ALLOC;
     }
@@ -284,27 +282,71 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     hipStream_t s = ix.stream;
     ProfileScope prof(ix, PCPX_K_BUILD);
     if (n > ix.cap || !ix.d_xyz) {
+        // Grow: every new buffer is allocated first and swapped in only when all allocations have succeeded, so a
+        // failure (e.g. out of memory on a 50 M-point rebuild) leaves the handle on its previous, still valid index.
         PCPX_HIP(hipStreamSynchronize(s));
         u64 cap = n < 64 ? 64 : n;
+        struct Fresh {
+            float* xyz = nullptr;
+            u64* codes[2] = {nullptr, nullptr};
+            u32* vals[2] = {nullptr, nullptr};
+            Leaf* leaves = nullptr;
+            NodeBox* nodes = nullptr;
+            void* sort_tmp = nullptr;
+            bool keep = false;
+            ~Fresh()
+            {
+                if (keep) return;
+                (void)hipFree(xyz);
+                (void)hipFree(codes[0]); (void)hipFree(codes[1]);
+                (void)hipFree(vals[0]); (void)hipFree(vals[1]);
+                (void)hipFree(leaves); (void)hipFree(nodes); (void)hipFree(sort_tmp);
+            }
+        } nw;
         int st;
-        if ((st = dev_alloc(ix.d_xyz, cap * 3)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.xyz, cap * 3)) != PCPX_OK) return st;
         for (int b = 0; b < 2; ++b) {
-            if ((st = dev_alloc(ix.d_codes[b], cap)) != PCPX_OK) return st;
-            if ((st = dev_alloc(ix.d_vals[b], cap)) != PCPX_OK) return st;
+            if ((st = dev_alloc(nw.codes[b], cap)) != PCPX_OK) return st;
+            if ((st = dev_alloc(nw.vals[b], cap)) != PCPX_OK) return st;
         }
         u32 nl = static_cast<u32>((cap + LEAF - 1) / LEAF);
-        if ((st = dev_alloc(ix.d_leaves, nl)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.leaves, nl)) != PCPX_OK) return st;
         u64 nodes = level_start(depth_for(nl) + 1);
-        if ((st = dev_alloc(ix.d_nodes, nodes)) != PCPX_OK) return st;
-        ix.nodes_cap = nodes;
+        if ((st = dev_alloc(nw.nodes, nodes)) != PCPX_OK) return st;
         size_t tb = 0;
-        if ((st = sort_pairs_u64(nullptr, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], cap, s)) != PCPX_OK)
-            return st;
-        if (ix.d_sort_tmp) (void)hipFree(ix.d_sort_tmp);
-        ix.d_sort_tmp = nullptr;
-        PCPX_HIP(hipMalloc(&ix.d_sort_tmp, tb ? tb : 16));
+        if ((st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, cap, s)) != PCPX_OK) return st;
+        {
+            hipError_t e = hipMalloc(&nw.sort_tmp, tb ? tb : 16);
+            if (e != hipSuccess) {
+                nw.sort_tmp = nullptr;
+                set_error("hipMalloc(%zu bytes) for the sort's temporary storage failed: %s", tb, hipGetErrorString(e));
+                (void)hipGetLastError();
+                return PCPX_ERR_ALLOC;
+            }
+        }
+        (void)hipFree(ix.d_xyz);
+        for (int b = 0; b < 2; ++b) {
+            (void)hipFree(ix.d_codes[b]);
+            (void)hipFree(ix.d_vals[b]);
+            ix.d_codes[b] = nw.codes[b];
+            ix.d_vals[b] = nw.vals[b];
+        }
+        (void)hipFree(ix.d_leaves);
+        (void)hipFree(ix.d_nodes);
+        (void)hipFree(ix.d_sort_tmp);
+        ix.d_xyz = nw.xyz;
+        ix.d_leaves = nw.leaves;
+        ix.d_nodes = nw.nodes;
+        ix.d_sort_tmp = nw.sort_tmp;
+        nw.keep = true;
+        ix.nodes_cap = nodes;
         ix.sort_tmp_bytes = tb;
         ix.cap = cap;
+        // the old index is gone: until this build completes the handle holds an empty one
+        ix.n = ix.n_in = 0;
+        ix.nleaves = 0;
+        ix.depth = 0;
+        ix.leaf0 = 0;
     }
     if (!ix.d_scalars) {
         int st;

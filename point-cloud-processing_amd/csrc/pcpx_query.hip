@@ -29,7 +29,8 @@
 // (include/pcp/common/vector3d_queries.hpp:47-64).  The box lower bound is monotone in float, so
 // pruning never changes the result.  Rows are the exact k nearest in ascending (d2, index) order; if
 // several points tie EXACTLY with the k-th distance, which of them is kept is unspecified -- as in the
-// reference, where it depends on heap order (linked_octree_node.hpp:479-489, linked_kdtree.hpp:483-488).#include "pcpx_device.h"
+// reference, where it depends on heap order (linked_octree_node.hpp:479-489, linked_kdtree.hpp:483-488).
+#include "pcpx_device.h"
 #include "pcpx_eig3.h"
 
 namespace pcpx {

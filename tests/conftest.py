@@ -91,3 +91,49 @@ def knn_rows_equivalent(xyz, queries, idx_a, cnt_a, idx_b, cnt_b):
 def _d2(p, q):
     d = p - q[None, :]
     return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+
+
+def analytic_normal_cases():
+    """Point sets whose PCA normal is known in closed form and whose scatter matrix is EXACT in float32, so that what
+    is tested is the eigen-solver alone (beyond the reference's axis-aligned 7-point KAT,
+    test/common/normal_estimation.cpp:11-38, whose scatter matrix is diagonal and never enters the QR iteration).
+
+    Construction: an orthonormal basis (u, v, w) with rational entries (two Pythagorean rotations: multiples of 1/65),
+    points {+-a u +- b v +- c w} over a few (a, b, c) triples that are multiples of 65/64 -- all coordinates are small
+    integers / 64, so the mean is exactly 0, every product and partial sum of the scatter matrix is an exact float32, and
+    Cov = R diag(8 sum a^2, 8 sum b^2, 8 sum c^2) R^T exactly.  The eigenvector of the smallest of the three is the
+    corresponding basis vector.  Yields (name, points float32 (m, 3), unit normal float64 (3,), relative eigen-gap)."""
+    import itertools
+    from fractions import Fraction as F
+    def mat(rows):
+        return [[F(x) for x in r] for r in rows]
+    def mul(a, b):
+        return [[sum(a[i][k] * b[k][j] for k in range(3)) for j in range(3)] for i in range(3)]
+    c1, s1, c2, s2 = F(3, 5), F(4, 5), F(5, 13), F(12, 13)
+    rz = mat([[c1, -s1, 0], [s1, c1, 0], [0, 0, 1]])
+    rx = mat([[1, 0, 0], [0, c2, -s2], [0, s2, c2]])
+    ry = mat([[c2, 0, s2], [0, 1, 0], [-s2, 0, c2]])
+    bases = {"zx": (mul(rz, rx), 65), "xz": (mul(rx, rz), 65), "zy": (mul(rz, ry), 65), "yxz": (mul(ry, mul(rx, rz)), 845)}
+    spreads = {
+        "flat": [(8, 6, 1), (4, 7, 0), (2, 3, 1)],          # thin slab: well separated smallest eigenvalue
+        "mild": [(8, 6, 5), (4, 7, 4), (2, 3, 5)],          # anisotropic but thick
+        "near_tie": [(8, 8, 7), (5, 5, 5), (3, 2, 2)],      # two large eigenvalues close, smallest only ~25 % below
+        "needle": [(1, 9, 2), (0, 7, 1), (1, 8, 0)],        # one dominant direction: the normal is one of two small ones
+    }
+    for bname, (basis, den) in bases.items():
+        ib = [[int(basis[r][c] * den) for c in range(3)] for r in range(3)]  # den * R: integers
+        assert all(F(ib[r][c], den) == basis[r][c] for r in range(3) for c in range(3))
+        for sname, triples in spreads.items():
+            rows = []
+            for (a, b, c) in triples:
+                for sa, sb, sc in itertools.product((-1, 1), repeat=3):
+                    rows.append([sa * a * ib[r][0] + sb * b * ib[r][1] + sc * c * ib[r][2] for r in range(3)])
+            pts = np.array(rows, dtype=np.int64)  # integer coordinates (the cloud scaled by den); /64 keeps them exact
+            assert np.abs(pts).max() < 2 ** 15     # so squares and their sums stay below 2^24 * 64^2: exact in float32
+            lam = np.array([8.0 * sum(t[i] ** 2 for t in triples) for i in range(3)])
+            order = np.argsort(lam)
+            normal = np.array([float(basis[r][order[0]]) for r in range(3)])
+            gap = (lam[order[1]] - lam[order[0]]) / lam[order[2]]
+            p32 = (pts.astype(np.float64) / 64.0).astype(np.float32)
+            assert np.array_equal(p32.astype(np.float64) * 64.0, pts.astype(np.float64)), "coordinates must be exact in float32"
+            yield "%s/%s" % (bname, sname), p32, normal / np.linalg.norm(normal), float(gap)

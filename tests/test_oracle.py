@@ -198,3 +198,21 @@ def test_estimate_normals_driver_consistent(oracle):
     for i in range(0, 1000, 37):
         e = oracle.estimate_normal(pts[ki[i, : kc[i]]])
         assert np.all(np.abs(nrm[i] - e) < 1e-5) or np.all(np.abs(nrm[i] + e) < 1e-5)
+
+
+def test_oracle_normals_on_analytic_cases_that_enter_the_qr_iteration(oracle):
+    """The reference's only normal KAT (7 axis points, test/common/normal_estimation.cpp:11-38) has a diagonal scatter
+    matrix: the restated Eigen solver returns before its Householder step and QR loop do anything.  These clouds have
+    the same kind of closed-form answer but a dense, EXACT scatter matrix (conftest.analytic_normal_cases), and the
+    oracle reports which solver paths ran."""
+    from conftest import analytic_normal_cases
+    general, sweeps = 0, 0
+    for name, pts, normal, gap in analytic_normal_cases():
+        n, ev, householder, qr_steps = oracle.estimate_normal_traced(pts)
+        err = 1.0 - abs(float(n.astype(np.float64) @ normal))
+        assert err <= 1e-6, (name, err)
+        assert abs(float(np.sqrt((n.astype(np.float64) ** 2).sum())) - 1.0) < 1e-6
+        assert ev[0] <= ev[1] <= ev[2] and gap > 1e-3
+        general += householder
+        sweeps += qr_steps >= 2
+    assert general >= 12 and sweeps >= 8  # the general tridiagonalisation and >= 2 QR steps are really exercised
