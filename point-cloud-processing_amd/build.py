@@ -14,7 +14,7 @@ OBJ_DIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libpcpx.so")
 SOURCES = ["pcpx_query.hip", "pcpx_range.hip", "pcpx_normals.hip", "pcpx_prep.hip", "pcpx_orient.hip", "pcpx_build.hip", "pcpx_sort.hip",
            "pcpx_api.hip"]
-HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(CSRC, "pcpx_device.h"), os.path.join(CSRC, "pcpx_eig3.h"),
+HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(CSRC, "pcpx_device.h"), os.path.join(CSRC, "pcpx_eig3.h"), os.path.join(CSRC, "pcpx_curve.h"),
            os.path.join(INCLUDE, "pcpx.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the reference evaluates dx*dx+dy*dy+dz*dz without FMA; neighbour order and the

@@ -6,7 +6,7 @@
 // Morton-sorted implicit AABB tree (pcpx_internal.h) built by:
 //   bbox reduce -> 63-bit Morton codes (+ out-of-grid drop) -> radix sort of (code, index) (pcpx_sort.hip)
 //   -> leaf records (SoA, NaN padded) -> leaf AABBs -> bottom-up sweep of the W-ary levels.
-#include "pcpx_internal.h"
+#include "pcpx_curve.h"
 
 #include <cmath>
 #include <limits>
@@ -73,27 +73,7 @@ __global__ void k_bbox_decode(const u32* enc6, float* out6)
     if (threadIdx.x < 6) out6[threadIdx.x] = dec_f(enc6[threadIdx.x]);
 }
 
-__device__ __forceinline__ u64 spread21(u32 v)
-{
-    u64 x = v & 0x1FFFFFu;
-    x = (x | (x << 32)) & 0x001F00000000FFFFull;
-    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
-    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
-    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
-
-__device__ __forceinline__ u32 quant21(float v, float lo, float hi)
-{
-    float ext = hi - lo;
-    float t = ext > 0.f ? (v - lo) / ext : 0.f;
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    u32 q = static_cast<u32>(t * 2097152.f);
-    return q > 2097151u ? 2097151u : q;
-}
-
-// Morton code of every point inside the grid; points outside (or NaN) get PAD_CODE and sort to the
+// Curve key (pcpx_curve.h) of every point inside the grid; points outside (or NaN) get PAD_CODE and sort to the
 // end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive containment,
 // include/pcp/common/axis_aligned_bounding_box.hpp:111-125).
 __global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6,
@@ -105,7 +85,7 @@ __global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u6
         float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
         const bool ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
         u64 c = PAD_CODE;
-        if (ok) c = (spread21(quant21(x, b0, b3)) << 2) | (spread21(quant21(y, b1, b4)) << 1) | spread21(quant21(z, b2, b5));
+        if (ok) c = curve_key(x, y, z, b0, b1, b2, b3, b4, b5);
         codes[i] = c;
         vals[i] = static_cast<u32>(i);
     }

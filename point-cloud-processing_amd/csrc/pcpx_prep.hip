@@ -1,4 +1,5 @@
 // pcpx_prep.hip -- arbitrary query batches: Morton-sort the queries on the index's grid and seed every group of 64.
+#include "pcpx_curve.h"
 #include "pcpx_device.h"
 
 namespace pcpx {
@@ -9,33 +10,13 @@ namespace {
 // arbitrary query batches: Morton-sort the queries on the index's grid, seed each group at the
 // 64-point chunk where its first query would sit in the sorted cloud
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 spread21(u32 v)
-{
-    u64 x = v & 0x1FFFFFu;
-    x = (x | (x << 32)) & 0x001F00000000FFFFull;
-    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
-    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
-    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
-__device__ __forceinline__ u32 quant21(float v, float lo, float hi)
-{
-    float ext = hi - lo;
-    float t = ext > 0.f ? (v - lo) / ext : 0.f;
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    u32 q = static_cast<u32>(t * 2097152.f);
-    return q > 2097151u ? 2097151u : q;
-}
-
 __global__ __launch_bounds__(256) void k_query_codes(const float* __restrict__ q, u32 nq, const float* __restrict__ box6,
                                                      u64* __restrict__ codes, u32* __restrict__ vals)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     float x = q[3ull * i], y = q[3ull * i + 1], z = q[3ull * i + 2];
-    codes[i] = (spread21(quant21(x, box6[0], box6[3])) << 2) | (spread21(quant21(y, box6[1], box6[4])) << 1) |
-               spread21(quant21(z, box6[2], box6[5]));
+    codes[i] = curve_key(x, y, z, box6[0], box6[1], box6[2], box6[3], box6[4], box6[5]);  // (outside the box: clamped)
     vals[i] = i;
 }
 

@@ -1,0 +1,54 @@
+// Host-side check of the sort key (csrc/pcpx_curve.h), compiled with hipcc and run on the CPU: the index must be a
+// bijection of the grid whose consecutive values are face-adjacent cells -- the property that makes leaves and query
+// groups compact (a Morton code fails the second part at every Z jump).
+#include "pcpx_curve.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int B>
+static int check()
+{
+    const pcpx::u32 N = 1u << B;
+    const size_t cells = size_t(N) * N * N;
+    std::vector<int> at(cells * 3, -1);
+    std::vector<char> seen(cells, 0);
+    for (pcpx::u32 x = 0; x < N; ++x)
+        for (pcpx::u32 y = 0; y < N; ++y)
+            for (pcpx::u32 z = 0; z < N; ++z) {
+                const pcpx::u64 h = pcpx::hilbert_index<B>(x, y, z);
+                if (h >= cells || seen[h]) {
+                    std::printf("B=%d: not a bijection\n", B);
+                    return 1;
+                }
+                seen[h] = 1;
+                at[3 * h] = int(x);
+                at[3 * h + 1] = int(y);
+                at[3 * h + 2] = int(z);
+            }
+    for (size_t h = 1; h < cells; ++h) {
+        const int d = std::abs(at[3 * h] - at[3 * h - 3]) + std::abs(at[3 * h + 1] - at[3 * h - 2]) + std::abs(at[3 * h + 2] - at[3 * h - 1]);
+        if (d != 1) {
+            std::printf("B=%d: a jump at index %zu\n", B, h);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int main()
+{
+    int bad = check<1>() | check<2>() | check<3>() | check<4>() | check<6>() | check<8>();
+    // the full-width index orders cell corners like its own prefix: the 13-bit key of a cell and of its parent at 12 bits agree on
+    // the leading bits (what lets a query batch be seeded by binary search on truncated keys)
+    for (pcpx::u32 i = 0; i < 4096 && !bad; ++i) {
+        const pcpx::u32 x = (i * 2654435761u) >> 19, y = (i * 40503u + 77u) & 8191u, z = (i * 9973u + 5u) & 8191u;
+        if ((pcpx::hilbert_index<13>(x, y, z) >> 3) != pcpx::hilbert_index<12>(x >> 1, y >> 1, z >> 1)) {
+            std::printf("13-bit index is not a refinement of the 12-bit one at (%u,%u,%u)\n", x, y, z);
+            bad = 1;
+        }
+    }
+    if (!bad) std::printf("curve key: ok\n");
+    return bad;
+}

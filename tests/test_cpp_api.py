@@ -61,6 +61,15 @@ def test_cpp_ply_reader_and_writer(tmp_path, pkg):
         assert rp.shape == (3, 3) and rn.shape == (2, 3) and abs(rn[1, 2] - 0.8) < 1e-6
 
 
+def test_curve_key_is_a_continuous_bijection(tmp_path):
+    """csrc/pcpx_curve.h compiled for the host with hipcc (no GPU needed): the Hilbert index the index is sorted by."""
+    exe = tmp_path / "test_curve"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"),
+                    "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cpp", "test_curve.hip"), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "curve key: ok" in r.stdout, r.stdout
+
+
 REFERENCE_INCLUDE = "/root/reference/include"
 
 
