@@ -51,9 +51,10 @@ struct knn_map_t
     {
         auto const p = query_point(e);
         float const q[3] = {static_cast<float>(p.x()), static_cast<float>(p.y()), static_cast<float>(p.z())};
-        auto const r = tree->index().knn(q, 1, static_cast<std::uint32_t>(k), eps);
+        auto const row = tree->index().knn_one(q, static_cast<std::uint32_t>(k), eps);
         std::vector<element_type> out;
-        for (std::uint32_t i = 0; i < r.count[0]; ++i) out.push_back(tree->element(r.idx[i]));
+        out.reserve(row.size());
+        for (std::uint32_t i : row) out.push_back(tree->element(i));
         return out;
     }
 };
@@ -143,11 +144,35 @@ void estimate_normals_impl(ForwardIter1 begin, ForwardIter1 end, PointViewMap co
     }
     else
     {
-        for (; begin != end; ++begin)
+        // an arbitrary (user) knn_map: it is called per element, in order, like the reference's sequential overload; the
+        // neighbourhoods' coordinates are collected (CSR) and their PCA normals computed by ONE launch per block of
+        // elements (pcpx_estimate_normals_batch) instead of one pcp::estimate_normal round trip each
+        constexpr std::size_t block = std::size_t(1) << 16;
+        std::vector<float> xyz;
+        std::vector<std::uint64_t> off;
+        std::vector<float> nrm;
+        while (begin != end)
         {
-            auto const neighbours = knn(*begin);
-            using iterator_type   = decltype(std::begin(neighbours));
-            emit(*begin, pcp::estimate_normal<iterator_type, PointViewMap, Normal>(std::begin(neighbours), std::end(neighbours), point_map));
+            ForwardIter1 const first = begin;
+            xyz.clear();
+            off.assign(1, 0);
+            for (; begin != end && off.size() <= block; ++begin)
+            {
+                auto const neighbours = knn(*begin);
+                for (auto const& nb : neighbours)
+                {
+                    auto const p = point_map(nb);
+                    xyz.push_back(static_cast<float>(p.x()));
+                    xyz.push_back(static_cast<float>(p.y()));
+                    xyz.push_back(static_cast<float>(p.z()));
+                }
+                off.push_back(xyz.size() / 3);
+            }
+            std::size_t const rows = off.size() - 1;
+            nrm.assign(rows * 3, 0.f);
+            gpu::check(pcpx_estimate_normals_batch(xyz.data(), off.data(), rows, 0, nrm.data()), "pcpx_estimate_normals_batch");
+            std::size_t i = 0;
+            for (ForwardIter1 it = first; it != begin; ++it, ++i) emit(*it, make_normal<Normal>(nrm.data() + 3 * i));
         }
     }
 }

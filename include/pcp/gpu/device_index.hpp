@@ -9,6 +9,9 @@
 
 #include <array>
 #include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -37,14 +40,19 @@ class device_index_t
     device_index_t() = default;
     device_index_t(device_index_t const&)            = delete;
     device_index_t& operator=(device_index_t const&) = delete;
-    device_index_t(device_index_t&& o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    device_index_t(device_index_t&& o) noexcept { *this = std::move(o); }
     device_index_t& operator=(device_index_t&& o) noexcept
     {
         if (this != &o)
         {
             reset();
-            h_ = std::exchange(o.h_, nullptr);
-            n_ = o.n_;
+            h_      = std::exchange(o.h_, nullptr);
+            n_      = std::exchange(o.n_, 0);
+            xyz_    = std::exchange(o.xyz_, nullptr);
+            n_in_   = std::exchange(o.n_in_, 0);
+            lookup_ = std::move(o.lookup_);
+            knn_    = std::move(o.knn_);
+            range_  = std::move(o.range_);
         }
         return *this;
     }
@@ -55,6 +63,7 @@ class device_index_t
         if (h_) pcpx_index_destroy(h_);
         h_ = nullptr;
         n_ = 0;
+        forget();
     }
     bool valid() const { return h_ != nullptr; }
     std::uint64_t size() const { return n_; }
@@ -76,6 +85,101 @@ class device_index_t
         if (h_) check(pcpx_index_rebuild(h_, xyz, n, grid6 ? &p : nullptr), "pcpx_index_rebuild");
         else check(pcpx_index_create(xyz, n, grid6 ? &p : nullptr, device, &h_), "pcpx_index_create");
         check(pcpx_index_size(h_, &n_), "pcpx_index_size");
+        forget();
+        xyz_  = xyz;  // the owner keeps the coordinates alive and rebuilds after any change (see the containers)
+        n_in_ = n;
+    }
+
+    // ---- per-point calls of an unchanged reference caller -------------------------------------------------
+    // `nearest_neighbours(p, k)` inside a loop over the cloud's own points (examples/simple_example.cpp:83-99) is one
+    // GPU round trip per point if taken literally.  After `batch_after` single-query calls with the same (k, eps) the
+    // k nearest neighbours of EVERY indexed point are computed in one launch and kept on the host; a later call whose
+    // target has exactly the coordinates of an indexed point is answered from those rows (the row of a point depends on
+    // its coordinates only: the eps-box test excludes by position, not by index), any other target takes the
+    // single-query path.  Same results either way.  The same is done for sphere ranges of one radius.
+    static constexpr unsigned batch_after         = 16;
+    static constexpr std::uint64_t max_cache_ints = 1ull << 28;  // 1 GiB of indices at most
+
+    // row of k nearest neighbours of q (indices into the input array)
+    std::vector<std::uint32_t> knn_one(float const* q, std::uint32_t k, float eps) const
+    {
+        std::vector<std::uint32_t> out;
+        if (!h_ || k == 0) return out;
+        {
+            std::lock_guard<std::mutex> lock(*mu_);
+            if (!(knn_.ready && knn_.k == k && knn_.eps == eps))
+            {
+                if (knn_.k != k || knn_.eps != eps) knn_ = knn_cache_t{};
+                knn_.k   = k;
+                knn_.eps = eps;
+                if (!knn_.failed && ++knn_.calls >= batch_after && xyz_ && n_in_ * k <= max_cache_ints)
+                {
+                    build_lookup();
+                    knn_.rows = knn_self(k, eps, n_in_);
+                    knn_.ready = true;
+                }
+            }
+            if (knn_.ready && knn_.k == k && knn_.eps == eps)
+            {
+                std::int64_t const i = find(q);
+                if (i >= 0)
+                {
+                    auto const* row = knn_.rows.idx.data() + static_cast<std::size_t>(i) * k;
+                    out.assign(row, row + knn_.rows.count[static_cast<std::size_t>(i)]);
+                    return out;
+                }
+            }
+        }
+        out.resize(k);
+        std::uint32_t count = 0;
+        check(pcpx_knn_batch(h_, q, 1, k, eps, out.data(), &count, nullptr), "pcpx_knn_batch");
+        out.resize(count);
+        return out;
+    }
+
+    // indices of the points inside the sphere (centre c, radius r)
+    std::vector<std::uint32_t> range_sphere_one(float const* c, float r) const
+    {
+        std::vector<std::uint32_t> out;
+        if (!h_) return out;
+        {
+            std::lock_guard<std::mutex> lock(*mu_);
+            if (!(range_.ready && range_.radius == r))
+            {
+                if (range_.radius != r) range_ = range_cache_t{};
+                range_.radius = r;
+                if (!range_.failed && ++range_.calls >= batch_after && xyz_ && n_in_ > 0)
+                {
+                    build_lookup();
+                    std::vector<std::uint32_t> counts(static_cast<std::size_t>(n_in_));
+                    check(pcpx_range_count_batch(h_, xyz_, n_in_, r, counts.data()), "pcpx_range_count_batch");
+                    std::uint64_t total = 0;
+                    for (auto v : counts) total += v;
+                    if (total <= max_cache_ints)
+                    {
+                        range_.off.assign(static_cast<std::size_t>(n_in_) + 1, 0);
+                        range_.idx.resize(static_cast<std::size_t>(total));
+                        check(pcpx_range_sphere_batch(h_, xyz_, nullptr, r, n_in_, range_.off.data(), range_.idx.data(), total),
+                              "pcpx_range_sphere_batch");
+                        range_.ready = true;
+                    }
+                    else range_.failed = true;
+                }
+            }
+            if (range_.ready && range_.radius == r)
+            {
+                std::int64_t const i = find(c);
+                if (i >= 0)
+                {
+                    out.assign(range_.idx.begin() + static_cast<std::ptrdiff_t>(range_.off[static_cast<std::size_t>(i)]),
+                               range_.idx.begin() + static_cast<std::ptrdiff_t>(range_.off[static_cast<std::size_t>(i) + 1]));
+                    return out;
+                }
+            }
+        }
+        std::vector<std::uint64_t> off;
+        range_spheres(c, &r, 1, off, out);
+        return out;
     }
 
     std::array<float, 6> bbox() const
@@ -176,8 +280,74 @@ class device_index_t
     pcpx_index* handle() const { return h_; }
 
   private:
+    struct knn_cache_t
+    {
+        std::uint32_t k = 0;
+        float eps       = 0.f;
+        unsigned calls  = 0;
+        bool ready = false, failed = false;
+        knn_result_t rows;
+    };
+    struct range_cache_t
+    {
+        float radius   = -1.f;
+        unsigned calls = 0;
+        bool ready = false, failed = false;
+        std::vector<std::uint64_t> off;
+        std::vector<std::uint32_t> idx;
+    };
+
+    void forget()
+    {
+        xyz_  = nullptr;
+        n_in_ = 0;
+        lookup_.clear();
+        knn_   = knn_cache_t{};
+        range_ = range_cache_t{};
+    }
+    static std::uint64_t hash3(float const* p)
+    {
+        std::uint32_t b[3];
+        std::memcpy(b, p, sizeof b);
+        std::uint64_t h = (static_cast<std::uint64_t>(b[0]) * 0x9E3779B97F4A7C15ull) ^ (static_cast<std::uint64_t>(b[1]) * 0xC2B2AE3D27D4EB4Full) ^
+                          (static_cast<std::uint64_t>(b[2]) * 0x165667B19E3779F9ull);
+        return h ^ (h >> 29);
+    }
+    // coordinates (bit patterns) -> first index holding them: open addressing, built once per index
+    void build_lookup() const
+    {
+        if (!lookup_.empty() || !xyz_) return;
+        std::size_t cap = 16;
+        while (cap < 2 * static_cast<std::size_t>(n_in_)) cap <<= 1;
+        lookup_.assign(cap, 0xFFFFFFFFu);
+        for (std::uint64_t i = 0; i < n_in_; ++i)
+        {
+            std::size_t s = static_cast<std::size_t>(hash3(xyz_ + 3 * i)) & (cap - 1);
+            while (lookup_[s] != 0xFFFFFFFFu && std::memcmp(xyz_ + 3 * lookup_[s], xyz_ + 3 * i, 12) != 0) s = (s + 1) & (cap - 1);
+            if (lookup_[s] == 0xFFFFFFFFu) lookup_[s] = static_cast<std::uint32_t>(i);
+        }
+    }
+    std::int64_t find(float const* q) const
+    {
+        if (lookup_.empty()) return -1;
+        std::size_t const cap = lookup_.size();
+        std::size_t s         = static_cast<std::size_t>(hash3(q)) & (cap - 1);
+        while (lookup_[s] != 0xFFFFFFFFu)
+        {
+            if (std::memcmp(xyz_ + 3 * lookup_[s], q, 12) == 0) return lookup_[s];
+            s = (s + 1) & (cap - 1);
+        }
+        return -1;
+    }
+
     pcpx_index* h_   = nullptr;
     std::uint64_t n_ = 0;
+    float const* xyz_     = nullptr;  // coordinates the index was built from (owned by the container)
+    std::uint64_t n_in_   = 0;
+    mutable std::vector<std::uint32_t> lookup_;
+    mutable knn_cache_t knn_;
+    mutable range_cache_t range_;
+    mutable std::unique_ptr<std::mutex> mu_ = std::make_unique<std::mutex>();
 };
 
 } // namespace gpu

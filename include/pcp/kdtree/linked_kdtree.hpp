@@ -95,8 +95,8 @@ class basic_linked_kdtree_t
     {
         if (k == 0 || storage_.empty()) return {};
         float const q[3] = {static_cast<float>(target[0]), static_cast<float>(target[1]), static_cast<float>(target[2])};
-        auto const r = index().knn(q, 1, static_cast<std::uint32_t>(k), static_cast<float>(eps));
-        return gather(r.idx.data(), r.count[0]);
+        auto const row = index().knn_one(q, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+        return gather(row.data(), row.size());
     }
     std::vector<element_type> nearest_neighbours(element_type const& element_target, std::size_t k,
                                                  coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
@@ -119,8 +119,7 @@ class basic_linked_kdtree_t
         {
             float const c[3] = {static_cast<float>(range.position[0]), static_cast<float>(range.position[1]),
                                 static_cast<float>(range.position[2])};
-            float const r = static_cast<float>(range.radius);
-            index().range_spheres(c, &r, 1, off, idx);
+            idx = index().range_sphere_one(c, static_cast<float>(range.radius));
         }
         else if constexpr (std::is_same_v<Range, aabb_type>)
         {

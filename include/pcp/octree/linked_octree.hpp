@@ -149,8 +149,8 @@ class basic_linked_octree_t
     {
         if (k == 0 || elements_.empty()) return {};
         float const q[3] = {static_cast<float>(target.x()), static_cast<float>(target.y()), static_cast<float>(target.z())};
-        auto const r = index().knn(q, 1, static_cast<std::uint32_t>(k), static_cast<float>(eps));
-        return gather(r.idx.data(), r.count[0]);
+        auto const row = index().knn_one(q, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+        return gather(row.data(), row.size());
     }
 
     // k nearest neighbours of one of the container's own elements, located through the point-view map the
@@ -159,8 +159,8 @@ class basic_linked_octree_t
     {
         if (k == 0 || elements_.empty() || !point_of_) return {};
         auto const q = point_of_(e);
-        auto const r = index().knn(q.data(), 1, static_cast<std::uint32_t>(k), static_cast<float>(eps));
-        return gather(r.idx.data(), r.count[0]);
+        auto const row = index().knn_one(q.data(), static_cast<std::uint32_t>(k), static_cast<float>(eps));
+        return gather(row.data(), row.size());
     }
 
     // every element whose point satisfies range.contains(point)
@@ -174,8 +174,7 @@ class basic_linked_octree_t
         {
             float const c[3] = {static_cast<float>(range.position.x()), static_cast<float>(range.position.y()),
                                 static_cast<float>(range.position.z())};
-            float const r = static_cast<float>(range.radius);
-            index().range_spheres(c, &r, 1, off, idx);
+            idx = index().range_sphere_one(c, static_cast<float>(range.radius));
         }
         else if constexpr (std::is_same_v<Range, aabb_type>)
         {

@@ -32,7 +32,10 @@
  *   - Functions return PCPX_OK (0) or a negative pcpx_status; pcpx_last_error() gives the text of
  *     the calling thread's last failure.  Nothing throws across this boundary.
  *   - `*_dev` variants take DEVICE pointers and a hipStream_t (as void*); they enqueue work on that
- *     stream and return without synchronising.  The others take HOST pointers and are synchronous.
+ *     stream and return without synchronising.  A NULL stream is the legacy default stream (ordered against
+ *     the caller's other default-stream work), never a private one.  The others take HOST pointers and are
+ *     synchronous; they run on a stream of their own.  Every entry point restores the calling thread's
+ *     current device before it returns.
  *   - There is no CPU fallback: without a usable HIP device every compute entry point fails
  *     with PCPX_ERR_DEVICE.
  */
@@ -46,7 +49,7 @@
 extern "C" {
 #endif
 
-#define PCPX_ABI_VERSION 1
+#define PCPX_ABI_VERSION 2
 
 typedef enum pcpx_status {
     PCPX_OK = 0,
@@ -185,11 +188,18 @@ int pcpx_normals_from_knn(pcpx_index* idx, const uint32_t* nbr_idx, const uint32
                           uint32_t k, float* out_normals, float* opt_out_evals);
 /* estimate_normal over an arbitrary point set (no index needed): xyz is m x 3. */
 int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_normal[3]);
+/* The same for many point sets in one launch -- what algorithm::estimate_normals does with an arbitrary (user) knn_map:
+ * neighbourhood r = points [offsets[r], offsets[r+1]) of xyz (CSR, nrows + 1 offsets); out_normals is nrows x 3. */
+int pcpx_estimate_normals_batch(const float* xyz, const uint64_t* offsets, uint64_t nrows, int device,
+                                float* out_normals);
 
 /* ---- multi-GPU helper --------------------------------------------------------------------- */
 /* Contiguous, 64-aligned shard of the Morton-sorted query order for `rank` of `world`. */
 int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count);
 
+/* The host-pointer entry points stage through device buffers that stay with the handle between calls (no
+ * hipMalloc / hipFree per call); this releases the ones not in use.  pcpx_index_destroy releases everything. */
+int pcpx_index_trim(pcpx_index* idx);
 /* Block until everything enqueued on the index's stream has finished. */
 int pcpx_index_synchronize(pcpx_index* idx);
 

@@ -10,6 +10,7 @@ f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 
+ABI_VERSION = 2  # include/pcpx.h PCPX_ABI_VERSION
 PCPX_OK = 0
 PCPX_ERR_INVALID = -1
 PCPX_ERR_DEVICE = -2
@@ -50,6 +51,8 @@ SIGNATURES = {
     "pcpx_index_rebuild_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BuildParams)]),
     "pcpx_index_destroy": (None, [C.c_void_p]),
     "pcpx_index_size": (C.c_int, [C.c_void_p, u64p]),
+    "pcpx_index_trim": (C.c_int, [C.c_void_p]),
+    "pcpx_estimate_normals_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "pcpx_index_bbox": (C.c_int, [C.c_void_p, f32p]),
     "pcpx_bounding_box": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),
     "pcpx_bounding_box_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
@@ -127,7 +130,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pcpx_abi_version() != 1:
+    if lib.pcpx_abi_version() != ABI_VERSION:
         raise ImportError("libpcpx.so ABI version mismatch")
     _lib = lib
     return lib

@@ -3,7 +3,9 @@
 // enqueue on the index's stream.  No CPU fallback exists: every compute call needs a HIP device.
 #include "pcpx_internal.h"
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <mutex>
 #include <new>
@@ -12,6 +14,7 @@
 namespace pcpx {
 
 static thread_local std::string g_err;
+static const bool g_few_no_poll = std::getenv("PCPX_FEW_NO_POLL") != nullptr;  // diagnostic: wait on the stream instead
 
 void set_error(const char* fmt, ...)
 {
@@ -31,28 +34,123 @@ int check_hip(hipError_t e, const char* what, const char* file, int line)
     return (e == hipErrorOutOfMemory) ? PCPX_ERR_ALLOC : PCPX_ERR_DEVICE;
 }
 
+// ---- DevPool / PinnedStage (pcpx_internal.h) --------------------------------------------------------
+void* DevPool::acquire(size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    int best = -1;
+    for (size_t i = 0; i < blocks.size(); ++i)  // best fit among the free blocks that are not wastefully large
+        if (!blocks[i].used && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + (1u << 20) &&
+            (best < 0 || blocks[i].bytes < blocks[static_cast<size_t>(best)].bytes))
+            best = static_cast<int>(i);
+    if (best >= 0) {
+        blocks[static_cast<size_t>(best)].used = true;
+        return blocks[static_cast<size_t>(best)].p;
+    }
+    void* p = nullptr;
+    const size_t rounded = (bytes + 4095) / 4096 * 4096;
+    hipError_t e = hipMalloc(&p, rounded);
+    if (e != hipSuccess) {  // give back what is cached and try once more
+        (void)hipGetLastError();
+        trim();
+        e = hipMalloc(&p, rounded);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu bytes) failed: %s", rounded, hipGetErrorString(e));
+        return nullptr;
+    }
+    blocks.push_back(Block{p, rounded, true});
+    return p;
+}
+void DevPool::release(void* p)
+{
+    for (auto& b : blocks)
+        if (b.p == p) {
+            b.used = false;
+            return;
+        }
+}
+void DevPool::trim()
+{
+    size_t keep = 0;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        if (blocks[i].used) blocks[keep++] = blocks[i];
+        else (void)hipFree(blocks[i].p);
+    }
+    blocks.resize(keep);
+}
+size_t DevPool::cached_bytes() const
+{
+    size_t t = 0;
+    for (auto const& b : blocks) t += b.bytes;
+    return t;
+}
+DevPool::~DevPool()
+{
+    for (auto& b : blocks) (void)hipFree(b.p);
+}
+int PinnedStage::ensure(size_t need)
+{
+    if (need <= bytes) return PCPX_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    const size_t want = need < (1u << 16) ? (1u << 16) : (need + 4095) / 4096 * 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        p = nullptr;
+        (void)hipGetLastError();
+        set_error("hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return PCPX_ERR_ALLOC;
+    }
+    bytes = want;
+    return PCPX_OK;
+}
+PinnedStage::~PinnedStage()
+{
+    if (p) (void)hipHostFree(p);
+}
+
 namespace {
 
-// RAII device buffer for the host-pointer entry points
+// RAII device buffer for the host-pointer entry points: a block of the owner's pool (no hipMalloc / hipFree per call);
+// returned to the pool on scope exit -- every such function synchronises its stream before it returns
 struct DevBuf {
     void* p = nullptr;
+    DevPool* pool = nullptr;
+    explicit DevBuf(DevPool& owner) : pool(&owner) {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf()
     {
-        if (p) (void)hipFree(p);
+        if (p) pool->release(p);
     }
     int alloc(size_t bytes)
     {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-            return PCPX_ERR_ALLOC;
-        }
-        return PCPX_OK;
+        p = pool->acquire(bytes);
+        return p ? PCPX_OK : PCPX_ERR_ALLOC;
     }
     template <class T>
     T* as() const { return static_cast<T*>(p); }
 };
+
+// entry points without a handle (bounding box of a host array, one normal, the sort diagnostic) share one pool and one
+// pinned stage per device; they hold its mutex for their duration
+struct DeviceShared {
+    std::mutex mu;
+    DevPool pool;
+    PinnedStage pinned;
+};
+DeviceShared& shared_of(int device)
+{
+    static std::mutex table_mu;
+    static std::vector<DeviceShared*> table;  // never freed: the HIP runtime may be gone at exit
+    std::lock_guard<std::mutex> lock(table_mu);
+    if (static_cast<size_t>(device) >= table.size()) table.resize(static_cast<size_t>(device) + 1, nullptr);
+    if (!table[static_cast<size_t>(device)]) table[static_cast<size_t>(device)] = new DeviceShared();
+    return *table[static_cast<size_t>(device)];
+}
 
 int select_device(int device)
 {
@@ -158,7 +256,7 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
     if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
-    delete ix;
+    delete ix;  // (the pool and the pinned stage free their memory in their destructors, while the device is still current)
 }
 
 int exclusive_scan_host(const std::vector<u32>& cnt, u64* offsets)
@@ -226,7 +324,7 @@ static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_bui
         }
         ix->own_stream = true;
     }
-    DevBuf staged;
+    DevBuf staged(ix->pool);
     const float* d_src = xyz;
     if (!on_device && n > 0) {
         if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) {
@@ -268,7 +366,7 @@ int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_b
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !xyz) return PCPX_ERR_INVALID;
-    DevBuf staged;
+    DevBuf staged(ix->pool);
     if (n > 0) {
         if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
         PCPX_HIP(hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
@@ -303,6 +401,17 @@ int pcpx_index_bbox(pcpx_index* h, float out6[6])
     std::memcpy(out6, reinterpret_cast<Index*>(h)->bbox, 6 * sizeof(float));
     return PCPX_OK;
 }
+int pcpx_index_trim(pcpx_index* h)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    ix->pool.trim();
+    return PCPX_OK;
+}
 int pcpx_index_synchronize(pcpx_index* h)
 {
     Index* ix = reinterpret_cast<Index*>(h);
@@ -321,12 +430,14 @@ int pcpx_bounding_box_dev(const float* d_xyz, uint64_t n, int device, void* stre
     if (st != PCPX_OK) return st;
     if (!d_out6 || (n > 0 && !d_xyz)) return PCPX_ERR_INVALID;
     // d_out6 must have room for the 6 floats; the encoded scratch is a temporary
-    DevBuf enc;
-    if ((st = enc.alloc(8 * sizeof(u32))) != PCPX_OK) return st;
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    DevBuf enc(shared.pool);
+    if ((st = enc.alloc(64 * sizeof(u32))) != PCPX_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
     st = device_bbox(d_xyz, n, s, enc.as<u32>(), d_out6);
     if (st != PCPX_OK) return st;
-    PCPX_HIP(hipStreamSynchronize(s));  // enc is freed on return
+    PCPX_HIP(hipStreamSynchronize(s));  // enc goes back to the pool on return
     return PCPX_OK;
 }
 int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6])
@@ -335,12 +446,15 @@ int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6])
     int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (!out6 || (n > 0 && !xyz)) return PCPX_ERR_INVALID;
-    DevBuf pts, box;
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    DevBuf pts(shared.pool), box(shared.pool);
     if ((st = pts.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
-    if ((st = box.alloc(6 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = box.alloc(64 * sizeof(u32))) != PCPX_OK) return st;
     if (n > 0) PCPX_HIP(hipMemcpy(pts.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
-    if ((st = pcpx_bounding_box_dev(pts.as<float>(), n, device, nullptr, box.as<float>())) != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpy(out6, box.p, 6 * sizeof(float), hipMemcpyDeviceToHost));
+    float* d_out = box.as<float>() + 32;
+    if ((st = device_bbox(pts.as<float>(), n, nullptr, box.as<u32>(), d_out)) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpy(out6, d_out, 6 * sizeof(float), hipMemcpyDeviceToHost));
     return PCPX_OK;
 }
 
@@ -369,6 +483,56 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
     return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
 }
 
+// Self queries with HOST outputs (pcpx_knn_self, pcpx_normals_knn_self): device staging from the handle's pool (no
+// hipMalloc / hipFree per call), one fused launch, one copy per output.  Rows are n x k x 4 bytes: at 10 M points and
+// k = 15 the copy to the host (760 MB, ~13.6 ms at this box's 56 GB/s) outweighs the kernel (~5 ms).  The two cannot
+// overlap: the kernel walks the curve order and writes row i = input point i, i.e. it scatters over the whole output,
+// so no part of an output array is final before the launch ends.  (Tried and measured, profiles/experiments/README.md:
+// chunks of the INPUT order through the batch-query form, each chunk's copy overlapping the next chunk's kernels --
+// a chunk's queries are ten times sparser than the cloud, a wave's 64 queries then share little of their search
+// regions, and the kernels alone took 25.7 ms against 5.3 ms.)
+constexpr u64 FEW_QUERIES_MAX = 512;  // up to here pcpx_knn_batch takes the latency path
+
+// any of out_normals / out_idx / out_d2 may be null (out_cnt is required with out_idx)
+static int self_queries_to_host(Index* ix, u32 k, float eps, float* out_normals, u32* out_idx, u32* out_cnt, float* out_d2)
+{
+    int st;
+    const u64 rows = ix->n_in;
+    if (rows == 0) return PCPX_OK;
+    const bool want_rows = out_idx != nullptr;
+    DevBuf dn(ix->pool), di(ix->pool), dc(ix->pool), dd(ix->pool);
+    if (out_normals && (st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
+    if (want_rows && (st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK) return st;
+    if ((want_rows || out_cnt) && (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
+    if (out_d2 && (st = dd.alloc(rows * k * sizeof(float))) != PCPX_OK) return st;
+    if (ix->n != ix->n_in) {  // rows of dropped (out-of-grid) points: count 0, padding
+        if (dn.p) PCPX_HIP(hipMemsetAsync(dn.p, 0, rows * 3 * sizeof(float), ix->stream));
+        if (di.p) PCPX_HIP(hipMemsetAsync(di.p, 0xFF, rows * k * sizeof(u32), ix->stream));
+        if (dc.p) PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
+        if (dd.p) PCPX_HIP(hipMemsetAsync(dd.p, 0x7F, rows * k * sizeof(float), ix->stream));
+    }
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    KnnOutputs o;
+    o.idx = di.as<u32>();
+    o.cnt = dc.as<u32>();
+    o.d2 = dd.as<float>();
+    o.normals = dn.as<float>();
+    DevBuf srows(ix->pool);
+    if (k > 32 && out_normals && !want_rows) {  // the multi-pass path builds normals from materialised rows
+        if ((st = srows.alloc(rows * k * sizeof(u32))) != PCPX_OK) return st;
+        o.idx = srows.as<u32>();
+        if (!dc.p && (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
+        o.cnt = dc.as<u32>();
+    }
+    if ((st = launch_knn(*ix, qv, true, 0, (ix->n + GROUP - 1) / GROUP, k, eps, o)) != PCPX_OK) return st;
+    if (out_normals) PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    if (want_rows) PCPX_HIP(hipMemcpyAsync(out_idx, di.p, rows * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    if (out_cnt) PCPX_HIP(hipMemcpyAsync(out_cnt, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    if (out_d2) PCPX_HIP(hipMemcpyAsync(out_d2, dd.p, rows * k * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
 int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count, float* out_d2)
 {
     Index* ix = reinterpret_cast<Index*>(h);
@@ -377,26 +541,11 @@ int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint3
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
-    u64 rows = ix->n_in;
-    if (k == 0) {
-        std::memset(out_count, 0, rows * sizeof(u32));
+    if (k == 0) {  // linked_octree_node.hpp:464: k == 0 -> {}
+        std::memset(out_count, 0, ix->n_in * sizeof(u32));
         return PCPX_OK;
     }
-    DevBuf di, dc, dd;
-    if ((st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK) return st;
-    if ((st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
-    if (out_d2 && (st = dd.alloc(rows * k * sizeof(float))) != PCPX_OK) return st;
-    // rows of dropped (out-of-grid) points: count 0, padding
-    PCPX_HIP(hipMemsetAsync(di.p, 0xFF, rows * k * sizeof(u32), ix->stream));
-    PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
-    if (out_d2) PCPX_HIP(hipMemsetAsync(dd.p, 0x7F, rows * k * sizeof(float), ix->stream));
-    st = pcpx_knn_self_dev(h, k, eps, 0, UINT64_MAX, di.as<u32>(), dc.as<u32>(), out_d2 ? dd.as<float>() : nullptr);
-    if (st != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(out_idx, di.p, rows * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
-    PCPX_HIP(hipMemcpyAsync(out_count, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
-    if (out_d2) PCPX_HIP(hipMemcpyAsync(out_d2, dd.p, rows * k * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-    PCPX_HIP(hipStreamSynchronize(ix->stream));
-    return PCPX_OK;
+    return self_queries_to_host(ix, k, eps, nullptr, out_idx, out_count, out_d2);
 }
 
 int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_t k, float eps, uint32_t* d_out_idx,
@@ -432,7 +581,47 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
         std::memset(out_count, 0, nq * sizeof(u32));
         return PCPX_OK;
     }
-    DevBuf dq, di, dc, dd;
+    if (nq <= FEW_QUERIES_MAX && k <= 32) {
+        // latency path (pcpx_few.hip): one wavefront per query, the queries and the rows live in the handle's pinned
+        // stage, which the device reads and writes in place -- no allocation, no copy, one launch, one synchronisation
+        const size_t o_done = 0, o_q = 64, o_idx = o_q + nq * 3 * sizeof(float), o_cnt = o_idx + nq * k * sizeof(u32),
+                     o_d2 = o_cnt + nq * sizeof(u32), o_flag = o_d2 + nq * k * sizeof(float), total = o_flag + nq * sizeof(u32);
+        const bool fresh = ix->pinned.bytes < total;
+        if ((st = ix->pinned.ensure(total)) != PCPX_OK) return st;
+        char* stage = static_cast<char*>(ix->pinned.p);
+        volatile u32* done = reinterpret_cast<volatile u32*>(stage + o_done);
+        if (fresh) *done = 0u;
+        if (!ix->d_queue) {  // the work-queue counters' allocation also holds the latency path's completion counter (word 15 of queue 7)
+            PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix->d_queue), 8 * 16 * sizeof(u32)));
+            PCPX_HIP(hipMemsetAsync(ix->d_queue, 0, 8 * 16 * sizeof(u32), ix->stream));
+        }
+        u32* done_count = ix->d_queue + 8 * 16 - 1;
+        std::memcpy(stage + o_q, q_xyz, nq * 3 * sizeof(float));
+        const u32 epoch = ++ix->few_epoch ? ix->few_epoch : ++ix->few_epoch;  // never 0
+        if ((st = launch_knn_few(*ix, reinterpret_cast<const float*>(stage + o_q), static_cast<u32>(nq), k, eps,
+                                 reinterpret_cast<u32*>(stage + o_idx), reinterpret_cast<u32*>(stage + o_cnt),
+                                 out_d2 ? reinterpret_cast<float*>(stage + o_d2) : nullptr, reinterpret_cast<u32*>(stage + o_flag),
+                                 done_count, const_cast<u32*>(done), epoch)) != PCPX_OK)
+            return st;
+        // poll the completion flag the kernel's last block stores into the pinned stage: no trip through the runtime's
+        // completion signal (the stream stays in order: the next launch on it runs after this kernel has retired)
+        bool seen = false;
+        if (!g_few_no_poll)
+            for (u32 spin = 0; spin < 400000u && !seen; ++spin) seen = *done == epoch;
+        if (!seen) PCPX_HIP(hipStreamSynchronize(ix->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        bool complete = true;
+        const u32* flags = reinterpret_cast<const u32*>(stage + o_flag);
+        for (u64 q = 0; q < nq; ++q) complete = complete && flags[q] == 0u;
+        if (complete) {
+            std::memcpy(out_idx, stage + o_idx, nq * k * sizeof(u32));
+            std::memcpy(out_count, stage + o_cnt, nq * sizeof(u32));
+            if (out_d2) std::memcpy(out_d2, stage + o_d2, nq * k * sizeof(float));
+            return PCPX_OK;
+        }
+        // a frontier or candidate list overflowed (a query far outside a large cloud, hundreds of exact ties): general path
+    }
+    DevBuf dq(ix->pool), di(ix->pool), dc(ix->pool), dd(ix->pool);
     if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = di.alloc(nq * k * sizeof(u32))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
@@ -476,7 +665,7 @@ int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_count) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
-    DevBuf dc;
+    DevBuf dc(ix->pool);
     if ((st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
     PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
     if ((st = pcpx_range_count_self_dev(h, radius, 0, UINT64_MAX, dc.as<u32>())) != PCPX_OK) return st;
@@ -494,7 +683,7 @@ int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (nq == 0) return PCPX_OK;
     if (!q_xyz || !out_count) return PCPX_ERR_INVALID;
-    DevBuf dq, dc;
+    DevBuf dq(ix->pool), dc(ix->pool);
     if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -521,7 +710,7 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
         out_offsets[0] = 0;
         return PCPX_OK;
     }
-    DevBuf dq, dr, dc, doff, dout;
+    DevBuf dq(ix->pool), dr(ix->pool), dc(ix->pool), doff(ix->pool), dout(ix->pool);
     if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -567,7 +756,7 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
         out_offsets[0] = 0;
         return PCPX_OK;
     }
-    DevBuf db, dc, doff, dout;
+    DevBuf db(ix->pool), dc(ix->pool), doff(ix->pool), dout(ix->pool);
     if ((st = db.alloc(nb * 6 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dc.alloc(nb * sizeof(u32))) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(db.p, boxes6, nb * 6 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -662,7 +851,7 @@ int pcpx_tangent_planes_knn_self(pcpx_index* h, uint32_t k, float eps, float* ou
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_centroids || !out_normals || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
-    DevBuf dc, dn;
+    DevBuf dc(ix->pool), dn(ix->pool);
     if ((st = dc.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
     PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * 3 * sizeof(float), ix->stream));
@@ -683,7 +872,7 @@ int pcpx_mean_knn_distance_self(pcpx_index* h, uint32_t k, float eps, float* out
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_mean_dist || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
-    DevBuf dm;
+    DevBuf dm(ix->pool);
     if ((st = dm.alloc(rows * sizeof(float))) != PCPX_OK) return st;
     PCPX_HIP(hipMemsetAsync(dm.p, 0, rows * sizeof(float), ix->stream));
     if ((st = pcpx_neighbourhoods_self_dev(h, k, eps, 0, UINT64_MAX, nullptr, nullptr, dm.as<float>())) != PCPX_OK) return st;
@@ -701,21 +890,7 @@ int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_norma
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
-    u64 rows = ix->n_in;
-    DevBuf dn, di, dc;
-    if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
-    if ((st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK) return st;
-    if ((st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
-    PCPX_HIP(hipMemsetAsync(dn.p, 0, rows * 3 * sizeof(float), ix->stream));
-    PCPX_HIP(hipMemsetAsync(di.p, 0xFF, rows * k * sizeof(u32), ix->stream));
-    PCPX_HIP(hipMemsetAsync(dc.p, 0, rows * sizeof(u32), ix->stream));
-    st = pcpx_normals_knn_self_dev(h, k, eps, 0, UINT64_MAX, dn.as<float>(), di.as<u32>(), dc.as<u32>());
-    if (st != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, rows * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-    if (opt_out_idx) PCPX_HIP(hipMemcpyAsync(opt_out_idx, di.p, rows * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
-    if (opt_out_count) PCPX_HIP(hipMemcpyAsync(opt_out_count, dc.p, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
-    PCPX_HIP(hipStreamSynchronize(ix->stream));
-    return PCPX_OK;
+    return self_queries_to_host(ix, k, eps, out_normals, opt_out_idx, opt_out_count, nullptr);
 }
 
 int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq, uint32_t k,
@@ -739,7 +914,7 @@ int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t
                 return PCPX_ERR_INVALID;
             }
     }
-    DevBuf di, dc, dn, de;
+    DevBuf di(ix->pool), dc(ix->pool), dn(ix->pool), de(ix->pool);
     if ((st = di.alloc(nq * k * sizeof(u32))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
     if ((st = dn.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
@@ -761,12 +936,53 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
     int st = dscope.select(device);
     if (st != PCPX_OK) return st;
     if (!out_normal || (m > 0 && !xyz)) return PCPX_ERR_INVALID;
-    DevBuf dp, dn;
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    if (m <= 4096) {
+        // one neighbourhood: no allocation and no copy -- the points go into the device's pinned stage, the kernel reads
+        // them and writes the normal there (host memory mapped into the device's address space)
+        if ((st = shared.pinned.ensure((m * 3 + 4) * sizeof(float))) != PCPX_OK) return st;
+        float* stage = static_cast<float*>(shared.pinned.p);
+        if (m > 0) std::memcpy(stage + 4, xyz, m * 3 * sizeof(float));
+        if ((st = launch_normal_single(stage + 4, m, stage, nullptr)) != PCPX_OK) return st;
+        PCPX_HIP(hipStreamSynchronize(nullptr));
+        std::memcpy(out_normal, stage, 3 * sizeof(float));
+        return PCPX_OK;
+    }
+    DevBuf dp(shared.pool), dn(shared.pool);
     if ((st = dp.alloc(m * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dn.alloc(3 * sizeof(float))) != PCPX_OK) return st;
-    if (m > 0) PCPX_HIP(hipMemcpy(dp.p, xyz, m * 3 * sizeof(float), hipMemcpyHostToDevice));
+    PCPX_HIP(hipMemcpy(dp.p, xyz, m * 3 * sizeof(float), hipMemcpyHostToDevice));
     if ((st = launch_normal_single(dp.as<float>(), m, dn.as<float>(), nullptr)) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpy(out_normal, dn.p, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PCPX_OK;
+}
+
+int pcpx_estimate_normals_batch(const float* xyz, const uint64_t* offsets, uint64_t nrows, int device, float* out_normals)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    if (nrows == 0) return PCPX_OK;
+    if (!offsets || !out_normals) return PCPX_ERR_INVALID;
+    for (u64 r = 0; r < nrows; ++r)
+        if (offsets[r + 1] < offsets[r]) {
+            set_error("pcpx_estimate_normals_batch: offsets must not decrease (row %llu)", static_cast<unsigned long long>(r));
+            return PCPX_ERR_INVALID;
+        }
+    const u64 total = offsets[nrows] - offsets[0];
+    if (total > 0 && !xyz) return PCPX_ERR_INVALID;
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    DevBuf dp(shared.pool), doff(shared.pool), dn(shared.pool);
+    if ((st = dp.alloc(total * 3 * sizeof(float))) != PCPX_OK || (st = doff.alloc((nrows + 1) * sizeof(u64))) != PCPX_OK ||
+        (st = dn.alloc(nrows * 3 * sizeof(float))) != PCPX_OK)
+        return st;
+    if (total > 0) PCPX_HIP(hipMemcpyAsync(dp.p, xyz + 3 * offsets[0], total * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    PCPX_HIP(hipMemcpyAsync(doff.p, offsets, (nrows + 1) * sizeof(u64), hipMemcpyHostToDevice, nullptr));
+    if ((st = launch_normals_csr(dp.as<float>(), doff.as<u64>(), nrows, dn.as<float>(), nullptr)) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(out_normals, dn.p, nrows * 3 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    PCPX_HIP(hipStreamSynchronize(nullptr));
     return PCPX_OK;
 }
 
@@ -778,14 +994,14 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_sta
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_stats || capacity < 16 || k == 0 || k > 16) return PCPX_ERR_INVALID;
-    DevBuf ds;
+    DevBuf ds(ix->pool);
     const size_t cap = 16 + 5 * 65536;  // 16 counters + 5-word records of up to 65536 persistent waves
     if ((st = ds.alloc(cap * sizeof(u64))) != PCPX_OK) return st;
     PCPX_HIP(hipMemsetAsync(ds.p, 0, cap * sizeof(u64), ix->stream));
     // capacity bit 63 set: "floor" mode -- start every lane from its true k-th distance (taken from a normal run first)
     const bool floor_mode = (capacity >> 63) != 0;
     capacity &= ~(1ull << 63);
-    DevBuf known;
+    DevBuf known(ix->pool);
     if (floor_mode) {
         if ((st = known.alloc(static_cast<size_t>(ix->n_in) * k * sizeof(float))) != PCPX_OK) return st;
         QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
@@ -900,7 +1116,7 @@ int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* 
         return PCPX_ERR_UNSUPPORTED;
     }
     const u64 rows = ix->n_in;
-    DevBuf dn, di, dc;
+    DevBuf dn(ix->pool), di(ix->pool), dc(ix->pool);
     if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK || (st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK ||
         (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK)
         return st;
@@ -929,7 +1145,7 @@ int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* no
         return PCPX_ERR_UNSUPPORTED;
     }
     const u64 rows = ix->n_in;
-    DevBuf dn, di, dc;
+    DevBuf dn(ix->pool), di(ix->pool), dc(ix->pool);
     if ((st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK || (st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK ||
         (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK)
         return st;
@@ -952,7 +1168,9 @@ int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n
     if (n > 0 && (!keys || !vals || !out_keys || !out_vals)) return PCPX_ERR_INVALID;
     size_t tb = 0;
     if ((st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, nullptr)) != PCPX_OK) return st;
-    DevBuf ki, ko, vi, vo, tmp;
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    DevBuf ki(shared.pool), ko(shared.pool), vi(shared.pool), vo(shared.pool), tmp(shared.pool);
     if ((st = ki.alloc(n * 8)) != PCPX_OK || (st = ko.alloc(n * 8)) != PCPX_OK || (st = vi.alloc(n * 4)) != PCPX_OK ||
         (st = vo.alloc(n * 4)) != PCPX_OK || (st = tmp.alloc(tb)) != PCPX_OK)
         return st;

@@ -36,21 +36,49 @@ __global__ void k_bbox_init(u32* enc6, u32* counter)
     else if (threadIdx.x == 6) *counter = 0u;
 }
 
+// Streaming min/max: the cloud is read as 16-byte vectors.  Four points are twelve floats = three float4, so after
+// peeling `head` points (which makes the address 16-byte aligned: 3 is invertible modulo 4) thread t owns point quads
+// t, t + stride, ... and every load instruction of a wave covers a contiguous run of memory (three interleaved 48-byte
+// strides).  Block-level reduction in LDS, then ONE set of six atomics per block (round 1: stride-3 scalar loads and six
+// atomics per wave -- 576 us for 10 M points, 2.6 % of the HBM rate).
+__device__ __forceinline__ void bbox_point(float (&mn)[3], float (&mx)[3], float x, float y, float z)
+{
+    if (x < mn[0]) mn[0] = x;
+    if (y < mn[1]) mn[1] = y;
+    if (z < mn[2]) mn[2] = z;
+    if (x > mx[0]) mx[0] = x;
+    if (y > mx[1]) mx[1] = y;
+    if (z > mx[2]) mx[2] = z;
+}
+
 __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, u64 n, u32* enc6)
 {
     float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(),
                    std::numeric_limits<float>::max()};
     float mx[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(),
                    std::numeric_limits<float>::lowest()};
-    for (u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x; i < n;
-         i += static_cast<u64>(gridDim.x) * blockDim.x) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float v = xyz[3 * i + a];
-            if (v < mn[a]) mn[a] = v;
-            if (v > mx[a]) mx[a] = v;
-        }
+    const u64 word = reinterpret_cast<uintptr_t>(xyz) >> 2;          // the array is 4-byte aligned
+    u64 head = ((4u - (word & 3u)) * 3u) & 3u;                       // points before the first 16-byte aligned point
+    if (head > n) head = n;
+    const u64 nquad = (n - head) >> 2;
+    const float4* v = reinterpret_cast<const float4*>(xyz + 3 * head);
+    const u64 gtid = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
+    const u64 gstride = static_cast<u64>(gridDim.x) * blockDim.x;
+    for (u64 q = gtid; q < nquad; q += gstride) {
+        const float4 a = v[3 * q], b = v[3 * q + 1], c = v[3 * q + 2];
+        bbox_point(mn, mx, a.x, a.y, a.z);
+        bbox_point(mn, mx, a.w, b.x, b.y);
+        bbox_point(mn, mx, b.z, b.w, c.x);
+        bbox_point(mn, mx, c.y, c.z, c.w);
     }
+    // the peeled points and the tail (fewer than 8 in all): the first threads of the grid take one each
+    const u64 tail0 = head + 4 * nquad;
+    const u64 loose = head + (n - tail0);
+    if (gtid < loose) {
+        const u64 i = gtid < head ? gtid : tail0 + (gtid - head);
+        bbox_point(mn, mx, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    }
+    __shared__ float red[4][6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -59,12 +87,21 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, u64
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
     }
+    const u32 w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&enc6[a], enc_f(mn[a]));
-            atomicMax(&enc6[3 + a], enc_f(mx[a]));
+            red[w][a] = mn[a];
+            red[w][3 + a] = mx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = static_cast<int>(threadIdx.x);
+        float r = red[0][a];
+        for (u32 i = 1; i < (blockDim.x >> 6); ++i) r = a < 3 ? fminf(r, red[i][a]) : fmaxf(r, red[i][a]);
+        if (a < 3) atomicMin(&enc6[a], enc_f(r));
+        else atomicMax(&enc6[a], enc_f(r));
     }
 }
 
@@ -217,8 +254,9 @@ int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_
 {
     k_bbox_init<<<1, 64, 0, s>>>(d_enc6, d_enc6 + 6);
     if (n > 0) {
-        u64 blocks = (n + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        u64 blocks = (n / 4 + 255) / 256;  // a thread takes four points per trip
+        if (blocks > 2048) blocks = 2048;   // 8 blocks per CU
+        if (blocks < 1) blocks = 1;
         k_bbox<<<static_cast<unsigned>(blocks), 256, 0, s>>>(d_xyz, n, d_enc6);
     }
     k_bbox_decode<<<1, 64, 0, s>>>(d_enc6, d_out6);

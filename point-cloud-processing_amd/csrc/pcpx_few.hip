@@ -1,0 +1,235 @@
+// pcpx_few.hip -- the LATENCY path: k nearest neighbours of a handful of query points.
+//
+// The reference's own benchmarks time ONE query per iteration (benchmark/spatial_data_structures_benchmark.cpp:243-264),
+// and unchanged callers ask per point (examples/simple_example.cpp:83-85).  The throughput kernel (pcpx_query.hip) gives
+// a query one lane and walks the tree step by dependent step: ~190 dependent record fetches for a lone query, and a sort
+// of the batch in front of it.  Here a whole wavefront serves one query and the parallelism is INSIDE the query:
+//
+//   1. beam descent: level by level keep the 8 nodes whose boxes are nearest to the query (32 child boxes tested by
+//      32 lanes at once, ranked by counting) -> 8 leaves = 64 points, one per lane; tau0 = k-th smallest distance among
+//      them: an upper bound of the true k-th distance;
+//   2. pruned breadth-first sweep: per level every child of the frontier is tested by its own lane against tau0, the
+//      survivors are compacted (ballot + prefix count) into the next frontier in LDS;
+//   3. the points of the surviving leaves, one per lane, with d2 <= tau0 outside the eps-box are the candidates (a
+//      superset of the answer); the k smallest by (d2, index) are found by counting ranks and written in order.
+//
+// About 2 x depth + 3 dependent memory round trips per query instead of ~190, no sort, no allocation, and the query
+// and the row can live in pinned host memory (the host-pointer entry points do exactly that: no copy is issued).
+// Arithmetic is the reference's (d = p - q, dx*dx + dy*dy + dz*dz in float32 without FMA, eps-box exclusion), rows are
+// ascending in (d2, index): identical to the throughput kernel's rows except for WHICH of several points tied exactly at
+// the k-th distance is kept -- unspecified in the reference too (linked_octree_node.hpp:479-489).
+// Capacity: k <= 32; a frontier of more than FRONTIER nodes or more than CANDS candidates (a query far outside a huge
+// cloud, hundreds of exact ties) sets the query's flag and the caller re-runs the batch through the general path.
+#include "pcpx_device.h"
+
+namespace pcpx {
+
+namespace {
+
+constexpr int BEAM = 8;
+constexpr int FRONTIER = 1024;
+constexpr int CANDS = 768;
+
+__device__ __forceinline__ float lane_value(float v, int j)
+{
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
+}
+
+// rank of this lane's value among the first `width` lanes (ties broken by lane): counting, no data movement
+template <int WIDTH>
+__device__ __forceinline__ u32 rank_among(float v, u32 lane)
+{
+    u32 r = 0;
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) {
+        const float o = lane_value(v, j);
+        r += (o < v || (o == v && static_cast<u32>(j) < lane)) ? 1u : 0u;
+    }
+    return r;
+}
+
+__device__ __forceinline__ u32 level_base(int d) { return d == 0 ? 0u : (0x55555555u >> (32 - 2 * d)); }
+
+__global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restrict__ queries, u32 nq, u32 k, float eps,
+                                                u32* __restrict__ out_idx, u32* __restrict__ out_cnt, float* __restrict__ out_d2,
+                                                u32* __restrict__ flags, u32* __restrict__ done_count, u32* __restrict__ done_flag,
+                                                u32 epoch)
+{
+    __shared__ u32 front[2][FRONTIER];
+    __shared__ u64 cand[CANDS];
+    const u32 lane = threadIdx.x;
+    const u32 qi = blockIdx.x;
+    if (qi >= nq) return;
+    const float inf = std::numeric_limits<float>::infinity();
+    // Completion signal for a host that polls instead of waiting on the stream: when the last block of the launch has
+    // made its row visible system-wide it stores the launch's epoch into *done_flag (pinned host memory).
+    auto signal_done = [&]() {
+        __threadfence_system();  // this block's row, count and flag are visible to the host before the counter moves
+        if (lane == 0 && done_count) {
+            const u32 prev = atomicAdd(done_count, 1u);
+            if (prev == nq - 1u) {
+                *done_count = 0u;  // ready for the next launch on this stream
+                __threadfence_system();
+                __hip_atomic_store(done_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    const float qx = queries[3ull * qi], qy = queries[3ull * qi + 1], qz = queries[3ull * qi + 2];
+    u32* row_idx = out_idx + static_cast<u64>(qi) * k;
+    float* row_d2 = out_d2 ? out_d2 + static_cast<u64>(qi) * k : nullptr;
+    if (lane == 0) flags[qi] = 0u;
+    if (t.nleaves == 0) {
+        if (lane < k) {
+            row_idx[lane] = INVALID_ID;
+            if (row_d2) row_d2[lane] = inf;
+        }
+        if (lane == 0) out_cnt[qi] = 0u;
+        signal_done();
+        return;
+    }
+
+    // ---- 1. beam descent ----
+    u32 nbeam = 1;
+    if (lane == 0) front[0][0] = 0u;
+    __syncthreads();
+    int cur = 0;
+    for (int d = 0; d < t.depth; ++d) {
+        float bd = inf;
+        u32 node = 0;
+        if (lane < 4u * nbeam) {
+            node = front[cur][lane >> 2] * 4u + (lane & 3u);  // local index at level d + 1
+            const NodeBox b = t.nodes[level_base(d + 1) + node];
+            const float v = box_d2(b, qx, qy, qz);
+            bd = v == v ? v : inf;  // padding nodes (NaN) rank last
+        }
+        const u32 r = rank_among<4 * BEAM>(bd, lane);
+        const u64 keep = __builtin_amdgcn_ballot_w64(lane < 4u * nbeam && bd < inf && r < BEAM);
+        __syncthreads();
+        if (lane < 4u * nbeam && bd < inf && r < BEAM) front[cur ^ 1][r] = node;
+        nbeam = static_cast<u32>(__builtin_popcountll(keep));  // ranks of the finite values are 0 .. count-1: dense
+        cur ^= 1;
+        __syncthreads();
+    }
+    // the beam's leaves: up to 64 points, one per lane
+    float tau0 = inf;
+    {
+        float d2 = inf;
+        if (lane < 8u * nbeam) {
+            const u32 leaf = front[cur][lane >> 3];
+            if (leaf < t.nleaves) {
+                const Leaf& lf = t.leaves[leaf];
+                const float dx = lf.x[lane & 7u] - qx, dy = lf.y[lane & 7u] - qy, dz = lf.z[lane & 7u] - qz;
+                const float v = sq3(dx, dy, dz);
+                const float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                if (v == v && m >= eps) d2 = v;  // NaN: padding slot of the last leaf
+            }
+        }
+        const u32 r = rank_among<64>(d2, lane);
+        const u64 kth = __builtin_amdgcn_ballot_w64(r == k - 1u && d2 < inf);
+        if (kth != 0ull) tau0 = lane_value(d2, __builtin_ctzll(kth));
+    }
+
+    // ---- 2. pruned breadth-first sweep ----
+    __syncthreads();
+    if (lane == 0) front[0][0] = 0u;
+    __syncthreads();
+    cur = 0;
+    u32 m = 1;  // frontier size at level d
+    bool overflow = false;
+    {   // the root itself
+        const NodeBox rb = t.nodes[0];
+        const float v = box_d2(rb, qx, qy, qz);
+        if (!(v <= tau0)) m = 0;
+    }
+    for (int d = 0; d < t.depth && m > 0; ++d) {
+        u32 next = 0;
+        for (u32 c0 = 0; c0 < 4u * m; c0 += 64u) {
+            const u32 c = c0 + lane;
+            bool need = false;
+            u32 node = 0;
+            if (c < 4u * m) {
+                node = front[cur][c >> 2] * 4u + (c & 3u);
+                const NodeBox b = t.nodes[level_base(d + 1) + node];
+                need = box_d2(b, qx, qy, qz) <= tau0;  // false for padding nodes (NaN)
+            }
+            const u64 mask = __builtin_amdgcn_ballot_w64(need);
+            const u32 below = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mask), 0u));
+            const u32 slot = next + below;
+            if (need && slot < FRONTIER) front[cur ^ 1][slot] = node;
+            next += static_cast<u32>(__builtin_popcountll(mask));
+        }
+        if (next > FRONTIER) {
+            overflow = true;
+            next = FRONTIER;
+        }
+        m = next;
+        cur ^= 1;
+        __syncthreads();
+    }
+
+    // ---- 3. candidates: every point of the surviving leaves within tau0 and outside the eps-box ----
+    u32 nc = 0;
+    for (u32 c0 = 0; c0 < 8u * m; c0 += 64u) {
+        const u32 c = c0 + lane;
+        bool take = false;
+        u64 key = 0;
+        if (c < 8u * m) {
+            const u32 leaf = front[cur][c >> 3];
+            if (leaf < t.nleaves) {
+                const Leaf& lf = t.leaves[leaf];
+                const u32 s = c & 7u;
+                const float dx = lf.x[s] - qx, dy = lf.y[s] - qy, dz = lf.z[s] - qz;
+                const float v = sq3(dx, dy, dz);
+                const float mm = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                take = v <= tau0 && mm >= eps;  // NaN padding fails v <= tau0
+                key = (static_cast<u64>(__float_as_uint(v)) << 32) | lf.id[s];
+            }
+        }
+        const u64 mask = __builtin_amdgcn_ballot_w64(take);
+        const u32 below = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mask), 0u));
+        const u32 slot = nc + below;
+        if (take && slot < CANDS) cand[slot] = key;
+        nc += static_cast<u32>(__builtin_popcountll(mask));
+    }
+    if (nc > CANDS) {
+        overflow = true;
+        nc = CANDS;
+    }
+    __syncthreads();
+
+    // ---- the k smallest keys, by counting ranks (keys are distinct: the low word is the point's index) ----
+    const u32 found = nc < k ? nc : k;
+    for (u32 i = lane; i < nc; i += 64u) {
+        const u64 mine = cand[i];
+        u32 r = 0;
+        for (u32 j = 0; j < nc; ++j) r += cand[j] < mine ? 1u : 0u;
+        if (r < k) {
+            row_idx[r] = static_cast<u32>(mine);
+            if (row_d2) row_d2[r] = __uint_as_float(static_cast<u32>(mine >> 32));
+        }
+    }
+    for (u32 j = found + lane; j < k; j += 64u) {
+        row_idx[j] = INVALID_ID;
+        if (row_d2) row_d2[j] = inf;
+    }
+    if (lane == 0) {
+        out_cnt[qi] = found;
+        if (overflow) flags[qi] = 1u;
+    }
+    signal_done();
+}
+
+}  // namespace
+
+// queries (nq x 3), rows and flags may be device memory or pinned host memory mapped into the device
+int launch_knn_few(Index& ix, const float* q_aos, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2, u32* flags,
+                   u32* done_count, u32* done_flag, u32 epoch)
+{
+    if (nq == 0) return PCPX_OK;
+    ProfileScope prof(ix, PCPX_K_KNN);
+    k_knn_few<<<nq, 64, 0, ix.stream>>>(ix.view(), q_aos, nq, k, sanitize_eps(eps), out_idx, out_cnt, out_d2, flags, done_count, done_flag,
+                                        epoch);
+    return check_hip(hipGetLastError(), "k_knn_few launch", __FILE__, __LINE__);
+}
+
+}  // namespace pcpx

@@ -91,6 +91,33 @@ struct QueryView {
     u32 nq;
 };
 
+// Device allocations that outlive a call: the host-pointer entry points stage through device buffers, and a
+// hipMalloc / hipFree pair per buffer per call (hipFree synchronises the device) used to cost more than the kernels.
+// A pool belongs to one handle (or, for the entry points without a handle, to one device) and is only touched under
+// its owner's mutex; blocks are handed out best-fit and returned on scope exit, after the stream has been synchronised.
+struct DevPool {
+    struct Block {
+        void* p;
+        size_t bytes;
+        bool used;
+    };
+    std::vector<Block> blocks;
+    void* acquire(size_t bytes);  // nullptr (and the thread's error text set) when the device is out of memory
+    void release(void* p);
+    void trim();                  // frees every block that is not handed out
+    size_t cached_bytes() const;
+    ~DevPool();
+};
+
+// pinned host memory of a handle: staging for small transfers (a query point in, one row out) that the device reads and
+// writes in place, so a single-query call issues no copy at all
+struct PinnedStage {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    ~PinnedStage();
+};
+
 struct Index {
     // Entry points that take a handle hold this for their duration: the reference's containers are queried
     // concurrently from PSTL worker threads (estimate_normals.hpp:92), and the handle's scratch buffers, work
@@ -133,6 +160,10 @@ struct Index {
     // scratch for batch queries (grown on demand)
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+
+    DevPool pool;        // staging buffers of the host-pointer entry points
+    PinnedStage pinned;  // small-transfer staging
+    u32 few_epoch = 0;   // launch counter of the latency path (its completion flag carries the epoch)
 
     u64* sorted_codes() const { return d_codes[1]; }
     u32* perm() const { return d_vals[1]; }
@@ -186,6 +217,8 @@ int orient_normals_device(const float* d_xyz, u64 n, const u32* d_nbr, const u32
 // kNN + whatever per-neighbourhood products are requested (any pointer may be nullptr); all fused in k_knn
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
                const KnnOutputs& o);
+int launch_knn_few(Index& ix, const float* q_aos, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2, u32* flags,
+                   u32* done_count, u32* done_flag, u32 epoch);
 int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, const float* d_known_d2 = nullptr);
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
                        const float* d_radii, u32* d_out_cnt);
@@ -196,6 +229,7 @@ int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offs
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
                    float* d_out, float* d_evals, float* d_centroids = nullptr, float* d_meandist = nullptr);
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
+int launch_normals_csr(const float* d_xyz, const u64* d_offsets, u64 nrows, float* d_out, hipStream_t s);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
 
 }  // namespace pcpx

@@ -86,7 +86,42 @@ __global__ void k_normal_single(const float* __restrict__ xyz, u64 m, float* __r
     eig3_smallest(c00, c10, c20, c11, c21, c22, out3, ev);
 }
 
+// estimate_normal over many explicit point sets at once: row r = points [offsets[r], offsets[r+1]) of xyz (relative to
+// offsets[0]); one thread per row, same arithmetic and order as k_normal_single
+__global__ __launch_bounds__(256) void k_normals_csr(const float* __restrict__ xyz, const u64* __restrict__ offsets, u64 nrows,
+                                                     float* __restrict__ out)
+{
+    const u64 r = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
+    if (r >= nrows) return;
+    const u64 base = offsets[0], a = offsets[r] - base, b = offsets[r + 1] - base;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u64 j = a; j < b; ++j) {
+        float x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
+        if (j == a) { sx = x; sy = y; sz = z; }
+        else { sx += x; sy += y; sz += z; }
+    }
+    float fn = static_cast<float>(b - a);
+    float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    for (u64 j = a; j < b; ++j) {
+        float vx = xyz[3 * j] - mx, vy = xyz[3 * j + 1] - my, vz = xyz[3 * j + 2] - mz;
+        c00 += vx * vx; c10 += vy * vx; c11 += vy * vy; c20 += vz * vx; c21 += vz * vy; c22 += vz * vz;
+    }
+    float nrm[3], ev[3];
+    eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
+    out[3 * r] = nrm[0];
+    out[3 * r + 1] = nrm[1];
+    out[3 * r + 2] = nrm[2];
+}
+
 }  // namespace
+
+int launch_normals_csr(const float* d_xyz, const u64* d_offsets, u64 nrows, float* d_out, hipStream_t s)
+{
+    if (nrows == 0) return PCPX_OK;
+    k_normals_csr<<<static_cast<u32>((nrows + 255) / 256), 256, 0, s>>>(d_xyz, d_offsets, nrows, d_out);
+    return check_hip(hipGetLastError(), "k_normals_csr launch", __FILE__, __LINE__);
+}
 
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
                    float* d_out, float* d_evals, float* d_centroids, float* d_meandist)
