@@ -223,9 +223,9 @@ typedef struct pcpx_profile {
  * followed (capacity permitting) by {start, end (100 MHz ticks), groups done, slowest group ticks, its id}
  * of every persistent wave. */
 int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t* out_stats, uint64_t capacity);
-/* Diagnostic access to the build's radix sort: stable sort of (key, value) pairs by key. */
-int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
-                          uint32_t* out_vals);
+/* Diagnostic access to the build's radix sort: stable sort of 64-bit words by their bits [first_bit, 64)
+ * (first_bit a multiple of 8): words that agree on those bits keep their input order. */
+int pcpx_debug_sort_keys(const uint64_t* keys, uint64_t n, int first_bit, int device, uint64_t* out_keys);
 int pcpx_profile_begin(pcpx_index* idx);
 int pcpx_profile_end(pcpx_index* idx, pcpx_profile* out);
 

@@ -244,10 +244,8 @@ void free_index(Index* ix)
         (void)hipEventDestroy(iv.b);
     }
     (void)hipFree(ix->d_xyz);
-    for (int b = 0; b < 2; ++b) {
-        (void)hipFree(ix->d_codes[b]);
-        (void)hipFree(ix->d_vals[b]);
-    }
+    for (int b = 0; b < 2; ++b) (void)hipFree(ix->d_codes[b]);
+    (void)hipFree(ix->d_perm);
     (void)hipFree(ix->d_sort_tmp);
     (void)hipFree(ix->d_leaves);
     (void)hipFree(ix->d_nodes);
@@ -1159,30 +1157,29 @@ int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* no
     return PCPX_OK;
 }
 
-int pcpx_debug_sort_pairs(const uint64_t* keys, const uint32_t* vals, uint64_t n, int device, uint64_t* out_keys,
-                          uint32_t* out_vals)
+int pcpx_debug_sort_keys(const uint64_t* keys, uint64_t n, int first_bit, int device, uint64_t* out_keys)
 {
     DeviceScope dscope;
     int st = dscope.select(device);
     if (st != PCPX_OK) return st;
-    if (n > 0 && (!keys || !vals || !out_keys || !out_vals)) return PCPX_ERR_INVALID;
+    if (n > 0 && (!keys || !out_keys)) return PCPX_ERR_INVALID;
     size_t tb = 0;
-    if ((st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, nullptr)) != PCPX_OK) return st;
+    if ((st = sort_keys_u64(nullptr, tb, nullptr, nullptr, n, nullptr, first_bit)) != PCPX_OK) return st;
     DeviceShared& shared = shared_of(device);
     std::lock_guard<std::mutex> lock(shared.mu);
-    DevBuf ki(shared.pool), ko(shared.pool), vi(shared.pool), vo(shared.pool), tmp(shared.pool);
-    if ((st = ki.alloc(n * 8)) != PCPX_OK || (st = ko.alloc(n * 8)) != PCPX_OK || (st = vi.alloc(n * 4)) != PCPX_OK ||
-        (st = vo.alloc(n * 4)) != PCPX_OK || (st = tmp.alloc(tb)) != PCPX_OK)
-        return st;
-    if (n > 0) {
-        PCPX_HIP(hipMemcpy(ki.p, keys, n * 8, hipMemcpyHostToDevice));
-        PCPX_HIP(hipMemcpy(vi.p, vals, n * 4, hipMemcpyHostToDevice));
-    }
-    if ((st = sort_pairs_u64(tmp.p, tb, ki.as<u64>(), ko.as<u64>(), vi.as<u32>(), vo.as<u32>(), n, nullptr)) != PCPX_OK) return st;
+    DevBuf ki(shared.pool), ko(shared.pool), tmp(shared.pool);
+    if ((st = ki.alloc(n * 8)) != PCPX_OK || (st = ko.alloc(n * 8)) != PCPX_OK || (st = tmp.alloc(tb)) != PCPX_OK) return st;
+    if (n > 0) PCPX_HIP(hipMemcpy(ki.p, keys, n * 8, hipMemcpyHostToDevice));
+    if ((st = sort_keys_u64(tmp.p, tb, ki.as<u64>(), ko.as<u64>(), n, nullptr, first_bit)) != PCPX_OK) return st;
     PCPX_HIP(hipDeviceSynchronize());
     if (n > 0) {
+        u32 failed = 0;
+        PCPX_HIP(hipMemcpy(&failed, sort_failure_flag(tmp.p), sizeof(u32), hipMemcpyDeviceToHost));
+        if (failed) {
+            set_error("pcpx: internal error, the radix sort's look-back gave up");
+            return PCPX_ERR_DEVICE;
+        }
         PCPX_HIP(hipMemcpy(out_keys, ko.p, n * 8, hipMemcpyDeviceToHost));
-        PCPX_HIP(hipMemcpy(out_vals, vo.p, n * 4, hipMemcpyDeviceToHost));
     }
     return PCPX_OK;
 }

@@ -113,99 +113,115 @@ __global__ void k_bbox_decode(const u32* enc6, float* out6)
 // Curve key (pcpx_curve.h) of every point inside the grid; points outside (or NaN) get PAD_CODE and sort to the
 // end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive containment,
 // include/pcp/common/axis_aligned_bounding_box.hpp:111-125).
-__global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6,
-                                               u64* __restrict__ codes, u32* __restrict__ vals)
+__global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6, int idx_bits,
+                                               u64* __restrict__ codes)
 {
     u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
     if (i < n) {
         float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
         const bool ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
-        u64 c = PAD_CODE;
-        if (ok) c = curve_key(x, y, z, b0, b1, b2, b3, b4, b5);
-        codes[i] = c;
-        vals[i] = static_cast<u32>(i);
+        codes[i] = ok ? sort_word(curve_key(x, y, z, b0, b1, b2, b3, b4, b5), i, idx_bits) : (OUTSIDE_BIT | i);
     }
 }
 
-// number of inserted points = position of the first pad code in the sorted codes (one thread: a binary
+// number of inserted points = position of the first outside word in the sorted words (one thread: a binary
 // search; a per-wave atomic counter in k_codes serialises at ~90 atomics/us and cost 1.8 ms at 10 M points)
-__global__ void k_count_valid(const u64* __restrict__ sorted_codes, u32 n, u32* __restrict__ out)
+__global__ void k_count_valid(const u64* __restrict__ sorted_codes, u32 n, u32* __restrict__ out, const u32* __restrict__ sort_failed)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[1] = *sort_failed;  // travels to the host with the count
     u32 lo = 0, hi = n;
     while (lo < hi) {
         u32 m = lo + ((hi - lo) >> 1);
-        if (sorted_codes[m] != PAD_CODE) lo = m + 1;
+        if ((sorted_codes[m] & OUTSIDE_BIT) == 0ull) lo = m + 1;
         else hi = m;
     }
     *out = lo;
 }
 
-__global__ __launch_bounds__(256) void k_fill_leaves(const float* __restrict__ xyz, const u32* __restrict__ perm,
-                                                     u32 n, u32 nslots, Leaf* __restrict__ leaves)
+__device__ __forceinline__ NodeBox padding_node()
+{
+    NodeBox nb;
+    nb.lo[0] = nb.lo[1] = nb.lo[2] = 0.f;
+    nb.hi[0] = nb.hi[1] = nb.hi[2] = 0.f;
+    nb.poison = __builtin_nanf("");
+    nb.pad = 0.f;
+    return nb;
+}
+
+// min / max over the 8 lanes of a leaf (aligned groups of 8 lanes): two quad permutes and a half-row mirror
+__device__ __forceinline__ float leaf_min(float v)
+{
+    v = fminf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+    v = fminf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+    v = fminf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float leaf_max(float v)
+{
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));
+    return v;
+}
+
+// Leaf records (16 B per point, coalesced) from the sorted words -- the point's index is the word's low bits -- plus, in
+// the same pass, the sorted position -> input index table and the leaf's tight box (bottom level of the tree: min / max
+// over the leaf's 8 lanes).  Only REAL nodes are written, and the up to three padding siblings that complete the last
+// group of four (what a query can ever read): round 1 filled the whole power-of-four level, 134 MB at 10 M points.
+// nslots = 8 x (leaves rounded up to a multiple of 4).
+__global__ __launch_bounds__(256) void k_fill_leaves(const float* __restrict__ xyz, const u64* __restrict__ sorted_codes, int idx_bits,
+                                                     u32 n, u32 nleaves, u32 nslots, Leaf* __restrict__ leaves, u32* __restrict__ perm,
+                                                     NodeBox* __restrict__ level, bool write_padding)
 {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nslots) return;
     float x = __builtin_nanf(""), y = x, z = x;
     u32 id = INVALID_ID;
     if (p < n) {
-        id = perm[p];
+        id = static_cast<u32>(sorted_codes[p] & ((1ull << idx_bits) - 1ull));
         x = xyz[3 * static_cast<u64>(id)];
         y = xyz[3 * static_cast<u64>(id) + 1];
         z = xyz[3 * static_cast<u64>(id) + 2];
+        perm[p] = id;
     }
-    Leaf& lf = leaves[p / LEAF];
-    int s = p % LEAF;
-    lf.x[s] = x;
-    lf.y[s] = y;
-    lf.z[s] = z;
-    lf.id[s] = id;
-}
-
-// leaf-level nodes: slot j of the bottom level (node leaf0 + j); j >= nleaves are padding nodes
-__global__ __launch_bounds__(256) void k_leaf_boxes(const Leaf* __restrict__ leaves, u32 nleaves, u32 nslots,
-                                                    NodeBox* __restrict__ level)
-{
-    u32 l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= nslots) return;
-    float inf = std::numeric_limits<float>::infinity();
-    NodeBox nb;
-    nb.lo[0] = nb.lo[1] = nb.lo[2] = 0.f;
-    nb.hi[0] = nb.hi[1] = nb.hi[2] = 0.f;
-    nb.poison = __builtin_nanf("");
-    nb.pad = 0.f;
-    if (l < nleaves) {
-        float b[6] = {inf, inf, inf, -inf, -inf, -inf};
-        const Leaf& lf = leaves[l];
-#pragma unroll
-        for (int s = 0; s < LEAF; ++s) {  // NaN pads never win fminf/fmaxf
-            b[0] = fminf(b[0], lf.x[s]);
-            b[1] = fminf(b[1], lf.y[s]);
-            b[2] = fminf(b[2], lf.z[s]);
-            b[3] = fmaxf(b[3], lf.x[s]);
-            b[4] = fmaxf(b[4], lf.y[s]);
-            b[5] = fmaxf(b[5], lf.z[s]);
+    const u32 leaf = p / LEAF;
+    const int s = p % LEAF;
+    if (leaf < nleaves) {
+        Leaf& lf = leaves[leaf];
+        lf.x[s] = x;
+        lf.y[s] = y;
+        lf.z[s] = z;
+        lf.id[s] = id;
+    }
+    const float inf = std::numeric_limits<float>::infinity();
+    // (every lane of the 8-lane group takes part in the reduction, whatever it holds; nslots is a multiple of 8)
+    const float lx = leaf_min(p < n ? x : inf), ly = leaf_min(p < n ? y : inf), lz = leaf_min(p < n ? z : inf);
+    const float hx = leaf_max(p < n ? x : -inf), hy = leaf_max(p < n ? y : -inf), hz = leaf_max(p < n ? z : -inf);
+    if (s == 0) {
+        if (leaf < nleaves) {
+            NodeBox nb;
+            nb.lo[0] = lx; nb.lo[1] = ly; nb.lo[2] = lz;
+            nb.hi[0] = hx; nb.hi[1] = hy; nb.hi[2] = hz;
+            nb.poison = 0.f;
+            nb.pad = 0.f;
+            level[leaf] = nb;
+        } else if (write_padding) {
+            level[leaf] = padding_node();
         }
-        nb.lo[0] = b[0]; nb.lo[1] = b[1]; nb.lo[2] = b[2];
-        nb.hi[0] = b[3]; nb.hi[1] = b[4]; nb.hi[2] = b[5];
-        nb.poison = 0.f;
     }
-    level[l] = nb;
 }
 
 // one level up: node i = union of its 4 children (padding children are skipped)
-__global__ __launch_bounds__(256) void k_upper_boxes(const NodeBox* __restrict__ child, NodeBox* __restrict__ parent,
-                                                     u32 nparent)
+__device__ __forceinline__ NodeBox union_of_children(const NodeBox* __restrict__ child4)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nparent) return;
     float inf = std::numeric_limits<float>::infinity();
     float b[6] = {inf, inf, inf, -inf, -inf, -inf};
     bool any = false;
 #pragma unroll
     for (int c = 0; c < W; ++c) {
-        NodeBox cb = child[static_cast<u64>(i) * W + c];
+        NodeBox cb = child4[c];
         if (cb.poison == 0.f) {
             any = true;
             b[0] = fminf(b[0], cb.lo[0]);
@@ -221,7 +237,35 @@ __global__ __launch_bounds__(256) void k_upper_boxes(const NodeBox* __restrict__
     nb.hi[0] = any ? b[3] : 0.f; nb.hi[1] = any ? b[4] : 0.f; nb.hi[2] = any ? b[5] : 0.f;
     nb.poison = any ? 0.f : __builtin_nanf("");
     nb.pad = 0.f;
-    parent[i] = nb;
+    return nb;
+}
+
+// level d from level d + 1: the `nreal` real parents, then padding up to the next multiple of four (nwrite entries)
+__global__ __launch_bounds__(256) void k_upper_boxes(const NodeBox* __restrict__ child, NodeBox* __restrict__ parent,
+                                                     u32 nreal, u32 nwrite)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwrite) return;
+    parent[i] = i < nreal ? union_of_children(child + static_cast<u64>(i) * W) : padding_node();
+}
+
+// The top of the tree in ONE launch: levels dtop-1 ... 0 (at most 1024 nodes each) by a single workgroup, a device-scope
+// fence and a barrier between levels (round 1 launched every level separately: ten tiny kernels, 12 us each).
+// real(d) = ceil(nleaves / 4^(depth - d)) nodes of level d are real.
+constexpr int TOP_LEVELS = 6;  // levels 0..5 are the workgroup's
+__global__ __launch_bounds__(1024) void k_upper_boxes_top(NodeBox* __restrict__ nodes, int dtop, int depth, u32 nleaves)
+{
+    for (int d = dtop - 1; d >= 0; --d) {
+        const int sh = 2 * (depth - d);
+        const u32 nreal = static_cast<u32>((static_cast<u64>(nleaves) + (1ull << sh) - 1ull) >> sh);
+        const u32 nwrite = d == 0 ? 1u : (nreal + 3u) & ~3u;
+        const NodeBox* child = nodes + ((1ull << (2 * (d + 1))) - 1) / 3;
+        NodeBox* parent = nodes + ((1ull << (2 * d)) - 1) / 3;
+        for (u32 i = threadIdx.x; i < nwrite; i += blockDim.x)
+            parent[i] = i < nreal ? union_of_children(child + static_cast<u64>(i) * W) : padding_node();
+        __threadfence();
+        __syncthreads();
+    }
 }
 
 inline u64 pow4(int d) { return 1ull << (2 * d); }
@@ -307,7 +351,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         struct Fresh {
             float* xyz = nullptr;
             u64* codes[2] = {nullptr, nullptr};
-            u32* vals[2] = {nullptr, nullptr};
+            u32* perm = nullptr;
             Leaf* leaves = nullptr;
             NodeBox* nodes = nullptr;
             void* sort_tmp = nullptr;
@@ -317,22 +361,21 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
                 if (keep) return;
                 (void)hipFree(xyz);
                 (void)hipFree(codes[0]); (void)hipFree(codes[1]);
-                (void)hipFree(vals[0]); (void)hipFree(vals[1]);
+                (void)hipFree(perm);
                 (void)hipFree(leaves); (void)hipFree(nodes); (void)hipFree(sort_tmp);
             }
         } nw;
         int st;
         if ((st = dev_alloc(nw.xyz, cap * 3)) != PCPX_OK) return st;
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 2; ++b)
             if ((st = dev_alloc(nw.codes[b], cap)) != PCPX_OK) return st;
-            if ((st = dev_alloc(nw.vals[b], cap)) != PCPX_OK) return st;
-        }
+        if ((st = dev_alloc(nw.perm, cap)) != PCPX_OK) return st;
         u32 nl = static_cast<u32>((cap + LEAF - 1) / LEAF);
         if ((st = dev_alloc(nw.leaves, nl)) != PCPX_OK) return st;
         u64 nodes = level_start(depth_for(nl) + 1);
         if ((st = dev_alloc(nw.nodes, nodes)) != PCPX_OK) return st;
         size_t tb = 0;
-        if ((st = sort_pairs_u64(nullptr, tb, nullptr, nullptr, nullptr, nullptr, cap, s)) != PCPX_OK) return st;
+        if ((st = sort_keys_u64(nullptr, tb, nullptr, nullptr, cap, s)) != PCPX_OK) return st;
         {
             hipError_t e = hipMalloc(&nw.sort_tmp, tb ? tb : 16);
             if (e != hipSuccess) {
@@ -345,10 +388,10 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         (void)hipFree(ix.d_xyz);
         for (int b = 0; b < 2; ++b) {
             (void)hipFree(ix.d_codes[b]);
-            (void)hipFree(ix.d_vals[b]);
             ix.d_codes[b] = nw.codes[b];
-            ix.d_vals[b] = nw.vals[b];
         }
+        (void)hipFree(ix.d_perm);
+        ix.d_perm = nw.perm;
         (void)hipFree(ix.d_leaves);
         (void)hipFree(ix.d_nodes);
         (void)hipFree(ix.d_sort_tmp);
@@ -388,20 +431,31 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     u32 nvalid = 0;
     if (n > 0) {
         unsigned blocks = static_cast<unsigned>((n + 255) / 256);
-        k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.d_codes[0], ix.d_vals[0]);
+        ix.idx_bits = index_bits_for(n);
+        k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.idx_bits, ix.d_codes[0]);
         PCPX_HIP(hipGetLastError());
         size_t tb = ix.sort_tmp_bytes;
-        int st = sort_pairs_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], ix.d_vals[0], ix.d_vals[1], n, s, MORTON_SORT_FIRST_BIT);
+        int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, CURVE_FIRST_BIT);
         if (st != PCPX_OK) return st;
-        k_count_valid<<<1, 64, 0, s>>>(ix.d_codes[1], static_cast<u32>(n), ix.d_scalars + 6);
+        k_count_valid<<<1, 64, 0, s>>>(ix.d_codes[1], static_cast<u32>(n), ix.d_scalars + 6, sort_failure_flag(ix.d_sort_tmp));
     } else {
-        PCPX_HIP(hipMemsetAsync(ix.d_scalars + 6, 0, sizeof(u32), s));
+        PCPX_HIP(hipMemsetAsync(ix.d_scalars + 6, 0, 2 * sizeof(u32), s));
     }
     float hb[8];
     PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, 8 * sizeof(u32), hipMemcpyDeviceToHost, s));
     PCPX_HIP(hipStreamSynchronize(s));
     std::memcpy(&nvalid, &hb[0], sizeof(u32));
     std::memcpy(ix.bbox, &hb[2], 6 * sizeof(float));
+    {
+        u32 sort_failed = 0;
+        std::memcpy(&sort_failed, &hb[1], sizeof(u32));
+        if (n > 0 && sort_failed) {
+            ix.n = ix.n_in = 0;
+            ix.nleaves = 0;
+            set_error("pcpx: internal error, the radix sort's look-back gave up");
+            return PCPX_ERR_DEVICE;
+        }
+    }
     ix.n = nvalid;
 
     // implicit tree, heap layout
@@ -418,16 +472,21 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         set_error("pcpx: internal error, node capacity");
         return PCPX_ERR_INVALID;
     }
-    {
-        u32 nslots = nleaves * LEAF;
-        if (nslots)
-            k_fill_leaves<<<(nslots + 255) / 256, 256, 0, s>>>(ix.d_xyz, ix.perm(), nvalid, nslots, ix.d_leaves);
-        u32 bottom = static_cast<u32>(pow4(depth));
-        k_leaf_boxes<<<(bottom + 255) / 256, 256, 0, s>>>(ix.d_leaves, nleaves, bottom, ix.d_nodes + level_start(depth));
-        for (int d = depth - 1; d >= 0; --d) {
-            u32 np = static_cast<u32>(pow4(d));
-            k_upper_boxes<<<(np + 255) / 256, 256, 0, s>>>(ix.d_nodes + level_start(d + 1), ix.d_nodes + level_start(d), np);
+    if (nleaves > 0) {
+        // bottom level + leaf records in one pass, then the upper levels: real nodes only (+ the padding siblings of the
+        // last group of four, the only padding a query can read)
+        const u32 leaves_written = depth > 0 ? ((nleaves + 3u) & ~3u) : nleaves;
+        const u32 nslots = leaves_written * LEAF;
+        k_fill_leaves<<<(nslots + 255) / 256, 256, 0, s>>>(ix.d_xyz, ix.d_codes[1], ix.idx_bits, nvalid, nleaves, nslots, ix.d_leaves, ix.d_perm,
+                                                            ix.d_nodes + level_start(depth), depth > 0);
+        int d = depth - 1;
+        for (; d >= TOP_LEVELS; --d) {  // the wide levels: one launch each
+            const int sh = 2 * (depth - d);
+            const u32 nreal = static_cast<u32>((static_cast<u64>(nleaves) + (1ull << sh) - 1ull) >> sh);
+            const u32 nwrite = (nreal + 3u) & ~3u;
+            k_upper_boxes<<<(nwrite + 255) / 256, 256, 0, s>>>(ix.d_nodes + level_start(d + 1), ix.d_nodes + level_start(d), nreal, nwrite);
         }
+        if (d >= 0) k_upper_boxes_top<<<1, 1024, 0, s>>>(ix.d_nodes, d + 1, depth, nleaves);
         PCPX_HIP(hipGetLastError());
     }
     return PCPX_OK;

@@ -8,10 +8,11 @@
 // volume 1.9e-5 -> 5.6e-6, leaves visited per 64-query group 135 -> 84, node expansions 165 -> 88 (uniform cloud;
 // clustered: 131 -> 85, 156 -> 99).
 //
-// Key layout: 13 bits per axis of the 21-bit quantisation (the reference's octant bits, x most significant,
+// Sort word: 13 bits per axis of the 21-bit quantisation (the reference's octant bits, x most significant,
 // include/pcp/octree/linked_octree_node.hpp:258-265, are where the grid comes from) -> 39-bit Hilbert index in bits
-// [24, 63); bit 63 is clear, so PAD_CODE (all ones: points outside the voxel grid) sorts last.  The radix sort looks at
-// bits [MORTON_SORT_FIRST_BIT = 24, 64) only: 5 passes, as before.
+// [24, 63); bit 63 marks a point outside the voxel grid (it sorts last); the element's index sits in the low bits and
+// overwrites as many low key bits as it needs (a 13-bit index is a refinement of the 12-bit one, so dropping low bits
+// only coarsens the cells).  One 8-byte word per element is all the radix sort moves; it looks at bits [24, 64): 5 passes.
 #ifndef PCPX_CURVE_H
 #define PCPX_CURVE_H
 
@@ -72,13 +73,20 @@ __host__ __device__ __forceinline__ u64 hilbert_index(u32 x, u32 y, u32 z)
     return (spread21(X[0]) << 2) | (spread21(X[1]) << 1) | spread21(X[2]);
 }
 
-// sort key of a point inside the grid box6 = {min xyz, max xyz}
+// curve key (bits [24, 63)) of a point inside the grid box6 = {min xyz, max xyz}
 __device__ __forceinline__ u64 curve_key(float x, float y, float z, float b0, float b1, float b2, float b3, float b4, float b5)
 {
     const u32 qx = quant21(x, b0, b3) >> (21 - CURVE_BITS), qy = quant21(y, b1, b4) >> (21 - CURVE_BITS),
               qz = quant21(z, b2, b5) >> (21 - CURVE_BITS);
-    return hilbert_index(qx, qy, qz) << MORTON_SORT_FIRST_BIT;
+    return hilbert_index(qx, qy, qz) << CURVE_FIRST_BIT;
 }
+// the sort word of element `index`: its key with the low idx_bits replaced by the index
+__device__ __forceinline__ u64 sort_word(u64 key, u64 index, int idx_bits)
+{
+    const u64 low = (1ull << idx_bits) - 1ull;
+    return (key & ~low) | index;
+}
+constexpr u64 OUTSIDE_BIT = 1ull << 63;
 
 }  // namespace pcpx
 

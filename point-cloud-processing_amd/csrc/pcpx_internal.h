@@ -35,10 +35,18 @@ constexpr int LEAVES_PER_GROUP = GROUP / LEAF;
 constexpr int MAXDEPTH = 15;  // 4^15 leaves of 8 points: far beyond 2^32 points
 constexpr u32 INVALID_ID = 0xFFFFFFFFu;
 constexpr u64 PAD_CODE = ~0ull;
-// The Morton order only has to make leaves spatially compact: any order gives a correct tree (boxes come from the
-// points), so the sort looks at the top 40 bits of the 63-bit code (13 bits per axis: cells of 1/8192 of the grid
-// extent, far below a leaf's size for any cloud that fits a GPU) -- 5 radix passes instead of 8.
-constexpr int MORTON_SORT_FIRST_BIT = 24;
+// The curve order only has to make leaves spatially compact: any order gives a correct tree (boxes come from the
+// points).  A sort word is {bit 63: outside the grid, bits [24, 63): 39-bit curve key (13 bits per axis: cells of 1/8192
+// of the grid extent), low bits: the element's index}; the radix sort looks at bits [24, 64) only -- 5 passes -- and the
+// index overwrites as many of the key's low bits as it needs (more than 24 only beyond 16.7 M elements: 12 key bits per
+// axis up to 134 M, 11 up to 1 G); see pcpx_curve.h.
+constexpr int CURVE_FIRST_BIT = 24;
+inline int index_bits_for(u64 n)
+{
+    int b = 1;
+    while (b < 32 && (1ull << b) < n) ++b;
+    return b;
+}
 
 struct Leaf {
     float x[LEAF];
@@ -133,8 +141,9 @@ struct Index {
     float bbox[6] = {0, 0, 0, 0, 0, 0};
 
     float* d_xyz = nullptr;      // n_in x 3, input order
-    u64* d_codes[2] = {nullptr, nullptr};
-    u32* d_vals[2] = {nullptr, nullptr};
+    u64* d_codes[2] = {nullptr, nullptr};  // sort words: [0] input order, [1] sorted
+    u32* d_perm = nullptr;                 // sorted position -> input index
+    int idx_bits = 1;                      // low bits of a sort word that hold the input index
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     Leaf* d_leaves = nullptr;
@@ -166,7 +175,7 @@ struct Index {
     u32 few_epoch = 0;   // launch counter of the latency path (its completion flag carries the epoch)
 
     u64* sorted_codes() const { return d_codes[1]; }
-    u32* perm() const { return d_vals[1]; }
+    u32* perm() const { return d_perm; }
     TreeView view() const { return TreeView{d_leaves, d_nodes, nleaves, static_cast<u32>(n), depth, leaf0}; }
 };
 
@@ -203,10 +212,11 @@ int check_hip(hipError_t e, const char* what, const char* file, int line);
 // build.hip
 int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
 int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6);
-// stable LSD radix sort by key bits [first_bit, 64) (first_bit a multiple of 8); pairs whose keys agree on those
-// bits keep their input order
-int sort_pairs_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n,
-                   hipStream_t s, int first_bit = 0);
+// stable LSD radix sort of 64-bit words by their bits [first_bit, 64) (first_bit a multiple of 8); words that agree on
+// those bits keep their input order.  sort_failure_flag: device word of the temporary storage that the sort sets if its
+// look-back ever gave up (it never should); read it after synchronising the stream.
+int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit = 0);
+const u32* sort_failure_flag(void* tmp);
 int ensure_scratch(Index& ix, size_t bytes);
 
 // orient.hip: propagate_normal_orientations on the device (rows, counts, coordinates, normals are device arrays)
@@ -231,6 +241,7 @@ int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_r
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
 int launch_normals_csr(const float* d_xyz, const u64* d_offsets, u64 nrows, float* d_out, hipStream_t s);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
+int prepare_queue(Index& ix);  // zeroes the work-queue counters of the persistent kernels (stream-ordered)
 
 }  // namespace pcpx
 

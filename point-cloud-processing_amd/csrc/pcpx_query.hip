@@ -619,6 +619,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         u32 ps = real ? static_cast<u32>(key) : 0u;
         pos[s] = ps;
         u32 id = t.leaves[ps / LEAF].id[ps % LEAF];
+        asm volatile("" : "+v"(id));  // keep the load unconditional: sunk under `real` it becomes a branch per key, and the
+                                      // values live across those branches were what spilled to scratch
         best[s] = real ? ((key & 0xFFFFFFFF00000000ull) | id) : key;
     }
     bool unordered = false;
@@ -767,14 +769,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     }
 }
 
-// zeroed work-queue counters for one persistent launch (stream-ordered)
-int prepare_queue(Index& ix)
-{
-    if (!ix.d_queue) PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix.d_queue), 8 * QUEUE_STRIDE * sizeof(u32)));
-    PCPX_HIP(hipMemsetAsync(ix.d_queue, 0, 8 * QUEUE_STRIDE * sizeof(u32), ix.stream));
-    return PCPX_OK;
-}
-
 // number of workgroups that are resident at once (occupancy API x CUs), never more than there is work
 u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups)
 {
@@ -790,6 +784,14 @@ u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups
 }
 
 }  // namespace
+
+// zeroed work-queue counters for one persistent launch (stream-ordered)
+int prepare_queue(Index& ix)
+{
+    if (!ix.d_queue) PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix.d_queue), 8 * QUEUE_STRIDE * sizeof(u32)));
+    PCPX_HIP(hipMemsetAsync(ix.d_queue, 0, 8 * QUEUE_STRIDE * sizeof(u32), ix.stream));
+    return PCPX_OK;
+}
 
 template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, const KnnOutputs& o)

@@ -10,14 +10,14 @@ namespace {
 // sphere range: count / fill (include/pcp/octree/linked_octree_node.hpp:581-614 semantics:
 // every point with d2 <= r*r, query included)
 // ------------------------------------------------------------------------------------------------
+// One group of 64 curve-consecutive queries, one per lane: the wave-uniform walk of pcpx_device.h, a leaf's 8 points
+// broadcast from SGPRs, the count kept per lane (compare + add-with-carry: 2 VALU per candidate on top of the 8 of the
+// distance -- an exec-masked form would not be shorter).
 template <bool SELF, bool FILL>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
-                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
-                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
+__device__ __forceinline__ void range_group(const TreeView& t, const QueryView& qv, const u32 g, const float radius,
+                                            const float* __restrict__ radii, u32* __restrict__ out_cnt,
+                                            const u64* __restrict__ offsets, u32* __restrict__ out_idx, const u32 lane)
 {
-    const u32 lane = threadIdx.x & 63u;
-    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
-    if (g >= group_end) return;
     const u32 p = g * GROUP + lane;
     const u32 nq = SELF ? t.n : qv.nq;
     const bool valid = p < nq;
@@ -62,6 +62,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, Quer
         more = wk.next(t, need, leaf, nexp);
     }
     if (valid && !FILL) out_cnt[row] = cnt;
+}
+
+// One single-wave workgroup per group, XCD-aware block order (pcpx_device.h: virtual_block).  (Tried: a persistent grid
+// pulling groups from the 8 work queues like k_knn -- 10 M counts at r = 0.01 went from 2.8 to 3.1 ms: these groups are
+// short and even, the dispatcher is the better scheduler here.)
+template <bool SELF, bool FILL>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, QueryView qv, u32 group_first, u32 group_end, float radius,
+                                                               const float* __restrict__ radii, u32* __restrict__ out_cnt,
+                                                               const u64* __restrict__ offsets, u32* __restrict__ out_idx)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
+    if (g >= group_end) return;
+    range_group<SELF, FILL>(t, qv, g, radius, radii, out_cnt, offsets, out_idx, lane);
 }
 
 // AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:

@@ -379,24 +379,28 @@ def test_sorted_shards_cover_the_cloud(pkg):
 
 
 # ---- build pipeline: the hand-written radix sort -------------------------------------------------------
-@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 100_000, 1_000_003])
-def test_radix_sort_is_a_stable_sort(pkg, n):
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 100_000, 1_000_003, 5_000_001])
+@pytest.mark.parametrize("first_bit", [0, 24])
+def test_radix_sort_is_a_stable_sort(pkg, n, first_bit):
+    """The build's onesweep radix sort (pcpx_sort.hip): words ordered by their bits [first_bit, 64), input order kept
+    among words that agree on those bits -- against numpy's stable argsort."""
     import ctypes as C
     import importlib
     capi = importlib.import_module("point-cloud-processing_amd._capi")
     lib = capi.load()
-    rng = np.random.default_rng(n)
-    # few distinct keys in every byte position => many ties => stability is exercised in all 8 passes
+    rng = np.random.default_rng(n + first_bit)
+    # few distinct values in every byte position => many ties => stability is exercised in every pass
     keys = rng.integers(0, 7, n, dtype=np.uint64) * np.uint64(0x0101010101010101) + (rng.integers(0, 3, n, dtype=np.uint64) << np.uint64(40))
     if n > 10:
-        keys[rng.integers(0, n, n // 10)] = np.uint64(0xFFFFFFFFFFFFFFFF)  # pad codes
+        keys[rng.integers(0, n, n // 10)] = np.uint64(0xFFFFFFFFFFFFFFFF)  # outside-the-grid words
         keys[rng.integers(0, n, n // 10)] = rng.integers(0, 2 ** 63, n // 10, dtype=np.uint64)
-    vals = np.arange(n, dtype=np.uint32)
-    ok, ov = np.empty(n, np.uint64), np.empty(n, np.uint32)
+    if first_bit:  # low bits = the element's index, like the build's words: what stability is observed through
+        keys = (keys & ~np.uint64((1 << first_bit) - 1)) | (np.arange(n, dtype=np.uint64) & np.uint64((1 << first_bit) - 1))
+    out = np.empty(n, np.uint64)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    capi.check(lib.pcpx_debug_sort_pairs(vp(keys), vp(vals), n, 0, vp(ok), vp(ov)))
-    order = np.argsort(keys, kind="stable")
-    assert np.array_equal(ok, keys[order]) and np.array_equal(ov, vals[order])
+    capi.check(lib.pcpx_debug_sort_keys(vp(keys), n, first_bit, 0, vp(out)))
+    order = np.argsort(keys >> np.uint64(first_bit), kind="stable")
+    assert np.array_equal(out, keys[order])
 
 
 # ---- the callers right next to the normal loop (SURVEY.md section 8f rows 2 and 3) ----------------------
