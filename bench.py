@@ -74,7 +74,9 @@ def host_cores():
 def cpu_baseline(pts, k, budget_s=12.0):
     """Reference algorithms and parameters (octree capacity 32 / depth 21 / auto bbox + estimate_normals,
     driven like examples/simple_example.cpp:83-99) from the oracle restatement, on all host threads, over a
-    bounded sample of the same cloud's queries.  kind = "port": the real reference cannot be built here."""
+    bounded sample of the same cloud's queries.  kind = "port": the real reference cannot be built here.
+    Beside it, the figure "as the reference would get it on this box": the same loop under std::execution::par
+    (the policy the reference's examples pass), which libstdc++ runs on ONE thread when it has no TBB backend."""
     from oracle import pcp_oracle as O
     threads = host_cores()
     t0 = time.perf_counter()
@@ -95,9 +97,16 @@ def cpu_baseline(pts, k, budget_s=12.0):
         rate = sample / dt
     else:
         sample = probe
+    par_n = int(min(n, max(2000, rate / threads * 3.0)))  # ~3 s on one thread
+    t0 = time.perf_counter()
+    _, par_threads = tree.estimate_normals_stdpar(k, first=(n - par_n) // 2, count=par_n)
+    par_rate = par_n / (time.perf_counter() - t0)
     return {"value": rate / 1e6, "unit": "Mqueries/s", "cores": threads, "kind": "port",
             "sample": "%d of %d queries (kNN k=%d + PCA normal each) on the full %d-point cloud, oracle octree "
-                      "(capacity 32, depth 21), %d threads; octree build %.1f s not included" % (sample, n, k, n, threads, build_s)}
+                      "(capacity 32, depth 21), %d threads; octree build %.1f s not included" % (sample, n, k, n, threads, build_s),
+            "std_execution_par": {"value": par_rate / 1e6, "unit": "Mqueries/s", "threads_observed": par_threads,
+                                  "sample": "%d queries under std::transform(std::execution::par, ...); libstdc++ without TBB "
+                                            "runs the policy on the calling thread" % par_n}}
 
 
 def _reduce(torch, dist, value, op, dev, rehearse):
@@ -107,7 +116,7 @@ def _reduce(torch, dist, value, op, dev, rehearse):
     return float(t.item())
 
 
-def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profile, rehearse=False):
+def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profile, rehearse=False, side=True, collective=False):
     kind, n, seed, k = WORKLOADS[name]
     dev = torch.device("cuda", torch.cuda.current_device())
     pts = make_cloud(pkg, kind, n, seed)
@@ -122,7 +131,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     d_box = torch.empty(6, dtype=torch.float32, device=dev)
     capi.check(lib.pcpx_bounding_box_dev(d_pts.data_ptr() + 12 * lo, hi - lo, dev.index, stream, d_box.data_ptr()))
     torch.cuda.current_stream().synchronize()
-    d_box = mg.global_grid(d_box.cpu() if rehearse else d_box, dist, world)  # the one collective: 24 B per rank over RCCL
+    d_box = mg.global_grid(d_box.cpu() if rehearse else d_box, dist, world, always=collective)  # the one collective: 24 B per rank over RCCL
     grid = d_box.cpu().numpy()
 
     torch.cuda.synchronize()
@@ -176,17 +185,19 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         complete = int(_reduce(torch, dist, complete, dist.ReduceOp.SUM, dev, rehearse))
 
     # rebuild cost (same grid), for the "incl. build" figure
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reb = 3
-    for _ in range(reb):
-        ix.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid)
-    torch.cuda.synchronize()
-    rebuild_ms = (time.perf_counter() - t0) * 1e3 / reb
+    rebuild_ms = None
+    if side:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reb = 5
+        for _ in range(reb):
+            ix.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid)
+        torch.cuda.synchronize()
+        rebuild_ms = (time.perf_counter() - t0) * 1e3 / reb
 
     # config 3 shape on the same cloud: radius count r = 0.01 around every point (device resident)
     range_ms = None
-    if name == "uniform_10m_k15" and world == 1:
+    if side and name == "uniform_10m_k15" and world == 1:
         d_rc = torch.empty(n, dtype=torch.int32, device=dev)
         ix.range_count_self_dev(0.01, d_rc.data_ptr())
         torch.cuda.synchronize()
@@ -204,6 +215,48 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     return res
 
 
+def host_api_rates(pkg, pts, k):
+    """What a caller of the host-pointer C ABI (= the drop-in C++ headers) gets on the bench cloud: H2D of the points
+    is excluded (the index exists), outputs are host arrays allocated and touched beforehand, PCIe included."""
+    import ctypes as C
+    capi = importlib.import_module("point-cloud-processing_amd._capi")
+    lib = capi.load()
+    n = len(pts)
+    ix = pkg.Index(pts)
+    nrm = np.zeros((n, 3), np.float32)
+    idx = np.zeros((n, k), np.uint32)
+    cnt = np.zeros(n, np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = {}
+    for name, fn in (("host_api_normals", lambda: lib.pcpx_normals_knn_self(ix._h, k, 1e-5, vp(nrm), None, None)),
+                     ("host_api_rows", lambda: lib.pcpx_normals_knn_self(ix._h, k, 1e-5, vp(nrm), vp(idx), vp(cnt)))):
+        capi.check(fn())
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            capi.check(fn())
+            best = min(best, time.perf_counter() - t0)
+        out[name + "_ms"] = round(best * 1e3, 3)
+        out[name + "_mqps"] = round(n / best / 1e6, 1)
+    out["host_api_rows_bytes_to_host"] = (12 + 4 * k + 4) * n
+    ix.close()
+    return out, nrm, idx
+
+
+def normals_evidence(pts, idx, nrm, sample=100_000):
+    """SURVEY.md section 8(d) parity gate, on GPU output: float64 eigh of each sampled row's scatter matrix against the
+    float32 normal; rows with relative eigen-gap (l1 - l0) / l2 < 1e-3 are "ill-conditioned in the reference itself"."""
+    rows = np.random.default_rng(1).integers(0, len(pts), sample)
+    nb = pts[idx[rows].astype(np.int64)].astype(np.float64)
+    v = nb - nb.mean(axis=1, keepdims=True)
+    w, vec = np.linalg.eigh(np.einsum("rki,rkj->rij", v, v))
+    gap = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300)
+    well = gap >= 1e-3
+    err = 1.0 - np.abs((vec[:, :, 0] * nrm[rows].astype(np.float64)).sum(1))
+    return {"rows_sampled": int(sample), "max_1_minus_abs_cos_vs_float64_eigh": float(err[well].max()),
+            "ill_conditioned_fraction": float(1.0 - well.mean()), "tolerance": 1e-4}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,7 +264,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="uniform_10m_k15", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (rebuild, range count)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the side measurements (rebuild, range count, host-pointer ABI rates, normal evidence): the "
+                         "process then launches nothing but the timed steps, which is what the profiling scripts want")
     ap.add_argument("--with-1m", action="store_true",
                     help="also time configs[1] (1 M points, k=15) and report it under extra; off by default so that the "
                          "default command launches k_knn on the headline workload only (its rocprofv3 average then "
@@ -228,10 +283,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the pcpx hot path has no CPU fallback")
     # PCPX_BENCH_REHEARSE=1: run the N > 1 code path on ONE GPU (all ranks on device 0, collectives over gloo) --
-    # a functional rehearsal of sharding and reduction for tests, not a measurement
+    # a functional rehearsal of sharding and reduction for tests, not a measurement.
+    # PCPX_BENCH_COLLECTIVE=1: initialise RCCL and run the bounding-box all-gather even with one rank (what a one-GPU
+    # box can exercise of the real multi-GPU branch: communicator set-up and a device-tensor collective on hardware).
     rehearse = os.environ.get("PCPX_BENCH_REHEARSE") == "1"
+    collective = os.environ.get("PCPX_BENCH_COLLECTIVE") == "1"
     torch.cuda.set_device(0 if rehearse else local_rank)
-    if world > 1:
+    if world > 1 or collective:
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
@@ -239,19 +297,30 @@ def main():
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
+    side = not args.no_extra
     main_res = run_workload(pkg, torch, dist, args.workload, rank, world, args.steps, args.warmup, want_profile=True,
-                            rehearse=rehearse)
+                            rehearse=rehearse, side=side, collective=collective)
     n, k = main_res["n"], main_res["k"]
 
-    extra = {"index_build_ms_first": round(main_res["first_build_ms"], 3),
-             "index_rebuild_ms": round(main_res["rebuild_ms"], 3),
-             "value_incl_build": round(n / ((main_res["ms_per_step"] + main_res["rebuild_ms"]) / 1e3) / 1e6, 3),
-             "shard_of_rank0": list(main_res["shard"])}
+    extra = {"index_build_ms_first": round(main_res["first_build_ms"], 3), "shard_of_rank0": list(main_res["shard"])}
+    if main_res["rebuild_ms"] is not None:
+        reb = main_res["rebuild_ms"]
+        extra["index_rebuild_ms"] = round(reb, 3)
+        extra["value_incl_build"] = round(n / ((main_res["ms_per_step"] + (0.0 if args.workload in STREAMING else reb)) / 1e3) / 1e6, 3)
+        # the build's algorithmic traffic is 30 B/point (12 read + 12 sorted xyz + 4 perm + node boxes);
+        # the build IS bandwidth-shaped work, so this is the fraction that means something for it
+        extra["build_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_point": 30, "achieved_GBps": round(30 * n / reb / 1e6, 1),
+                                   "frac": round(30 * n / (reb * 1e-3) / HBM_PEAK, 5)}
+        # replicated build inside the step (configs[4]): Amdahl ceiling of the 8-rank speed-up from this rank's numbers
+        q_ms = main_res["ms_per_step"] - (reb if args.workload in STREAMING else 0.0)
+        extra["amdahl_ceiling_8_ranks_build_in_step"] = round((q_ms + reb) / (q_ms / 8.0 + reb), 2)
     if main_res["min_count"] is not None:
         extra["min_neighbours_found"] = main_res["min_count"]
     extra["rows_with_k_neighbours_all_ranks"] = main_res["complete"]  # = points when the shards cover the cloud exactly once
     if rehearse:
         extra["rehearsal"] = "one GPU, gloo: functional check of the N > 1 path, not a measurement"
+    if collective:
+        extra["collective"] = "bounding-box all-gather over %s with %d rank(s)" % ("gloo" if rehearse else "RCCL (backend nccl)", world)
     if main_res.get("range_ms"):
         extra["config3_range_count_r0.01_ms"] = round(main_res["range_ms"], 3)
         extra["config3_range_count_r0.01_mqps"] = round(n / main_res["range_ms"] / 1e3, 1)
@@ -266,30 +335,23 @@ def main():
         # write + 12 B normal write per query (84 B at k = 15); the fused k_knn launch does exactly that
         bytes_per_q = 12 + 4 * k + (0 if args.workload in STREAMING else 12)
         achieved = q_per_launch * bytes_per_q / avg_s
-        roofline = {"bound": "hbm", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
+        roofline = {"bound": "hbm", "limiter": "valu-issue", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_query": bytes_per_q, "queries_per_launch": q_per_launch,
-                    "note": "fused kNN+normals kernel; it is VALU-issue bound, not HBM bound (DESIGN.md 'Roofline'); traffic = "
-                            "PMC HBM bytes per launch of an earlier profiled run (profiles/r01_hbm_traffic.json)"}
-        traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+                    "note": "fused kNN+normals kernel: a tree search, bounded by vector-instruction issue, not by HBM (DESIGN.md "
+                            "'Roofline'); achieved = algorithmic bytes / HIP-event time of the launch on its stream, measured in this "
+                            "run; traffic = PMC HBM bytes per launch from the committed rocprofv3 --pmc passes of this command "
+                            "(profiles/r02_hbm_traffic.json), null when that file is not for this workload"}
+        traffic_file = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
                 if tr.get("workload") == args.workload and world == 1:
                     roofline["traffic"] = tr.get("k_knn_hbm_bytes_per_launch")
-                    # report the measured HBM rate beside the algorithmic one
+                    roofline["traffic_source"] = "profiles/r02_hbm_traffic.json (separate --pmc passes, not this run)"
                     roofline["hbm_measured_GBps"] = round(roofline["traffic"] / avg_s / 1e9, 1)
                     roofline["hbm_measured_frac"] = round(roofline["traffic"] / avg_s / HBM_PEAK, 5)
-            except Exception:
-                pass
-        model_file = os.path.join(ROOT, "profiles", "r01_valu_issue_model.json")
-        if os.path.exists(model_file) and world == 1:
-            try:
-                m = json.load(open(model_file))
-                if m.get("workload") == args.workload:  # the bound that matters: share of SIMD cycles spent issuing VALU
-                    roofline["valu_issue_frac_model"] = round(m["valu_issue_cycles_per_group_total"] * (q_per_launch / 64) /
-                                                              (avg_s * 2.4e9 * 1024), 3)
             except Exception:
                 pass
         nl, nms = prof["normals"]
@@ -299,9 +361,15 @@ def main():
         extra["knn_only_mqps"] = round(q_per_launch * world / avg_s / 1e6, 3)
 
     if rank == 0 and world == 1 and args.with_1m and args.workload != "uniform_1m_k15":
-        side = run_workload(pkg, torch, dist, "uniform_1m_k15", 0, 1, max(args.steps, 10), args.warmup, want_profile=False)
-        extra["configs1_uniform_1m_k15_mqps"] = round(side["mqps"], 3)
-        extra["configs1_uniform_1m_k15_ms_per_step"] = round(side["ms_per_step"], 4)
+        side_res = run_workload(pkg, torch, dist, "uniform_1m_k15", 0, 1, max(args.steps, 10), args.warmup, want_profile=False, side=False)
+        extra["configs1_uniform_1m_k15_mqps"] = round(side_res["mqps"], 3)
+        extra["configs1_uniform_1m_k15_ms_per_step"] = round(side_res["ms_per_step"], 4)
+
+    if rank == 0 and world == 1 and side and args.workload not in STREAMING:
+        rates, h_nrm, h_idx = host_api_rates(pkg, main_res["pts"], k)
+        extra.update(rates)
+        extra["normals_check"] = normals_evidence(main_res["pts"], h_idx, h_nrm)
+        del h_nrm, h_idx
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -317,10 +385,10 @@ def main():
                 "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": args.workload, "points": n, "queries": n, "k": k,
-                           "parallelism": "replicated index, Morton-sorted query shards x%d, bbox all-gather (RCCL)" % world},
+                           "parallelism": "replicated index, curve-sorted query shards x%d, bbox all-gather (RCCL)" % world},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -193,9 +193,30 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
 int pcpx_estimate_normals_batch(const float* xyz, const uint64_t* offsets, uint64_t nrows, int device,
                                 float* out_normals);
 
-/* ---- multi-GPU helper --------------------------------------------------------------------- */
-/* Contiguous, 64-aligned shard of the Morton-sorted query order for `rank` of `world`. */
+/* ---- multi-GPU: one process per GPU ------------------------------------------------------------ */
+/* Contiguous, 64-aligned shard of the curve-sorted query order for `rank` of `world`. */
 int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count);
+
+/* The path's one collective -- an RCCL all-gather of the per-rank bounding boxes (6 floats = 24 B per rank over
+ * xGMI) -- behind the ABI, so that a C++ host of the drop-in headers has the multi-GPU path too.  The reference has
+ * no counterpart (it is single-process).  Sequence per rank: communicator (either created here from an id that rank 0
+ * generates and shares out of band -- MPI_Bcast, a file, a socket -- or an existing ncclComm_t of the host program);
+ * pcpx_comm_global_grid_dev over this rank's slice of the input -> the same grid on every rank; pcpx_index_create_dev
+ * of the WHOLE cloud with PCPX_BUILD_USE_GRID on that grid; *_self_dev calls restricted to pcpx_shard_range.
+ * librccl.so.1 is loaded at the first pcpx_comm_* call; PCPX_ERR_UNSUPPORTED if it cannot be. */
+typedef struct pcpx_comm pcpx_comm;
+#define PCPX_COMM_ID_BYTES 128
+int pcpx_comm_unique_id(char out_id[PCPX_COMM_ID_BYTES]);
+int pcpx_comm_init_rank(const char id[PCPX_COMM_ID_BYTES], int world, int rank, int device, pcpx_comm** out);
+/* adopt an ncclComm_t the host program already has (it stays the caller's: pcpx_comm_destroy does not destroy it) */
+int pcpx_comm_wrap(void* nccl_comm, int world, int rank, int device, pcpx_comm** out);
+void pcpx_comm_destroy(pcpx_comm* comm);
+/* all-gather of one box per rank: d_local6 (6 floats) -> d_all (world x 6 floats), enqueued on `stream` */
+int pcpx_comm_allgather_boxes_dev(pcpx_comm* comm, const float* d_local6, float* d_all, void* stream);
+/* bounding box of this rank's device-resident slice, all-gather, union: the common grid, returned on the host
+ * (synchronises `stream`) */
+int pcpx_comm_global_grid_dev(pcpx_comm* comm, const float* d_xyz_slice, uint64_t n_slice, void* stream,
+                              float out_grid6[6]);
 
 /* The host-pointer entry points stage through device buffers that stay with the handle between calls (no
  * hipMalloc / hipFree per call); this releases the ones not in use.  pcpx_index_destroy releases everything. */

@@ -33,10 +33,13 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <execution>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <queue>
+#include <set>
 #include <thread>
 #include <vector>
 
@@ -786,6 +789,40 @@ void orc_estimate_normals(void* h, int tree_kind, u64 first, u64 count, u32 k, f
         if (out_idx)
             for (u32 j = 0; j < k; ++j) out_idx[i * k + j] = j < c ? nb[j] : 0xFFFFFFFFu;
     });
+}
+
+// The same loop under the policy the reference's examples pass: std::transform(std::execution::par, ...)
+// (include/pcp/algorithm/estimate_normals.hpp:92, examples/simple_example.cpp:92-99) -- "as the reference would get it on
+// this box": libstdc++'s parallel algorithms need TBB, and without its headers std::execution::par runs on the calling
+// thread.  Reports how many distinct threads executed the body.
+void orc_estimate_normals_stdpar(void* h, int tree_kind, u64 first, u64 count, u32 k, float eps, float* out_normals,
+                                 int* distinct_threads)
+{
+    Octree const* ot = tree_kind == 0 ? static_cast<Octree*>(h) : nullptr;
+    KdTree const* kt = tree_kind == 1 ? static_cast<KdTree*>(h) : nullptr;
+    std::vector<P3> const& pts = ot ? ot->pts : kt->pts;
+    std::vector<u64> ids(count);
+    std::iota(ids.begin(), ids.end(), u64(0));
+    std::set<std::thread::id> seen;
+    std::mutex mu;
+    struct N3 { float v[3]; };
+    std::vector<N3> out(count);
+    std::transform(std::execution::par, ids.begin(), ids.end(), out.begin(), [&](u64 i) {
+        thread_local bool counted = false;
+        if (!counted) {
+            std::lock_guard<std::mutex> lock(mu);
+            seen.insert(std::this_thread::get_id());
+            counted = true;
+        }
+        std::vector<u32> nb(k);
+        u32 c = ot ? oct_knn(*ot, pts[first + i], k, eps, nb.data(), nullptr)
+                   : kd_knn(*kt, pts[first + i], k, eps, nb.data(), nullptr);
+        N3 n;
+        estimate_normal(pts.data(), nb.data(), c, n.v, nullptr);
+        return n;
+    });
+    for (u64 i = 0; i < count; ++i) std::memcpy(out_normals + 3 * i, out[i].v, 3 * sizeof(float));
+    if (distinct_threads) *distinct_threads = static_cast<int>(seen.size());
 }
 
 // pcp::common::center_of_geometry (include/pcp/common/vector3d_queries.hpp:77-99) of every neighbour row:

@@ -126,6 +126,17 @@ class _Tree:
         return (nrm, idx) if want_idx else nrm
 
 
+    def estimate_normals_stdpar(self, k, eps=1e-5, first=0, count=None):
+        """The same loop under std::execution::par, as the reference's examples run it; returns (normals, number of
+        distinct threads that executed the body) -- 1 where libstdc++ has no TBB backend."""
+        count = len(self.xyz) - first if count is None else count
+        nrm = np.empty((count, 3), np.float32)
+        nt = C.c_int(0)
+        lib().orc_estimate_normals_stdpar(self._h, C.c_int(self._kind), C.c_uint64(first), C.c_uint64(count), C.c_uint32(k),
+                                          C.c_float(eps), _p(nrm, _f32p), C.byref(nt))
+        return nrm, nt.value
+
+
 class Octree(_Tree):
     """basic_linked_octree_t restatement (include/pcp/octree/linked_octree.hpp)."""
     _kind = 0

@@ -86,6 +86,12 @@ SIGNATURES = {
                                         C.c_void_p]),
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),
     "pcpx_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "pcpx_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pcpx_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pcpx_comm_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pcpx_comm_destroy": (None, [C.c_void_p]),
+    "pcpx_comm_allgather_boxes_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcpx_comm_global_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, f32p]),
     "pcpx_index_synchronize": (C.c_int, [C.c_void_p]),
     "pcpx_debug_knn_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, u64p, C.c_uint64]),
     "pcpx_debug_sort_keys": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),

@@ -21,9 +21,10 @@ def union_of_boxes(boxes):
     return torch.cat([boxes[:, :3].min(0).values, boxes[:, 3:].max(0).values])
 
 
-def global_grid(local_box, dist=None, world=1):
-    """All-gather the per-rank boxes and return the union (identical on every rank)."""
-    if world <= 1 or dist is None:
+def global_grid(local_box, dist=None, world=1, always=False):
+    """All-gather the per-rank boxes and return the union (identical on every rank).  always=True runs the collective
+    even with one rank (a hardware rehearsal of RCCL initialisation and a device-tensor all-gather)."""
+    if dist is None or (world <= 1 and not always):
         return local_box.clone()
     gathered = [torch.empty_like(local_box) for _ in range(world)]
     dist.all_gather(gathered, local_box)
