@@ -303,7 +303,7 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 // 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
 // The cap only steers the work, never the result (a lane that fails the cap goes round again).
 #ifndef PCPX_CAP_MULT
-#define PCPX_CAP_MULT 1.375f  // measured, 10 M points, 2 extra seed leaves, Mq/s uniform / clustered: 1: 1131 / 960, 1.25: 1175 / 1035, 1.375: 1168 / 1053, 1.5: 1164 / 1057, 1.75: 1156 / 1063
+#define PCPX_CAP_MULT 1.25f  // measured, 10 M points, Hilbert order, 2 extra seed leaves, Mq/s uniform / clustered: 1.25: 1873 / 1610, 1.375: 1865 / 1579, 1.5: 1855 / 1578, 1.75: 1841 / 1588, 2: 1834 / 1587 (round 1, Z-order: 1: 1131 / 960, 1.25: 1175 / 1035, 1.375: 1168 / 1053, 1.5: 1164 / 1057)
 #endif
 #ifndef PCPX_CAP_GROW
 #define PCPX_CAP_GROW 4.f  // radius^2 growth per further round
@@ -778,6 +778,9 @@ u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups
     (void)hipGetLastError();
     u64 want = static_cast<u64>(per_cu) * cus;
     u64 need = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    // (tried for short launches -- one rank's eighth of the queries is 2.7 groups per resident wave and ends with a tail:
+    //  fewer waves so that each gets >= 3 / 4 / 6 groups: 0.776 -> 0.795 / 0.862 / 0.925 ms per 1.25 M queries; the full
+    //  resident grid stays)
     u64 g = want < need ? want : need;
     g = (g + 7) / 8 * 8;
     return static_cast<u32>(g < 8 ? 8 : g);
