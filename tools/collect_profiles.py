@@ -4,7 +4,7 @@ usage: tools/collect_profiles.py r01"""
 import glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -17,7 +17,9 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("bench_clustered_10m_k15.json", "bench_clustered_10m_k15.json"),
                   ("bench_uniform_10m_k8.json", "bench_uniform_10m_k8.json"),
                   ("bench_c5_50m_k32_stream.json", "bench_c5_50m_k32_stream.json"), ("pcie_inclusive.json", "pcie_inclusive.json"),
-                  ("batch_query_rate.json", "batch_query_rate.json"),
+                  ("batch_query_rate.json", "batch_query_rate.json"), ("latency.json", "latency.json"),
+                  ("shard_rate.json", "shard_rate.json"), ("pcie_rate.json", "pcie_rate.json"),
+                  ("rebuild_10m.json", "rebuild_10m.json"), ("rebuild_50m.json", "rebuild_50m.json"),
                   ("valu_issue_rates.txt", "valu_issue_rates.txt")):
     if os.path.exists(os.path.join(src, name)):
         cp(name, out)
@@ -27,6 +29,11 @@ if stats:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), stats[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rocprofv3_kernel_stats.txt"), "w").write(
         "rocprofv3 --kernel-trace --stats -- python3 bench.py   (MI355X, tools/collect_profiles.sh)\n" + txt)
+rstats = glob.glob(os.path.join(src, "trace_rebuild", "**", "*kernel_stats.csv"), recursive=True)
+if rstats:
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), rstats[0]], capture_output=True, text=True).stdout
+    open(os.path.join(dst, tag + "_rebuild_kernel_stats.txt"), "w").write(
+        "rocprofv3 --kernel-trace --stats -- python3 tools/rebuild_loop.py 1e7 10   (12 rebuilds of 10 M points, auto bounding box)\n" + txt)
 pmc = os.path.join(src, "pmc", "pmc_summary.json")
 if os.path.exists(pmc):
     shutil.copyfile(pmc, os.path.join(dst, tag + "_pmc_summary.json"))
