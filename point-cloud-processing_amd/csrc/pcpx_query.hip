@@ -130,9 +130,9 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 #ifndef PCPX_COMPACT_BY8
 #define PCPX_COMPACT_BY8 1     // k <= 16 kernel: compaction in chunks of 8 keys (80 VGPRs, 6 waves/SIMD): 1171 -> 1250 Mq/s
 #endif
-#ifndef PCPX_COMPACT_BY8_32
-#define PCPX_COMPACT_BY8_32 0  // k <= 32 kernel: measured worse (720 vs 735 Mq/s; 5 waves/SIMD spill 308 B: 692)
-#endif
+// (the k <= 32 kernel keeps the 16-key compaction: the chunked form measured worse in round 1 -- 720 vs 735 Mq/s, 5 waves/SIMD
+//  spill 308 B -- and relies on the empty-slots-hold-PAD_KEY invariant that only the k <= 16 kernels establish; under the Hilbert
+//  order, 10 M points k = 32: 16 rows 1021 Mq/s, 14 rows 995, 12 rows 969, 5 waves/SIMD 570)
 #ifndef PCPX_BUF8
 #define PCPX_BUF8 10   // k <= 8: 10 rows x 512 B = 5 KB per wave, 8 waves/SIMD (10 M uniform, k = 8, Mq/s, chunk-of-8 compaction: 7 waves 9 rows 1506, 7/10 1530, 8/9 1553, 8/10 1581; the k <= 16 kernel of the time did 1337)
 #endif
@@ -465,7 +465,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 st_c3 += any_lane(cnt > 3) ? 0u : 1u;
                 st_c4 += any_lane(cnt > 4) ? 0u : 1u;
             }
-            if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (KCAP == 32 && PCPX_COMPACT_BY8_32))) compact_by8<KCAP, BUF>(best, col, cnt);
+            if (PCPX_COMPACT_BY8 && KCAP <= 16) compact_by8<KCAP, BUF>(best, col, cnt);
             else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
