@@ -34,6 +34,58 @@ struct knn_result_t
     std::vector<std::uint32_t> count;
 };
 
+// A typed block of device memory (hipMalloc behind the C ABI: this header does not need a HIP toolchain).
+template <class T>
+class device_array_t
+{
+  public:
+    device_array_t() = default;
+    explicit device_array_t(std::size_t count, int device = 0) : n_(count), device_(device)
+    {
+        check(pcpx_device_malloc(static_cast<std::uint64_t>(count) * sizeof(T), device, &p_), "pcpx_device_malloc");
+    }
+    device_array_t(device_array_t const&)            = delete;
+    device_array_t& operator=(device_array_t const&) = delete;
+    device_array_t(device_array_t&& o) noexcept : p_(std::exchange(o.p_, nullptr)), n_(std::exchange(o.n_, 0)), device_(o.device_) {}
+    device_array_t& operator=(device_array_t&& o) noexcept
+    {
+        if (this != &o)
+        {
+            pcpx_device_free(p_, device_);
+            p_      = std::exchange(o.p_, nullptr);
+            n_      = std::exchange(o.n_, 0);
+            device_ = o.device_;
+        }
+        return *this;
+    }
+    ~device_array_t() { pcpx_device_free(p_, device_); }
+    T* data() const { return static_cast<T*>(p_); }
+    std::size_t size() const { return n_; }
+    void upload(T const* src, std::size_t count) { check(pcpx_device_upload(p_, src, count * sizeof(T), device_, nullptr), "pcpx_device_upload"); }
+    // elements [first, first + count) to the host
+    std::vector<T> download(std::size_t first, std::size_t count) const
+    {
+        std::vector<T> out(count);
+        check(pcpx_device_download(out.data(), data() + first, count * sizeof(T), device_, nullptr), "pcpx_device_download");
+        return out;
+    }
+    std::vector<T> download() const { return download(0, n_); }
+
+  private:
+    void* p_       = nullptr;
+    std::size_t n_ = 0;
+    int device_    = 0;
+};
+
+// Device-resident results of the self queries (row i belongs to input point i): nothing crosses PCIe until asked for.
+struct device_rows_t
+{
+    std::uint32_t k = 0;
+    device_array_t<std::uint32_t> idx;    // rows x k
+    device_array_t<std::uint32_t> count;  // rows
+    device_array_t<float> normals;        // rows x 3 (empty unless normals were requested)
+};
+
 class device_index_t
 {
   public:
@@ -88,6 +140,23 @@ class device_index_t
         forget();
         xyz_  = xyz;  // the owner keeps the coordinates alive and rebuilds after any change (see the containers)
         n_in_ = n;
+    }
+
+    // ---- device-resident form: one fused launch, rows and normals stay in HBM (the full rate) ----
+    device_rows_t knn_self_device(std::uint32_t k, float eps, std::uint64_t rows, bool with_normals, int device = 0) const
+    {
+        device_rows_t r;
+        r.k     = k;
+        r.idx   = device_array_t<std::uint32_t>(static_cast<std::size_t>(rows) * k, device);
+        r.count = device_array_t<std::uint32_t>(static_cast<std::size_t>(rows), device);
+        if (with_normals)
+        {
+            r.normals = device_array_t<float>(static_cast<std::size_t>(rows) * 3, device);
+            check(pcpx_normals_knn_self_dev(h_, k, eps, 0, UINT64_MAX, r.normals.data(), r.idx.data(), r.count.data()), "pcpx_normals_knn_self_dev");
+        }
+        else check(pcpx_knn_self_dev(h_, k, eps, 0, UINT64_MAX, r.idx.data(), r.count.data(), nullptr), "pcpx_knn_self_dev");
+        check(pcpx_index_synchronize(h_), "pcpx_index_synchronize");
+        return r;
     }
 
     // ---- per-point calls of an unchanged reference caller -------------------------------------------------

@@ -193,6 +193,15 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
 int pcpx_estimate_normals_batch(const float* xyz, const uint64_t* offsets, uint64_t nrows, int device,
                                 float* out_normals);
 
+/* ---- device memory for callers without a HIP toolchain --------------------------------------------- */
+/* The *_dev forms take raw device pointers; a C or C++ host that does not compile against HIP gets them here
+ * (hipMalloc / hipFree / hipMemcpyAsync + stream synchronisation behind the ABI).  include/pcp/gpu/device_index.hpp builds its
+ * device-resident result handle (pcp::gpu::device_rows_t) on these. */
+int pcpx_device_malloc(uint64_t bytes, int device, void** out_ptr);
+void pcpx_device_free(void* d_ptr, int device);
+int pcpx_device_upload(void* d_dst, const void* src, uint64_t bytes, int device, void* stream);   /* synchronous */
+int pcpx_device_download(void* dst, const void* d_src, uint64_t bytes, int device, void* stream); /* synchronous */
+
 /* ---- multi-GPU: one process per GPU ------------------------------------------------------------ */
 /* Contiguous, 64-aligned shard of the curve-sorted query order for `rank` of `world`. */
 int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count);

@@ -86,6 +86,10 @@ SIGNATURES = {
                                         C.c_void_p]),
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),
     "pcpx_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "pcpx_device_malloc": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
+    "pcpx_device_free": (None, [C.c_void_p, C.c_int]),
+    "pcpx_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
+    "pcpx_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "pcpx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pcpx_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pcpx_comm_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -1224,6 +1224,52 @@ int pcpx_profile_end(pcpx_index* h, pcpx_profile* out)
     return PCPX_OK;
 }
 
+int pcpx_device_malloc(uint64_t bytes, int device, void** out_ptr)
+{
+    if (!out_ptr) return PCPX_ERR_INVALID;
+    *out_ptr = nullptr;
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    hipError_t e = hipMalloc(out_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        *out_ptr = nullptr;
+        (void)hipGetLastError();
+        set_error("hipMalloc(%llu bytes) failed: %s", static_cast<unsigned long long>(bytes), hipGetErrorString(e));
+        return PCPX_ERR_ALLOC;
+    }
+    return PCPX_OK;
+}
+void pcpx_device_free(void* d_ptr, int device)
+{
+    if (!d_ptr) return;
+    DeviceScope dscope;
+    if (dscope.select(device) != PCPX_OK) return;
+    (void)hipFree(d_ptr);
+}
+int pcpx_device_upload(void* d_dst, const void* src, uint64_t bytes, int device, void* stream)
+{
+    if (bytes == 0) return PCPX_OK;
+    if (!d_dst || !src) return PCPX_ERR_INVALID;
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    PCPX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PCPX_OK;
+}
+int pcpx_device_download(void* dst, const void* d_src, uint64_t bytes, int device, void* stream)
+{
+    if (bytes == 0) return PCPX_OK;
+    if (!dst || !d_src) return PCPX_ERR_INVALID;
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    PCPX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PCPX_OK;
+}
+
 int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count)
 {
     if (!out_first || !out_count || world == 0 || rank >= world) return PCPX_ERR_INVALID;

@@ -339,6 +339,35 @@ static void normal_scenarios()
     for (std::size_t j = 0; j < 15u && j < a.size() && j < b.size(); ++j) REQUIRE(b[j].point() == &cloud[a[j]]);
 }
 
+// device-resident results (pcp/gpu/device_index.hpp): the rows and normals of every point stay in HBM, a slice is
+// downloaded on demand; they equal what the host-pointer path returns
+static void device_resident_scenarios()
+{
+    auto const point_map = [](point_t const& p) { return p; };
+    std::mt19937 gen(7);
+    std::uniform_real_distribution<float> dis(0.f, 1.f);
+    std::vector<point_t> cloud(20000);
+    std::generate(cloud.begin(), cloud.end(), [&]() { return point_t{dis(gen), dis(gen), dis(gen)}; });
+    pcp::linked_octree_t octree(cloud.begin(), cloud.end(), point_map);
+    std::uint32_t const k = 15u;
+    auto const& ix = octree.index();
+    pcp::gpu::device_rows_t const dev = ix.knn_self_device(k, 1e-5f, cloud.size(), /*with_normals*/ true);
+    auto const host_rows = ix.knn_self(k, 1e-5f, cloud.size());
+    auto const host_nrm  = ix.normals_self(k, 1e-5f, cloud.size());
+    REQUIRE(dev.idx.size() == cloud.size() * k && dev.normals.size() == cloud.size() * 3);
+    auto const idx = dev.idx.download();
+    auto const cnt = dev.count.download(100, 50);
+    auto const nrm = dev.normals.download(3 * 777, 3);
+    REQUIRE(idx == host_rows.idx);
+    for (std::size_t i = 0; i < cnt.size(); ++i) REQUIRE(cnt[i] == host_rows.count[100 + i]);
+    REQUIRE(nrm[0] == host_nrm[3 * 777] && nrm[1] == host_nrm[3 * 777 + 1] && nrm[2] == host_nrm[3 * 777 + 2]);
+    pcp::gpu::device_array_t<float> up(6);
+    float const six[6] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f};
+    up.upload(six, 6);
+    auto const back = up.download();
+    REQUIRE(back.size() == 6u && back[5] == 6.f);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1 && std::strcmp(argv[1], "--compile-only") == 0) return 0;
@@ -348,6 +377,7 @@ int main(int argc, char** argv)
         octree_range_and_insertion_scenarios();
         kdtree_scenarios();
         normal_scenarios();
+        device_resident_scenarios();
     }
     catch (std::exception const& e)
     {

@@ -4,10 +4,8 @@ import importlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 b = importlib.import_module("point-cloud-processing_amd.build")
-variants = {"i8_s1_l8": [], "i8_s0_l8": ["-DPCPX_SORT_STAGE=0"], "i16_s0_l8": ["-DPCPX_SORT_ITEMS=16", "-DPCPX_SORT_STAGE=0"],
-            "i16_s1_l8": ["-DPCPX_SORT_ITEMS=16"], "i8_s0_l16": ["-DPCPX_SORT_STAGE=0", "-DPCPX_SORT_LOOK=16"],
-            "i16_s0_l16": ["-DPCPX_SORT_ITEMS=16", "-DPCPX_SORT_STAGE=0", "-DPCPX_SORT_LOOK=16"],
-            "i12_s0_l16": ["-DPCPX_SORT_ITEMS=12", "-DPCPX_SORT_STAGE=0", "-DPCPX_SORT_LOOK=16"]}
+variants = {"i16_l8": [], "i16_l4": ["-DPCPX_SORT_LOOK=4"], "i16_l2": ["-DPCPX_SORT_LOOK=2"], "i24_l8": ["-DPCPX_SORT_ITEMS=24"],
+            "i32_l8": ["-DPCPX_SORT_ITEMS=32"], "i32_l4": ["-DPCPX_SORT_ITEMS=32", "-DPCPX_SORT_LOOK=4"], "i24_l4": ["-DPCPX_SORT_ITEMS=24", "-DPCPX_SORT_LOOK=4"]}
 for tag, flags in variants.items():
     lib = b.build(tag=tag, extra_flags=flags) if flags else b.build()
     env = dict(os.environ, PCPX_LIB=lib)
