@@ -23,13 +23,15 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("valu_issue_rates.txt", "valu_issue_rates.txt")):
     if os.path.exists(os.path.join(src, name)):
         cp(name, out)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+# (bench.py starts one child process for the host-pointer ABI side measurement; rocprofv3 writes a file per process: the
+#  main process is the one that finishes last)
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
 if stats:
     shutil.copyfile(stats[0], os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), stats[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rocprofv3_kernel_stats.txt"), "w").write(
         "rocprofv3 --kernel-trace --stats -- python3 bench.py   (MI355X, tools/collect_profiles.sh)\n" + txt)
-rstats = glob.glob(os.path.join(src, "trace_rebuild", "**", "*kernel_stats.csv"), recursive=True)
+rstats = sorted(glob.glob(os.path.join(src, "trace_rebuild", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
 if rstats:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), rstats[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rebuild_kernel_stats.txt"), "w").write(
