@@ -193,6 +193,43 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
 int pcpx_estimate_normals_batch(const float* xyz, const uint64_t* offsets, uint64_t nrows, int device,
                                 float* out_normals);
 
+/* ---- consumers of sphere ranges: bilateral filter and WLOP ------------------------------------------- */
+/* The reference's kd-tree sphere range has two in-library consumers; both loop over every point's range and
+ * reduce it to a few numbers, so here the loop is fused into the range walk (no neighbour list is written).
+ * Arithmetic is the reference's, in float; what is not specified by its interface -- the order in which a
+ * range's points are summed -- is tree order here: results agree with the reference to float rounding
+ * (tests/test_gpu_filters.py states the tolerances), not bit for bit.
+ *
+ * bilateral_filter_points (include/pcp/algorithm/bilateral_filter.hpp:303-428): `iterations` (params_t::K)
+ * rounds of p' = sum w * projection(p) / sum w over the range of radius 2 * sigmaf around p, w = gaussian(sigmaf,
+ * |s - p|) * gaussian(sigmag, |projection - s|), projection onto the neighbour's tangent plane (:47-101); the
+ * range tree is rebuilt over the moved points every round, the normals stay.  xyz, normals, out_xyz: n x 3.
+ * bilateral_filter_normals (:460-574): the normals move instead (n' = normalize(J n), J the Jacobian of the
+ * filter at the point, :103-269), the points and their tree stay.
+ * sigmaf / sigmag are converted to float like the reference converts params_t's doubles to the point's scalar
+ * type.  iterations == 0 copies the input.  out may alias the array it replaces.  A point with a NaN
+ * coordinate has an empty range and comes back NaN.  The *_dev forms take device arrays, run on `stream`
+ * (NULL = the legacy default stream) and return after the work has completed. */
+int pcpx_bilateral_filter_points(const float* xyz, const float* normals, uint64_t n, double sigmaf, double sigmag,
+                                 uint64_t iterations, int device, float* out_xyz);
+int pcpx_bilateral_filter_normals(const float* xyz, const float* normals, uint64_t n, double sigmaf, double sigmag,
+                                  uint64_t iterations, int device, float* out_normals);
+int pcpx_bilateral_filter_points_dev(const float* d_xyz, const float* d_normals, uint64_t n, double sigmaf,
+                                     double sigmag, uint64_t iterations, int device, void* stream, float* d_out_xyz);
+int pcpx_bilateral_filter_normals_dev(const float* d_xyz, const float* d_normals, uint64_t n, double sigmaf,
+                                      double sigmag, uint64_t iterations, int device, void* stream,
+                                      float* d_out_normals);
+/* wlop::wlop (include/pcp/algorithm/wlop.hpp:287-428): weighted locally optimal projection of n_samples points
+ * onto the cloud.  The reference seeds x with a std::random_device shuffle of the cloud (:331-343); here the
+ * caller names the seed points (sample[i] < n, n_samples <= n), everything after that is the reference's:
+ * v_j over the cloud (uniform != 0, :29-65), then per iteration a tree over x, w_i (:67-105), and
+ * x' = median of the cloud around x (:107-170) + mu-weighted repulsion among x (:172-229), radius h.
+ * out_xyz is n_samples x 3 (iterations == 0: the seed points). */
+int pcpx_wlop(const float* xyz, uint64_t n, const uint64_t* sample, uint64_t n_samples, double mu, double h,
+              uint64_t iterations, int uniform, int device, float* out_xyz);
+int pcpx_wlop_dev(const float* d_xyz, uint64_t n, const uint64_t* d_sample, uint64_t n_samples, double mu, double h,
+                  uint64_t iterations, int uniform, int device, void* stream, float* d_out_xyz);
+
 /* ---- device memory for callers without a HIP toolchain --------------------------------------------- */
 /* The *_dev forms take raw device pointers; a C or C++ host that does not compile against HIP gets them here
  * (hipMalloc / hipFree / hipMemcpyAsync + stream synchronisation behind the ABI).  include/pcp/gpu/device_index.hpp builds its

@@ -905,6 +905,339 @@ u64 orc_propagate_normal_orientations(float const* xyz, u64 n, u32 const* nbr, u
     return reached;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Consumers of kd-tree sphere ranges: bilateral filter and WLOP
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// The kd-tree both algorithms build (bilateral_filter.hpp:385-389, wlop.hpp:360-363): compute_max_depth,
+// nth_element construction, 64 elements per leaf.
+std::unique_ptr<KdTree> filter_kdtree(P3 const* pts, u64 n)
+{
+    return std::unique_ptr<KdTree>(
+        static_cast<KdTree*>(orc_kdtree_create(reinterpret_cast<float const*>(pts), n, 12, 1, 64)));
+}
+inline std::vector<u32> filter_range(KdTree const& t, P3 const& c, float r)
+{
+    std::vector<u32> v;
+    if (t.root) kd_range(t, Sphere{c, r}, t.aabb, t.root.get(), v, 0);  // the reference's visiting order
+    return v;
+}
+
+// T = float is the reference's arithmetic (scalar_type = point_t::coordinate_type); T = double is only a yardstick
+// for the tests (how far float summation in ANY neighbour order sits from the real-number value): it takes the
+// neighbour sets from the same float range search.
+template <class T>
+struct V3 {
+    T x, y, z;
+};
+template <class T>
+inline T norm3(T x, T y, T z)
+{
+    T const xx = x * x, yy = y * y, zz = z * z;  // norm.hpp:47-66
+    return std::sqrt(xx + yy + zz);
+}
+// bilateral_filter.hpp:361-370 / :517-526
+template <class T>
+inline T gaussian(T sigma, T r)
+{
+    T const pi = static_cast<T>(3.14159265358979323846);
+    T const s2 = sigma * sigma;
+    T const r2 = r * r;
+    T const power = -r2 / (2 * s2);
+    T const coeff = T(1) / (sigma * std::sqrt(T(2) * pi));
+    return coeff * std::exp(power);
+}
+// :528-537
+template <class T>
+inline T dgaussian(T sigma, T r)
+{
+    T const pi = static_cast<T>(3.14159265358979323846);
+    T const s2 = sigma * sigma;
+    T const s3 = sigma * s2;
+    T const r2 = r * r;
+    T const power = -r2 / (2 * s2);
+    T const coeff = -r / (s3 * std::sqrt(T(2) * pi));
+    return coeff * std::exp(power);
+}
+// :372-379  s + dot(p - s, n) * n  (point - point = vector, inner_product norm.hpp:34-45, k * vector, point + vector)
+template <class T>
+inline V3<T> project(V3<T> const& p, V3<T> const& n, V3<T> const& s)
+{
+    T const spx = p.x - s.x, spy = p.y - s.y, spz = p.z - s.z;
+    T const xx = n.x * spx, yy = n.y * spy, zz = n.z * spz;
+    T const d = xx + yy + zz;
+    return V3<T>{s.x + d * n.x, s.y + d * n.y, s.z + d * n.z};
+}
+
+// bilateral::detail::compute_pi (bilateral_filter.hpp:47-101)
+template <class T>
+V3<T> bilateral_pi(std::vector<u32> const& nb, V3<T> const& s, std::vector<V3<T>> const& pts, std::vector<V3<T>> const& nrm,
+                   T sigmaf, T sigmag)
+{
+    T k = 0;
+    V3<T> sp{0, 0, 0};
+    for (u32 j : nb) {
+        V3<T> const& p = pts[j];
+        V3<T> const pr = project(p, nrm[j], s);
+        T const rf = norm3(s.x - p.x, s.y - p.y, s.z - p.z);
+        T const rg = norm3(pr.x - s.x, pr.y - s.y, pr.z - s.z);
+        T const w = gaussian(sigmaf, rf) * gaussian(sigmag, rg);
+        k += w;
+        sp = V3<T>{sp.x + w * pr.x, sp.y + w * pr.y, sp.z + w * pr.z};
+    }
+    return V3<T>{sp.x / k, sp.y / k, sp.z / k};
+}
+
+// Eigen 3.3.8 fixed-size reductions of 3 terms are a0 + (a1 + a2) (redux_novec_unroller splits 3 as 1 + 2);
+// normalized()/normalize() divide by sqrt(squaredNorm) only when squaredNorm > 0 (Dot.h).
+template <class T>
+inline T sum3(T a, T b, T c)
+{
+    return a + (b + c);
+}
+template <class T>
+inline void normalized3(T const v[3], T out[3])
+{
+    T const z = sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2]);
+    if (z > T(0)) {
+        T const n = std::sqrt(z);
+        out[0] = v[0] / n, out[1] = v[1] / n, out[2] = v[2] / n;
+    } else {
+        out[0] = v[0], out[1] = v[1], out[2] = v[2];
+    }
+}
+
+// bilateral::detail::compute_ni (bilateral_filter.hpp:103-269)
+template <class T>
+V3<T> bilateral_ni(std::vector<u32> const& nb, V3<T> const& s, V3<T> const& ns, std::vector<V3<T>> const& pts,
+                   std::vector<V3<T>> const& nrm, T sigmaf, T sigmag)
+{
+    T Jsum[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    T pifg[3] = {0, 0, 0};
+    T gradk[3] = {0, 0, 0};
+    T k = 0;
+    for (u32 j : nb) {
+        V3<T> const& p = pts[j];
+        V3<T> const& np = nrm[j];
+        V3<T> const pr = project(p, np, s);
+        T const sp[3] = {s.x - p.x, s.y - p.y, s.z - p.z};
+        T const sps[3] = {pr.x - s.x, pr.y - s.y, pr.z - s.z};
+        T const rf = std::sqrt(sum3(sp[0] * sp[0], sp[1] * sp[1], sp[2] * sp[2]));      // Eigen norm()
+        T const rg = std::sqrt(sum3(sps[0] * sps[0], sps[1] * sps[1], sps[2] * sps[2]));
+        T const wf = gaussian(sigmaf, rf);
+        T const wg = gaussian(sigmag, rg);
+        T const w = wf * wg;
+        k += w;
+        pifg[0] += w * pr.x, pifg[1] += w * pr.y, pifg[2] += w * pr.z;
+        T const wdf = dgaussian(sigmaf, rf);
+        T spu[3];
+        normalized3(sp, spu);
+        T const gradf[3] = {spu[0] * wdf, spu[1] * wdf, spu[2] * wdf};
+        T Jpi[3][3];  // :213-222 (as written there: 1 - n_i^2 on the diagonal, +n_i n_j off it)
+        Jpi[0][0] = 1 - (np.x * np.x), Jpi[1][1] = 1 - (np.y * np.y), Jpi[2][2] = 1 - (np.z * np.z);
+        Jpi[0][1] = Jpi[1][0] = np.x * np.y;
+        Jpi[0][2] = Jpi[2][0] = np.x * np.z;
+        Jpi[1][2] = Jpi[2][1] = np.y * np.z;
+        T const wdg = dgaussian(sigmag, rg);
+        T spsu[3];
+        normalized3(sps, spsu);
+        T gradg[3];
+        for (int c = 0; c < 3; ++c) {
+            T const row = sum3(spsu[0] * Jpi[0][c], spsu[1] * Jpi[1][c], spsu[2] * Jpi[2][c]);
+            gradg[c] = (row - spsu[c]) * wdg;
+        }
+        for (int c = 0; c < 3; ++c) gradk[c] += (gradf[c] * wg) + (wf * gradg[c]);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Jsum[r][c] += ((Jpi[r][c] * wf) * wg + (sps[r] * gradf[c]) * wg) + (sps[r] * wf) * gradg[c];
+    }
+    T const ks2_inv = T(1) / (k * k);
+    T J[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r][c] = ks2_inv * (Jsum[r][c] * k - pifg[r] * gradk[c]);
+    T const v[3] = {sum3(J[0][0] * ns.x, J[0][1] * ns.y, J[0][2] * ns.z), sum3(J[1][0] * ns.x, J[1][1] * ns.y, J[1][2] * ns.z),
+                    sum3(J[2][0] * ns.x, J[2][1] * ns.y, J[2][2] * ns.z)};
+    T o[3];
+    normalized3(v, o);
+    return V3<T>{o[0], o[1], o[2]};
+}
+
+template <class T>
+std::vector<V3<T>> widen(float const* a, u64 n)
+{
+    std::vector<V3<T>> v(n);
+    for (u64 i = 0; i < n; ++i) v[i] = V3<T>{T(a[3 * i]), T(a[3 * i + 1]), T(a[3 * i + 2])};
+    return v;
+}
+
+// bilateral_filter_points (:303-428: a new kd-tree over p(k) every iteration) and bilateral_filter_normals
+// (:460-574: one kd-tree, the normals iterate)
+template <class T>
+void bilateral_filter(float const* xyz, float const* normals, u64 n, double sigmaf_, double sigmag_, u64 K, bool do_points,
+                      float* out, int nthreads)
+{
+    T const sigmaf = static_cast<T>(static_cast<float>(sigmaf_)), sigmag = static_cast<T>(static_cast<float>(sigmag_));
+    float const radius = 2.f * static_cast<float>(sigmaf_);  // :73 two * sigmaf, in the point's scalar type
+    std::vector<P3> fpts(reinterpret_cast<P3 const*>(xyz), reinterpret_cast<P3 const*>(xyz) + n);
+    std::vector<V3<T>> pts = widen<T>(xyz, n), nrm = widen<T>(normals, n), tmp(n);
+    std::unique_ptr<KdTree> tree;
+    for (u64 it = 0; it < K; ++it) {
+        if (do_points || it == 0) tree = filter_kdtree(fpts.data(), n);
+        parallel_for(n, nthreads, [&](u64 i) {
+            std::vector<u32> const nb = filter_range(*tree, fpts[i], radius);
+            tmp[i] = do_points ? bilateral_pi<T>(nb, pts[i], pts, nrm, sigmaf, sigmag)
+                               : bilateral_ni<T>(nb, pts[i], nrm[i], pts, nrm, sigmaf, sigmag);
+        });
+        if (do_points) {
+            pts = tmp;
+            for (u64 i = 0; i < n; ++i)
+                fpts[i] = P3{static_cast<float>(pts[i].x), static_cast<float>(pts[i].y), static_cast<float>(pts[i].z)};
+        } else {
+            nrm = tmp;
+        }
+    }
+    std::vector<V3<T>> const& res = do_points ? pts : nrm;
+    for (u64 i = 0; i < n; ++i) {
+        out[3 * i] = static_cast<float>(res[i].x);
+        out[3 * i + 1] = static_cast<float>(res[i].y);
+        out[3 * i + 2] = static_cast<float>(res[i].z);
+    }
+}
+
+// ---- WLOP (wlop.hpp) ----
+template <class T>
+inline bool near_eq(T a, T b)
+{
+    return std::abs(a - b) < static_cast<T>(1e-9);  // floating_point_equals(.., eps = 1e-9 in scalar_type)
+}
+template <class T>
+inline bool same_point(V3<T> const& a, V3<T> const& b)
+{
+    return near_eq(a.x, b.x) && near_eq(a.y, b.y) && near_eq(a.z, b.z);
+}
+template <class T>
+inline T sqd(V3<T> const& p1, V3<T> const& p2)
+{
+    T const dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// wlop.hpp:287-428.  `sample` = the I source indices that seed x (the reference draws them with std::random_device
+// + std::shuffle, :331-343: it has no reproducible choice to restate, so the choice is an input here).
+template <class T>
+void wlop_run(float const* xyz, u64 J, u64 const* sample, u64 I, double mu_, double h_, u64 K, bool uniform, float* out,
+              int nthreads)
+{
+    T const mu = static_cast<T>(static_cast<float>(mu_)), h = static_cast<T>(static_cast<float>(h_));
+    float const hf = static_cast<float>(h_);
+    T const h2 = h * h;
+    T const h_over_4_squared = h2 / T(16);
+    auto theta = [=](T r2) { return std::exp(-r2 / h_over_4_squared); };  // :321-323
+    std::vector<P3> fp(reinterpret_cast<P3 const*>(xyz), reinterpret_cast<P3 const*>(xyz) + J), fx(I);
+    std::vector<V3<T>> P = widen<T>(xyz, J), x(I), xp(I);
+    std::vector<T> vj(J, T(1)), wi(I, T(1));
+    for (u64 i = 0; i < I; ++i) {
+        x[i] = P[sample[i]];
+        fx[i] = fp[sample[i]];
+    }
+    xp = x;
+    std::unique_ptr<KdTree> ptree = filter_kdtree(fp.data(), J);
+    // compute_vj / compute_wi (:29-105): 1 + sum of theta(r2) over the range, points equal to the centre skipped
+    auto density = [&](KdTree const& t, std::vector<P3> const& fpts, std::vector<V3<T>> const& pts, u64 c) {
+        T v{1};
+        for (u32 o : filter_range(t, fpts[c], hf)) {
+            if (same_point(pts[c], pts[o])) continue;
+            v += theta(sqd(pts[c], pts[o]));
+        }
+        return v;
+    };
+    if (uniform) {
+        std::vector<T> v(J);
+        parallel_for(J, nthreads, [&](u64 j) { v[j] = density(*ptree, fp, P, j); });
+        vj = v;
+    }
+    for (u64 it = 0; it < K; ++it) {
+        std::unique_ptr<KdTree> qtree = filter_kdtree(fx.data(), I);
+        if (uniform) {
+            std::vector<T> w(I);
+            parallel_for(I, nthreads, [&](u64 i) { w[i] = density(*qtree, fx, x, i); });
+            wi = w;
+        }
+        parallel_for(I, nthreads, [&](u64 ip) {
+            V3<T> const q = x[ip];
+            // solve_first_energy_median (:107-170)
+            T sum{0};
+            V3<T> med{0, 0, 0};
+            for (u32 j : filter_range(*ptree, fx[ip], hf)) {
+                V3<T> const& p = P[j];
+                if (same_point(q, p)) continue;
+                T const r2 = sqd(q, p);
+                T const r = std::sqrt(r2);
+                T const v = vj[j];
+                T const alpha = near_eq(r, T(0)) ? T(0) : theta(r2) / r;
+                T const coeff = near_eq(v, T(0)) ? T(0) : alpha / v;
+                med = V3<T>{med.x + coeff * p.x, med.y + coeff * p.y, med.z + coeff * p.z};
+                sum += coeff;
+            }
+            if (near_eq(sum, T(0))) med = q;
+            else med = V3<T>{med.x / sum, med.y / sum, med.z / sum};
+            // solve_second_energy_repulsion_force (:172-229)
+            V3<T> rep{0, 0, 0};
+            T rsum{0};
+            for (u32 i : filter_range(*qtree, fx[ip], hf)) {
+                V3<T> const& qi = x[i];
+                if (same_point(qi, q)) continue;
+                T const dx = q.x - qi.x, dy = q.y - qi.y, dz = q.z - qi.z;
+                T const r2 = sqd(q, qi);
+                T const r = std::sqrt(r2);
+                T const beta = near_eq(r, T(0)) ? T(0) : theta(r2) / r;
+                T const coeff = wi[i] * beta;
+                rep = V3<T>{rep.x + coeff * dx, rep.y + coeff * dy, rep.z + coeff * dz};
+                rsum += coeff;
+            }
+            T const f = near_eq(rsum, T(0)) ? T(0) : mu / rsum;
+            rep = V3<T>{f * rep.x, f * rep.y, f * rep.z};
+            xp[ip] = V3<T>{med.x + rep.x, med.y + rep.y, med.z + rep.z};  // :406-409
+        });
+        x = xp;
+        for (u64 i = 0; i < I; ++i)
+            fx[i] = P3{static_cast<float>(x[i].x), static_cast<float>(x[i].y), static_cast<float>(x[i].z)};
+    }
+    for (u64 i = 0; i < I; ++i) {
+        out[3 * i] = static_cast<float>(xp[i].x);
+        out[3 * i + 1] = static_cast<float>(xp[i].y);
+        out[3 * i + 2] = static_cast<float>(xp[i].z);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// pcp::algorithm::bilateral_filter_points / bilateral_filter_normals; f64_yardstick != 0: the same in double (tests only)
+void orc_bilateral_filter_points(float const* xyz, float const* normals, u64 n, double sigmaf, double sigmag, u64 K,
+                                 float* out_xyz, int f64_yardstick, int nthreads)
+{
+    if (f64_yardstick) bilateral_filter<double>(xyz, normals, n, sigmaf, sigmag, K, true, out_xyz, nthreads);
+    else bilateral_filter<float>(xyz, normals, n, sigmaf, sigmag, K, true, out_xyz, nthreads);
+}
+void orc_bilateral_filter_normals(float const* xyz, float const* normals, u64 n, double sigmaf, double sigmag, u64 K,
+                                  float* out_normals, int f64_yardstick, int nthreads)
+{
+    if (f64_yardstick) bilateral_filter<double>(xyz, normals, n, sigmaf, sigmag, K, false, out_normals, nthreads);
+    else bilateral_filter<float>(xyz, normals, n, sigmaf, sigmag, K, false, out_normals, nthreads);
+}
+// pcp::algorithm::wlop::wlop with the initial sample given
+void orc_wlop(float const* xyz, u64 J, u64 const* sample, u64 I, double mu, double h, u64 K, int uniform, float* out_xyz,
+              int f64_yardstick, int nthreads)
+{
+    if (f64_yardstick) wlop_run<double>(xyz, J, sample, I, mu, h, K, uniform != 0, out_xyz, nthreads);
+    else wlop_run<float>(xyz, J, sample, I, mu, h, K, uniform != 0, out_xyz, nthreads);
+}
+
 int orc_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
 
 }  // extern "C"

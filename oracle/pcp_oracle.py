@@ -253,3 +253,33 @@ def mean_dist_from_knn(xyz, queries, nbr, cnt):
     lib().orc_mean_dist_from_knn(_p(xyz, _f32p), _p(q, _f32p), _p(nbr, _u32p), _p(cnt, _u32p), C.c_uint64(nq), C.c_uint32(k),
                                  _p(out, _f32p))
     return out
+
+
+def bilateral_filter_points(xyz, normals, sigmaf, sigmag, K=1, f64_yardstick=False, nthreads=1):
+    """pcp::algorithm::bilateral_filter_points (bilateral_filter.hpp:303-428); f64_yardstick: same in double."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    nrm = _f32(normals).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    lib().orc_bilateral_filter_points(_p(xyz, _f32p), _p(nrm, _f32p), C.c_uint64(len(xyz)), C.c_double(sigmaf), C.c_double(sigmag),
+                                      C.c_uint64(K), _p(out, _f32p), C.c_int(int(f64_yardstick)), C.c_int(nthreads))
+    return out
+
+
+def bilateral_filter_normals(xyz, normals, sigmaf, sigmag, K=1, f64_yardstick=False, nthreads=1):
+    """pcp::algorithm::bilateral_filter_normals (bilateral_filter.hpp:460-574)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    nrm = _f32(normals).reshape(-1, 3)
+    out = np.empty_like(nrm)
+    lib().orc_bilateral_filter_normals(_p(xyz, _f32p), _p(nrm, _f32p), C.c_uint64(len(xyz)), C.c_double(sigmaf), C.c_double(sigmag),
+                                       C.c_uint64(K), _p(out, _f32p), C.c_int(int(f64_yardstick)), C.c_int(nthreads))
+    return out
+
+
+def wlop(xyz, sample, mu, h, K, uniform=True, f64_yardstick=False, nthreads=1):
+    """pcp::algorithm::wlop::wlop (wlop.hpp:287-428) from a given initial sample (indices into xyz)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    sample = np.ascontiguousarray(sample, np.uint64)
+    out = np.empty((len(sample), 3), np.float32)
+    lib().orc_wlop(_p(xyz, _f32p), C.c_uint64(len(xyz)), _p(sample, C.POINTER(C.c_uint64)), C.c_uint64(len(sample)), C.c_double(mu),
+                   C.c_double(h), C.c_uint64(K), C.c_int(int(uniform)), _p(out, _f32p), C.c_int(int(f64_yardstick)), C.c_int(nthreads))
+    return out

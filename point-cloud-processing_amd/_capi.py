@@ -86,6 +86,15 @@ SIGNATURES = {
                                         C.c_void_p]),
     "pcpx_estimate_normal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),
     "pcpx_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "pcpx_bilateral_filter_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_void_p]),
+    "pcpx_bilateral_filter_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_void_p]),
+    "pcpx_bilateral_filter_points_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int,
+                                                   C.c_void_p, C.c_void_p]),
+    "pcpx_bilateral_filter_normals_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int,
+                                                    C.c_void_p, C.c_void_p]),
+    "pcpx_wlop": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),
+    "pcpx_wlop_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p]),
     "pcpx_device_malloc": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "pcpx_device_free": (None, [C.c_void_p, C.c_int]),
     "pcpx_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),

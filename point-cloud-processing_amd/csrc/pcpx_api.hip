@@ -1270,6 +1270,239 @@ int pcpx_device_download(void* dst, const void* d_src, uint64_t bytes, int devic
     return PCPX_OK;
 }
 
+}  // extern "C"
+
+// ---- bilateral filter and WLOP: the in-library consumers of sphere ranges ------------------------
+
+namespace {
+
+// an index these calls build for themselves and drop again (the reference's functions build their own kd-trees too:
+// bilateral_filter.hpp:385-389, wlop.hpp:360-363 / :383-387); works on the caller's stream
+struct TempIndex {
+    Index* ix = nullptr;
+    int make(int device, hipStream_t stream)
+    {
+        ix = new (std::nothrow) Index();
+        if (!ix) return PCPX_ERR_ALLOC;
+        ix->device = device;
+        ix->stream = stream;
+        return PCPX_OK;
+    }
+    ~TempIndex() { free_index(ix); }  // synchronises the stream first: everything enqueued has completed
+};
+
+int check_filter_sizes(const char* what, u64 n)
+{
+    if (n > 0xFFFFFFFFull - 64ull) {
+        set_error("%s: more than 2^32 - 65 points", what);
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    return PCPX_OK;
+}
+
+// bilateral_filter_points (bilateral_filter.hpp:303-428: p(k+1) = F(p(k)), a new tree over p(k) every iteration) and
+// bilateral_filter_normals (:460-574: one tree, n(k+1) from n(k)); everything device resident, stream ordered
+int bilateral_device(const float* d_xyz, const float* d_normals, u64 n, double sigmaf_, double sigmag_, u64 iterations,
+                     bool normals_mode, int device, hipStream_t stream, float* d_out)
+{
+    const char* what = normals_mode ? "pcpx_bilateral_filter_normals" : "pcpx_bilateral_filter_points";
+    const float sigmaf = static_cast<float>(sigmaf_), sigmag = static_cast<float>(sigmag_);
+    if (!(sigmaf > 0.f) || !(sigmag > 0.f)) {  // the reference asserts both (:329-330)
+        set_error("%s: sigmaf and sigmag must be positive", what);
+        return PCPX_ERR_INVALID;
+    }
+    if (n == 0) return PCPX_OK;
+    if (!d_xyz || !d_normals || !d_out) {
+        set_error("%s: null argument", what);
+        return PCPX_ERR_INVALID;
+    }
+    int st = check_filter_sizes(what, n);
+    if (st != PCPX_OK) return st;
+    const float* first = normals_mode ? d_normals : d_xyz;
+    if (iterations == 0) {  // (the reference asserts K > 0; zero iterations of a filter is its input)
+        if (d_out != first) PCPX_HIP(hipMemcpyAsync(d_out, first, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        return check_hip(hipStreamSynchronize(stream), "bilateral sync", __FILE__, __LINE__);
+    }
+    TempIndex tmp;
+    if ((st = tmp.make(device, stream)) != PCPX_OK) return st;
+    Index& ix = *tmp.ix;
+    DevBuf attr(ix.pool), keep(ix.pool);
+    const size_t attr_bytes = ((n + LEAF - 1) / LEAF) * LEAF * 3 * sizeof(float);
+    if ((st = attr.alloc(attr_bytes)) != PCPX_OK) return st;
+    // d_out may alias an input (in-place filtering): the aliased input is then copied first
+    const float* src_xyz = d_xyz;
+    const float* src_nrm = d_normals;
+    if (d_out == d_xyz || d_out == d_normals) {
+        if ((st = keep.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
+        PCPX_HIP(hipMemcpyAsync(keep.p, d_out, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        if (d_out == d_xyz) src_xyz = keep.as<float>();
+        if (d_out == d_normals) src_nrm = keep.as<float>();
+    }
+    // a centre that is not in the tree (a NaN coordinate) has an empty range: sprime / 0 = NaN in the reference
+    bool first_write = true;
+    for (u64 it = 0; it < iterations; ++it) {
+        if (!normals_mode || it == 0) {
+            if ((st = build_index(ix, (!normals_mode && it > 0) ? d_out : src_xyz, n, nullptr)) != PCPX_OK) return st;
+        }
+        if ((st = launch_leaf_attributes(ix, (normals_mode && it > 0) ? d_out : src_nrm, 3, attr.as<float>())) != PCPX_OK) return st;
+        if (first_write) {
+            PCPX_HIP(hipMemsetAsync(d_out, 0xFF, n * 3 * sizeof(float), stream));
+            first_write = false;
+        }
+        if ((st = launch_bilateral(ix, attr.as<float>(), sigmaf, sigmag, normals_mode, d_out)) != PCPX_OK) return st;
+    }
+    return check_hip(hipStreamSynchronize(stream), "bilateral sync", __FILE__, __LINE__);
+}
+
+// wlop::wlop (wlop.hpp:287-428) from a given initial sample: x = cloud[sample]; every iteration builds a tree over x,
+// (uniform) recomputes the sample densities w_i, and moves every x to median(cloud around x) + repulsion(x around x)
+int wlop_device(const float* d_xyz, u64 n, const u64* d_sample, u64 m, double mu_, double h_, u64 iterations, bool uniform, int device,
+                hipStream_t stream, float* d_out)
+{
+    const char* what = "pcpx_wlop";
+    const float mu = static_cast<float>(mu_), h = static_cast<float>(h_);
+    if (m == 0) return PCPX_OK;
+    if (!d_xyz || !d_sample || !d_out || n == 0) {
+        set_error("%s: null argument or an empty cloud", what);
+        return PCPX_ERR_INVALID;
+    }
+    if (m > n) {  // the reference asserts I > 0 && J >= I (:309)
+        set_error("%s: %llu samples from %llu points", what, static_cast<unsigned long long>(m), static_cast<unsigned long long>(n));
+        return PCPX_ERR_INVALID;
+    }
+    if (!(mu >= 0.f && mu <= 0.5f) || !(h > 0.f)) {  // :310 (and a radius)
+        set_error("%s: mu must lie in [0, 0.5] and h must be positive", what);
+        return PCPX_ERR_INVALID;
+    }
+    int st = check_filter_sizes(what, n);
+    if (st != PCPX_OK) return st;
+    TempIndex cloud, samples;
+    if ((st = cloud.make(device, stream)) != PCPX_OK || (st = samples.make(device, stream)) != PCPX_OK) return st;
+    Index& P = *cloud.ix;
+    Index& Q = *samples.ix;
+    DevBuf vj_rows(P.pool), vj_leaf(P.pool), x(Q.pool), med(Q.pool), wi_rows(Q.pool), wi_leaf(Q.pool);
+    if ((st = vj_rows.alloc(n * sizeof(float))) != PCPX_OK || (st = vj_leaf.alloc(((n + LEAF - 1) / LEAF) * LEAF * sizeof(float))) != PCPX_OK ||
+        (st = x.alloc(m * 3 * sizeof(float))) != PCPX_OK || (st = med.alloc(m * 3 * sizeof(float))) != PCPX_OK ||
+        (st = wi_rows.alloc(m * sizeof(float))) != PCPX_OK || (st = wi_leaf.alloc(((m + LEAF - 1) / LEAF) * LEAF * sizeof(float))) != PCPX_OK)
+        return st;
+    if ((st = build_index(P, d_xyz, n, nullptr)) != PCPX_OK) return st;
+    if ((st = launch_fill_f32(vj_rows.as<float>(), n, 1.f, stream)) != PCPX_OK) return st;  // :311 v_j = 1 (LOP keeps it)
+    if (uniform && (st = launch_wlop_density(P, h, vj_rows.as<float>())) != PCPX_OK) return st;  // :365-376
+    if ((st = launch_leaf_attributes(P, vj_rows.as<float>(), 1, vj_leaf.as<float>())) != PCPX_OK) return st;
+    if ((st = launch_take_rows(d_xyz, n, d_sample, m, x.as<float>(), stream)) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(d_out, x.p, m * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));  // :343 xp = x
+    for (u64 it = 0; it < iterations; ++it) {
+        if ((st = build_index(Q, x.as<float>(), m, nullptr)) != PCPX_OK) return st;
+        if ((st = launch_fill_f32(wi_rows.as<float>(), m, 1.f, stream)) != PCPX_OK) return st;
+        if (uniform && (st = launch_wlop_density(Q, h, wi_rows.as<float>())) != PCPX_OK) return st;  // :389-399
+        if ((st = launch_leaf_attributes(Q, wi_rows.as<float>(), 1, wi_leaf.as<float>())) != PCPX_OK) return st;
+        QueryView qv{};
+        if ((st = prepare_queries(P, x.as<float>(), m, qv)) != PCPX_OK) return st;
+        if ((st = launch_wlop_median(P, qv, h, vj_leaf.as<float>(), med.as<float>())) != PCPX_OK) return st;
+        PCPX_HIP(hipMemsetAsync(d_out, 0xFF, m * 3 * sizeof(float), stream));  // a sample with a NaN coordinate stays NaN
+        if ((st = launch_wlop_repulsion(Q, h, mu, wi_leaf.as<float>(), med.as<float>(), d_out)) != PCPX_OK) return st;
+        PCPX_HIP(hipMemcpyAsync(x.p, d_out, m * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));  // :417 x = xp
+    }
+    return check_hip(hipStreamSynchronize(stream), "wlop sync", __FILE__, __LINE__);
+}
+
+// host-pointer form of the two bilateral filters: stage in, run, stage out
+int bilateral_host(const float* xyz, const float* normals, u64 n, double sigmaf, double sigmag, u64 iterations, bool normals_mode, int device,
+                   float* out)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    if (n == 0) return PCPX_OK;
+    if (!xyz || !normals || !out) {
+        set_error("pcpx_bilateral_filter: null argument");
+        return PCPX_ERR_INVALID;
+    }
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    DevBuf dp(shared.pool), dn(shared.pool), dout(shared.pool);
+    const size_t bytes = n * 3 * sizeof(float);
+    if ((st = dp.alloc(bytes)) != PCPX_OK || (st = dn.alloc(bytes)) != PCPX_OK || (st = dout.alloc(bytes)) != PCPX_OK) return st;
+    PCPX_HIP(hipMemcpyAsync(dp.p, xyz, bytes, hipMemcpyHostToDevice, nullptr));
+    PCPX_HIP(hipMemcpyAsync(dn.p, normals, bytes, hipMemcpyHostToDevice, nullptr));
+    if ((st = bilateral_device(dp.as<float>(), dn.as<float>(), n, sigmaf, sigmag, iterations, normals_mode, device, nullptr, dout.as<float>())) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, nullptr));
+    PCPX_HIP(hipStreamSynchronize(nullptr));
+    return PCPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcpx_bilateral_filter_points(const float* xyz, const float* normals, uint64_t n, double sigmaf, double sigmag, uint64_t iterations,
+                                 int device, float* out_xyz)
+{
+    return bilateral_host(xyz, normals, n, sigmaf, sigmag, iterations, false, device, out_xyz);
+}
+int pcpx_bilateral_filter_normals(const float* xyz, const float* normals, uint64_t n, double sigmaf, double sigmag, uint64_t iterations,
+                                  int device, float* out_normals)
+{
+    return bilateral_host(xyz, normals, n, sigmaf, sigmag, iterations, true, device, out_normals);
+}
+int pcpx_bilateral_filter_points_dev(const float* d_xyz, const float* d_normals, uint64_t n, double sigmaf, double sigmag,
+                                     uint64_t iterations, int device, void* stream, float* d_out_xyz)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    return bilateral_device(d_xyz, d_normals, n, sigmaf, sigmag, iterations, false, device, static_cast<hipStream_t>(stream), d_out_xyz);
+}
+int pcpx_bilateral_filter_normals_dev(const float* d_xyz, const float* d_normals, uint64_t n, double sigmaf, double sigmag,
+                                      uint64_t iterations, int device, void* stream, float* d_out_normals)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    return bilateral_device(d_xyz, d_normals, n, sigmaf, sigmag, iterations, true, device, static_cast<hipStream_t>(stream), d_out_normals);
+}
+
+int pcpx_wlop_dev(const float* d_xyz, uint64_t n, const uint64_t* d_sample, uint64_t n_samples, double mu, double h, uint64_t iterations,
+                  int uniform, int device, void* stream, float* d_out_xyz)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    return wlop_device(d_xyz, n, d_sample, n_samples, mu, h, iterations, uniform != 0, device, static_cast<hipStream_t>(stream), d_out_xyz);
+}
+int pcpx_wlop(const float* xyz, uint64_t n, const uint64_t* sample, uint64_t n_samples, double mu, double h, uint64_t iterations, int uniform,
+              int device, float* out_xyz)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    if (n_samples == 0) return PCPX_OK;
+    if (!xyz || !sample || !out_xyz || n == 0) {
+        set_error("pcpx_wlop: null argument or an empty cloud");
+        return PCPX_ERR_INVALID;
+    }
+    for (u64 i = 0; i < n_samples; ++i)
+        if (sample[i] >= n) {
+            set_error("pcpx_wlop: sample[%llu] = %llu is not an index into the cloud", static_cast<unsigned long long>(i),
+                      static_cast<unsigned long long>(sample[i]));
+            return PCPX_ERR_INVALID;
+        }
+    DeviceShared& shared = shared_of(device);
+    std::lock_guard<std::mutex> lock(shared.mu);
+    DevBuf dp(shared.pool), ds(shared.pool), dout(shared.pool);
+    if ((st = dp.alloc(n * 3 * sizeof(float))) != PCPX_OK || (st = ds.alloc(n_samples * sizeof(u64))) != PCPX_OK ||
+        (st = dout.alloc(n_samples * 3 * sizeof(float))) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(dp.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    PCPX_HIP(hipMemcpyAsync(ds.p, sample, n_samples * sizeof(u64), hipMemcpyHostToDevice, nullptr));
+    if ((st = wlop_device(dp.as<float>(), n, ds.as<u64>(), n_samples, mu, h, iterations, uniform != 0, device, nullptr, dout.as<float>())) != PCPX_OK)
+        return st;
+    PCPX_HIP(hipMemcpyAsync(out_xyz, dout.p, n_samples * 3 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    PCPX_HIP(hipStreamSynchronize(nullptr));
+    return PCPX_OK;
+}
+
 int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count)
 {
     if (!out_first || !out_count || world == 0 || rank >= world) return PCPX_ERR_INVALID;

@@ -435,7 +435,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.idx_bits, ix.d_codes[0]);
         PCPX_HIP(hipGetLastError());
         size_t tb = ix.sort_tmp_bytes;
-        int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, CURVE_FIRST_BIT);
+        int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT);
         if (st != PCPX_OK) return st;
         k_count_valid<<<1, 64, 0, s>>>(ix.d_codes[1], static_cast<u32>(n), ix.d_scalars + 6, sort_failure_flag(ix.d_sort_tmp));
     } else {

@@ -89,9 +89,9 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
     if (nq > 0) {
         const float* d_box = reinterpret_cast<const float*>(ix.d_scalars + 8);
         const int qbits = index_bits_for(nq);
-        const int cmp_shift = std::max(CURVE_FIRST_BIT, std::max(qbits, ix.idx_bits));
+        const int cmp_shift = std::max(SORT_FIRST_BIT, std::max(qbits, ix.idx_bits));
         k_query_codes<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, n32, d_box, qbits, codes0);
-        if ((st = sort_keys_u64(base + o_tmp, tb, codes0, codes1, nq, s, CURVE_FIRST_BIT)) != PCPX_OK) return st;
+        if ((st = sort_keys_u64(base + o_tmp, tb, codes0, codes1, nq, s, SORT_FIRST_BIT)) != PCPX_OK) return st;
         k_query_gather<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, codes1, qbits, n32, qx, qy, qz, row);
         k_query_seeds<<<static_cast<u32>((ngroups + 255) / 256), 256, 0, s>>>(
             codes1, n32, ix.sorted_codes(), static_cast<u32>(ix.n), ix.nleaves, cmp_shift, seed, static_cast<u32>(ngroups));
