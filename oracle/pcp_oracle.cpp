@@ -14,6 +14,12 @@
 //   test/kdtree/kdtree_range_search.cpp, test/octree/octree_insertion.cpp,
 //   test/common/normal_estimation.cpp, test/common/aabb.cpp.
 //
+// The two in-library consumers of kd-tree sphere ranges, bilateral_filter_points / _normals and wlop::wlop, are restated
+// too (bottom of this file).  The reference's tests for them hold properties only, no numbers
+// (test/algorithm/bilateral_filter.cpp:126-129,148-150; test/algorithm/wlop.cpp:79-96): the restatement is pinned by
+// those scenarios and by an independent float64 evaluation of the formulas (tests/test_oracle_filters.py) -- for these
+// two algorithms "parity unpinned" beyond that, and by tolerance in any case (float sums in an unspecified order).
+//
 // Third-party arithmetic not under /root/reference: Eigen 3.3.8
 // SelfAdjointEigenSolver<Matrix3f>::compute (called at
 // include/pcp/common/normals/normal_estimation.hpp:53).  Its published algorithm

@@ -1327,8 +1327,7 @@ int bilateral_device(const float* d_xyz, const float* d_normals, u64 n, double s
     if ((st = tmp.make(device, stream)) != PCPX_OK) return st;
     Index& ix = *tmp.ix;
     DevBuf attr(ix.pool), keep(ix.pool);
-    const size_t attr_bytes = ((n + LEAF - 1) / LEAF) * LEAF * 3 * sizeof(float);
-    if ((st = attr.alloc(attr_bytes)) != PCPX_OK) return st;
+    if ((st = attr.alloc(leaf_record_bytes(n, 3))) != PCPX_OK) return st;
     // d_out may alias an input (in-place filtering): the aliased input is then copied first
     const float* src_xyz = d_xyz;
     const float* src_nrm = d_normals;
@@ -1344,12 +1343,12 @@ int bilateral_device(const float* d_xyz, const float* d_normals, u64 n, double s
         if (!normals_mode || it == 0) {
             if ((st = build_index(ix, (!normals_mode && it > 0) ? d_out : src_xyz, n, nullptr)) != PCPX_OK) return st;
         }
-        if ((st = launch_leaf_attributes(ix, (normals_mode && it > 0) ? d_out : src_nrm, 3, attr.as<float>())) != PCPX_OK) return st;
+        if ((st = launch_leaf_records(ix, (normals_mode && it > 0) ? d_out : src_nrm, 3, attr.p)) != PCPX_OK) return st;
         if (first_write) {
             PCPX_HIP(hipMemsetAsync(d_out, 0xFF, n * 3 * sizeof(float), stream));
             first_write = false;
         }
-        if ((st = launch_bilateral(ix, attr.as<float>(), sigmaf, sigmag, normals_mode, d_out)) != PCPX_OK) return st;
+        if ((st = launch_bilateral(ix, attr.p, sigmaf, sigmag, normals_mode, d_out)) != PCPX_OK) return st;
     }
     return check_hip(hipStreamSynchronize(stream), "bilateral sync", __FILE__, __LINE__);
 }
@@ -1381,26 +1380,32 @@ int wlop_device(const float* d_xyz, u64 n, const u64* d_sample, u64 m, double mu
     Index& P = *cloud.ix;
     Index& Q = *samples.ix;
     DevBuf vj_rows(P.pool), vj_leaf(P.pool), x(Q.pool), med(Q.pool), wi_rows(Q.pool), wi_leaf(Q.pool);
-    if ((st = vj_rows.alloc(n * sizeof(float))) != PCPX_OK || (st = vj_leaf.alloc(((n + LEAF - 1) / LEAF) * LEAF * sizeof(float))) != PCPX_OK ||
+    if ((st = vj_rows.alloc(n * sizeof(float))) != PCPX_OK || (st = vj_leaf.alloc(leaf_record_bytes(n, 1))) != PCPX_OK ||
         (st = x.alloc(m * 3 * sizeof(float))) != PCPX_OK || (st = med.alloc(m * 3 * sizeof(float))) != PCPX_OK ||
-        (st = wi_rows.alloc(m * sizeof(float))) != PCPX_OK || (st = wi_leaf.alloc(((m + LEAF - 1) / LEAF) * LEAF * sizeof(float))) != PCPX_OK)
+        (st = wi_rows.alloc(m * sizeof(float))) != PCPX_OK || (st = wi_leaf.alloc(leaf_record_bytes(m, 1))) != PCPX_OK)
         return st;
     if ((st = build_index(P, d_xyz, n, nullptr)) != PCPX_OK) return st;
     if ((st = launch_fill_f32(vj_rows.as<float>(), n, 1.f, stream)) != PCPX_OK) return st;  // :311 v_j = 1 (LOP keeps it)
-    if (uniform && (st = launch_wlop_density(P, h, vj_rows.as<float>())) != PCPX_OK) return st;  // :365-376
-    if ((st = launch_leaf_attributes(P, vj_rows.as<float>(), 1, vj_leaf.as<float>())) != PCPX_OK) return st;
+    if (uniform) {  // :365-376
+        if ((st = launch_leaf_records(P, nullptr, 0, vj_leaf.p)) != PCPX_OK) return st;
+        if ((st = launch_wlop_density(P, h, vj_leaf.p, vj_rows.as<float>())) != PCPX_OK) return st;
+    }
+    if ((st = launch_leaf_records(P, vj_rows.as<float>(), 1, vj_leaf.p)) != PCPX_OK) return st;
     if ((st = launch_take_rows(d_xyz, n, d_sample, m, x.as<float>(), stream)) != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(d_out, x.p, m * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));  // :343 xp = x
     for (u64 it = 0; it < iterations; ++it) {
         if ((st = build_index(Q, x.as<float>(), m, nullptr)) != PCPX_OK) return st;
         if ((st = launch_fill_f32(wi_rows.as<float>(), m, 1.f, stream)) != PCPX_OK) return st;
-        if (uniform && (st = launch_wlop_density(Q, h, wi_rows.as<float>())) != PCPX_OK) return st;  // :389-399
-        if ((st = launch_leaf_attributes(Q, wi_rows.as<float>(), 1, wi_leaf.as<float>())) != PCPX_OK) return st;
+        if (uniform) {  // :389-399
+            if ((st = launch_leaf_records(Q, nullptr, 0, wi_leaf.p)) != PCPX_OK) return st;
+            if ((st = launch_wlop_density(Q, h, wi_leaf.p, wi_rows.as<float>())) != PCPX_OK) return st;
+        }
+        if ((st = launch_leaf_records(Q, wi_rows.as<float>(), 1, wi_leaf.p)) != PCPX_OK) return st;
         QueryView qv{};
         if ((st = prepare_queries(P, x.as<float>(), m, qv)) != PCPX_OK) return st;
-        if ((st = launch_wlop_median(P, qv, h, vj_leaf.as<float>(), med.as<float>())) != PCPX_OK) return st;
+        if ((st = launch_wlop_median(P, qv, h, vj_leaf.p, med.as<float>())) != PCPX_OK) return st;
         PCPX_HIP(hipMemsetAsync(d_out, 0xFF, m * 3 * sizeof(float), stream));  // a sample with a NaN coordinate stays NaN
-        if ((st = launch_wlop_repulsion(Q, h, mu, wi_leaf.as<float>(), med.as<float>(), d_out)) != PCPX_OK) return st;
+        if ((st = launch_wlop_repulsion(Q, h, mu, wi_leaf.p, med.as<float>(), d_out)) != PCPX_OK) return st;
         PCPX_HIP(hipMemcpyAsync(x.p, d_out, m * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));  // :417 x = xp
     }
     return check_hip(hipStreamSynchronize(stream), "wlop sync", __FILE__, __LINE__);

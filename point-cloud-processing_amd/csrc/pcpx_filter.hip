@@ -3,9 +3,9 @@
 // pcp::algorithm::wlop::wlop (include/pcp/algorithm/wlop.hpp), fused into the range walk.  The reference materialises
 // every range (kdtree.range_search -> std::vector of elements) and then loops over it; here a lane is one range centre,
 // the wave walks the tree once for its 64 centres exactly as k_range does (pcpx_range.hip), and every point that passes a
-// lane's d2 <= r*r test (sphere.hpp:52-56) goes straight into that lane's accumulators under EXEC: no neighbour list is
-// ever written.  Per-point attributes the loops read (the neighbour's normal, its density weight) are gathered once into
-// leaf order, so a leaf's attributes arrive by scalar loads next to its coordinates.
+// lane's d2 <= r*r test (sphere.hpp:52-56) is noted in a short per-lane LDS list that the lane folds into its accumulators
+// every few leaves: no neighbour list ever reaches memory.  Per-point attributes the loops read (the neighbour's normal, its density weight) are gathered once into
+// leaf order, next to the coordinates they belong to.
 //
 // Arithmetic is the reference's, in float, statement by statement (fp contraction off); what differs is the ORDER in which
 // a centre's neighbours are summed (tree order here, kd-tree visiting order there: neither is specified by the reference's
@@ -16,25 +16,44 @@ namespace pcpx {
 
 namespace {
 
-struct Attr3 {
-    float a[LEAF], b[LEAF], c[LEAF];
+// One record per leaf slot, in leaf order: the point and the per-point attribute its range loop reads (the neighbour's
+// normal; its density weight), together in one 32-byte sector so that a lane working its list off fetches a neighbour
+// with one or two wide loads instead of six scattered dwords (the texture addresser, shared by the CU's four SIMDs, was
+// the limiter when coordinates and attributes were fetched from the leaves and from SoA attribute arrays).
+struct __attribute__((aligned(16))) Rec4 {  // x y z + one scalar
+    float x, y, z, a;
 };
-struct Attr1 {
-    float a[LEAF];
+struct __attribute__((aligned(32))) Rec8 {  // x y z + a 3-vector
+    float x, y, z, a, b, c, pad0, pad1;
 };
+static_assert(sizeof(Rec4) == 16 && sizeof(Rec8) == 32, "record sizes");
 
-// attribute rows (n_in x C, input order) -> leaf order; padding slots get 0
+// C = 3: Rec8 with the attribute rows (n_in x 3, input order); C = 1: Rec4 with a scalar per point; C = 0: Rec4, a = 0.
+// Padding slots hold NaN coordinates (they are never listed) and zero attributes.
 template <int C>
-__global__ __launch_bounds__(256) void k_leaf_attributes(const Leaf* __restrict__ leaves, u32 nslots, const float* __restrict__ attr,
-                                                         float* __restrict__ out)
+__global__ __launch_bounds__(256) void k_leaf_records(const Leaf* __restrict__ leaves, u32 nslots, const float* __restrict__ attr,
+                                                      float* __restrict__ out)
 {
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nslots) return;
-    const u32 leaf = p / LEAF, s = p % LEAF;
-    const u32 id = leaves[leaf].id[s];
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-        out[(static_cast<u64>(leaf) * C + c) * LEAF + s] = id == INVALID_ID ? 0.f : attr[static_cast<u64>(id) * C + c];
+    const Leaf& lf = leaves[p / LEAF];
+    const u32 s = p % LEAF;
+    const u32 id = lf.id[s];
+    const bool real = id != INVALID_ID;
+    if (C == 3) {
+        Rec8 r;
+        r.x = lf.x[s], r.y = lf.y[s], r.z = lf.z[s];
+        r.a = real ? attr[3ull * id] : 0.f;
+        r.b = real ? attr[3ull * id + 1] : 0.f;
+        r.c = real ? attr[3ull * id + 2] : 0.f;
+        r.pad0 = r.pad1 = 0.f;
+        reinterpret_cast<Rec8*>(out)[p] = r;
+    } else {
+        Rec4 r;
+        r.x = lf.x[s], r.y = lf.y[s], r.z = lf.z[s];
+        r.a = (C == 1 && real) ? attr[id] : 0.f;
+        reinterpret_cast<Rec4*>(out)[p] = r;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ p, u64 n, float v)
@@ -58,12 +77,57 @@ __global__ __launch_bounds__(256) void k_take_rows(const float* __restrict__ xyz
 
 // ------------------------------------------------------------------------------------------------
 // the walk: one group of 64 range centres, one per lane (self: the centres are the indexed points themselves, in leaf
-// order; batch: prepared queries).  Acc supplies begin / enter (a new leaf: load its attributes) / add (one accepted
-// neighbour, called under the lane's EXEC bit) / finish.
+// order; batch: prepared queries).  The wave-uniform walk tests a leaf's 8 points against all 64 ranges (8 VALU each); an
+// accepted point is only NOTED -- its leaf slot appended to the lane's own column of an LDS list -- because the
+// arithmetic of one neighbour (two exp, two sqrt, three divisions for the bilateral weight; far more for its Jacobian)
+// run under the EXEC mask of the few lanes that accepted that very point would keep ~5 % of the lanes busy.  When a
+// column could overflow, and at the end, every lane works its own list off, all lanes busy: slot -> the point's record (one
+// 16- or 32-byte load per lane), then Acc::add.  A lane's neighbours are still added in
+// the order the walk met them, so the result does not depend on where the flushes fall.
+// Acc supplies begin / add (one neighbour) / finish.
 // ------------------------------------------------------------------------------------------------
+// A list entry is 16 bits: the slot relative to the first slot of the leaf the walk stood at when the lists were last
+// emptied (the walk yields leaves in ascending order, so the offset is never negative; the lists are emptied before it
+// could exceed 16 bits).  Half the LDS of 32-bit entries, and LDS is what bounds the resident waves here -- the walk hides
+// its scalar-load latency with them (measured: 32-bit entries at 32 per lane 7.5 ms for the bilateral points loop over
+// 10 M ranges of ~42 points, 16-bit entries 5.7 ms).
+// Acc::CAP = entries per lane between two flushes, per loop, by measurement: a long list keeps more lanes busy when it
+// is worked off (the normal loop's Jacobian, ~400 instructions per neighbour: 13.0 ms at 32 entries, 8.0 ms at 64), a
+// short one leaves LDS for more waves (everything else: within 3 % between 32 and 48).
+#ifndef PCPX_CAP_POINTS
+#define PCPX_CAP_POINTS 40
+#endif
+#ifndef PCPX_CAP_NORMALS
+#define PCPX_CAP_NORMALS 64
+#endif
+#ifndef PCPX_CAP_DENSITY
+#define PCPX_CAP_DENSITY 40
+#endif
+#ifndef PCPX_CAP_MEDIAN
+#define PCPX_CAP_MEDIAN 40
+#endif
+#ifndef PCPX_CAP_REPULSION
+#define PCPX_CAP_REPULSION 40
+#endif
+typedef unsigned short list_entry;
+constexpr u32 LIST_SPAN = 65536u / LEAF;  // leaves one epoch of the lists can address
+
+template <class Acc>
+__device__ __forceinline__ void flush_list(const list_entry* list, const u32 base_slot, const u32 lane, const u32 cnt, const float qx,
+                                           const float qy, const float qz, Acc& acc)
+{
+    for (u32 i = 0; any_lane(i < cnt); ++i) {
+        if (i < cnt) {
+            const typename Acc::Rec r = acc.recs[base_slot + list[i * GROUP + lane]];
+            const float dx = r.x - qx, dy = r.y - qy, dz = r.z - qz;
+            acc.add(r, sq3(dx, dy, dz));  // (the same d2 the walk computed)
+        }
+    }
+}
+
 template <bool SELF, class Acc>
 __device__ __forceinline__ void visit_group(const TreeView& t, const QueryView& qv, const u32 g, const float radius, Acc& acc,
-                                            const u32 lane)
+                                            list_entry* list, const u32 lane)
 {
     const u32 p = g * GROUP + lane;
     const u32 nq = SELF ? t.n : qv.nq;
@@ -88,20 +152,34 @@ __device__ __forceinline__ void visit_group(const TreeView& t, const QueryView& 
     acc.begin(qx, qy, qz, p, valid);
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
     Walker wk;
-    u32 leaf = 0, nexp = 0;
+    u32 leaf = 0, nexp = 0, cnt = 0;
     bool more = wk.start(t, need, nexp);
     if (!more) more = wk.next(t, need, leaf, nexp);
+    u32 base_leaf = leaf;  // wave-uniform: the epoch of the lists
     while (more) {
+        if (leaf - base_leaf >= LIST_SPAN) {  // offsets from here on would not fit an entry
+            flush_list(list, base_leaf * LEAF, lane, cnt, qx, qy, qz, acc);
+            cnt = 0;
+            base_leaf = leaf;
+        }
         const Leaf lf = load_const(t.leaves + leaf);
-        acc.enter(leaf);
+        const u32 rel = (leaf - base_leaf) * LEAF;
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
             const float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-            const float d2 = sq3(dx, dy, dz);  // = common::squared_distance(centre, point), norm.hpp:102-112
-            if (d2 <= r2) acc.add(j, lf.x[j], lf.y[j], lf.z[j], d2);
+            if (sq3(dx, dy, dz) <= r2) {  // = common::squared_distance(centre, point) <= r*r, norm.hpp:102-112
+                list[cnt * GROUP + lane] = static_cast<list_entry>(rel + j);
+                ++cnt;
+            }
+        }
+        if (any_lane(cnt > Acc::CAP - LEAF)) {  // the next leaf could overflow a column
+            flush_list(list, base_leaf * LEAF, lane, cnt, qx, qy, qz, acc);
+            cnt = 0;
+            base_leaf = leaf;
         }
         more = wk.next(t, need, leaf, nexp);
     }
+    flush_list(list, base_leaf * LEAF, lane, cnt, qx, qy, qz, acc);
     if (valid) acc.finish(row);
 }
 
@@ -133,20 +211,20 @@ __device__ __forceinline__ float norm3(float x, float y, float z)
 
 // bilateral::detail::compute_pi (bilateral_filter.hpp:47-101)
 struct BilateralPoints {
-    const Attr3* nrm;
+    using Rec = Rec8;
+    static constexpr int CAP = PCPX_CAP_POINTS;
+    const Rec8* recs;  // point + its normal
     Gauss f, g;
     float* out;  // n_in x 3
     float sx, sy, sz, k, ax, ay, az;
-    Attr3 cur;
     __device__ __forceinline__ void begin(float qx, float qy, float qz, u32, bool)
     {
         sx = qx, sy = qy, sz = qz;
         k = ax = ay = az = 0.f;
     }
-    __device__ __forceinline__ void enter(u32 leaf) { cur = load_const(nrm + leaf); }
-    __device__ __forceinline__ void add(int j, float px, float py, float pz, float)
+    __device__ __forceinline__ void add(const Rec8& r, float)
     {
-        const float nx = cur.a[j], ny = cur.b[j], nz = cur.c[j];
+        const float px = r.x, py = r.y, pz = r.z, nx = r.a, ny = r.b, nz = r.c;
         // projection (:372-379): s + inner_product(p - s, n) * n
         const float spx = px - sx, spy = py - sy, spz = pz - sz;
         const float xx = nx * spx, yy = ny * spy, zz = nz * spz;
@@ -184,28 +262,28 @@ __device__ __forceinline__ void normalized3(float x, float y, float z, float& ox
 
 // bilateral::detail::compute_ni (bilateral_filter.hpp:103-269): the Jacobian of the filter at s applied to s's normal
 struct BilateralNormals {
-    const Attr3* nrm;
+    using Rec = Rec8;
+    static constexpr int CAP = PCPX_CAP_NORMALS;
+    const Rec8* recs;  // point + its normal
     Gauss f, g;
     float* out;  // n_in x 3
     float sx, sy, sz, nsx, nsy, nsz;
     float k, pi0, pi1, pi2, gk0, gk1, gk2;
     float J00, J01, J02, J10, J11, J12, J20, J21, J22;
-    Attr3 cur;
     __device__ __forceinline__ void begin(float qx, float qy, float qz, u32 p, bool valid)
     {
         sx = qx, sy = qy, sz = qz;
         nsx = nsy = nsz = 0.f;
-        if (valid) {  // the centre's own normal: its slot of the leaf-ordered attributes
-            const Attr3& mine = nrm[p / LEAF];
-            nsx = mine.a[p % LEAF], nsy = mine.b[p % LEAF], nsz = mine.c[p % LEAF];
+        if (valid) {  // the centre's own normal: its own record
+            const Rec8 mine = recs[p];
+            nsx = mine.a, nsy = mine.b, nsz = mine.c;
         }
         k = pi0 = pi1 = pi2 = gk0 = gk1 = gk2 = 0.f;
         J00 = J01 = J02 = J10 = J11 = J12 = J20 = J21 = J22 = 0.f;
     }
-    __device__ __forceinline__ void enter(u32 leaf) { cur = load_const(nrm + leaf); }
-    __device__ __forceinline__ void add(int j, float px, float py, float pz, float)
+    __device__ __forceinline__ void add(const Rec8& r, float)
     {
-        const float nx = cur.a[j], ny = cur.b[j], nz = cur.c[j];
+        const float px = r.x, py = r.y, pz = r.z, nx = r.a, ny = r.b, nz = r.c;
         const float spx = px - sx, spy = py - sy, spz = pz - sz;
         const float xx = nx * spx, yy = ny * spy, zz = nz * spz;
         const float d = xx + yy + zz;
@@ -273,6 +351,9 @@ __device__ __forceinline__ bool near_eq(float a, float b) { return fabsf(a - b) 
 
 // compute_vj / compute_wi (wlop.hpp:29-105): 1 + sum of theta(r2) over the range, points equal to the centre skipped
 struct WlopDensity {
+    using Rec = Rec4;
+    static constexpr int CAP = PCPX_CAP_DENSITY;
+    const Rec4* recs;
     float h16;   // (h * h) / 16
     float* out;  // n_in
     float sx, sy, sz, v;
@@ -281,10 +362,9 @@ struct WlopDensity {
         sx = qx, sy = qy, sz = qz;
         v = 1.f;
     }
-    __device__ __forceinline__ void enter(u32) {}
-    __device__ __forceinline__ void add(int, float px, float py, float pz, float d2)
+    __device__ __forceinline__ void add(const Rec4& r, float d2)
     {
-        if (near_eq(sx, px) && near_eq(sy, py) && near_eq(sz, pz)) return;
+        if (near_eq(sx, r.x) && near_eq(sy, r.y) && near_eq(sz, r.z)) return;
         v += expf(-d2 / h16);
     }
     __device__ __forceinline__ void finish(u32 row) { out[row] = v; }
@@ -292,22 +372,23 @@ struct WlopDensity {
 
 // solve_first_energy_median (wlop.hpp:107-170): centres are the samples x, the tree holds the input cloud and its v_j
 struct WlopMedian {
-    const Attr1* vj;
+    using Rec = Rec4;
+    static constexpr int CAP = PCPX_CAP_MEDIAN;
+    const Rec4* recs;  // cloud point + its v_j
     float h16;
     float* out;  // I x 3
     float sx, sy, sz, sum, mx, my, mz;
-    Attr1 cur;
     __device__ __forceinline__ void begin(float qx, float qy, float qz, u32, bool)
     {
         sx = qx, sy = qy, sz = qz;
         sum = mx = my = mz = 0.f;
     }
-    __device__ __forceinline__ void enter(u32 leaf) { cur = load_const(vj + leaf); }
-    __device__ __forceinline__ void add(int j, float px, float py, float pz, float d2)
+    __device__ __forceinline__ void add(const Rec4& rec, float d2)
     {
+        const float px = rec.x, py = rec.y, pz = rec.z;
         if (near_eq(sx, px) && near_eq(sy, py) && near_eq(sz, pz)) return;
         const float r = sqrtf(d2);
-        const float v = cur.a[j];
+        const float v = rec.a;
         const float alpha = near_eq(r, 0.f) ? 0.f : expf(-d2 / h16) / r;
         const float coeff = near_eq(v, 0.f) ? 0.f : alpha / v;
         mx += coeff * px;
@@ -327,25 +408,26 @@ struct WlopMedian {
 // solve_second_energy_repulsion_force (wlop.hpp:172-229) + the update x' = median + repulsion (:406-409): centres and
 // tree are both the samples x
 struct WlopRepulsion {
-    const Attr1* wi;
+    using Rec = Rec4;
+    static constexpr int CAP = PCPX_CAP_REPULSION;
+    const Rec4* recs;  // sample + its w_i
     float h16, mu;
     const float* median;  // I x 3
     float* out;           // I x 3
     float sx, sy, sz, sum, rx, ry, rz;
-    Attr1 cur;
     __device__ __forceinline__ void begin(float qx, float qy, float qz, u32, bool)
     {
         sx = qx, sy = qy, sz = qz;
         sum = rx = ry = rz = 0.f;
     }
-    __device__ __forceinline__ void enter(u32 leaf) { cur = load_const(wi + leaf); }
-    __device__ __forceinline__ void add(int j, float px, float py, float pz, float d2)
+    __device__ __forceinline__ void add(const Rec4& rec, float d2)
     {
+        const float px = rec.x, py = rec.y, pz = rec.z;
         if (near_eq(px, sx) && near_eq(py, sy) && near_eq(pz, sz)) return;
         const float dx = sx - px, dy = sy - py, dz = sz - pz;
         const float r = sqrtf(d2);
         const float beta = near_eq(r, 0.f) ? 0.f : expf(-d2 / h16) / r;
-        const float coeff = cur.a[j] * beta;
+        const float coeff = rec.a * beta;
         rx += coeff * dx;
         ry += coeff * dy;
         rz += coeff * dz;
@@ -364,10 +446,11 @@ struct WlopRepulsion {
 template <bool SELF, class Acc>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_accumulate(TreeView t, QueryView qv, u32 group_end, float radius, Acc acc)
 {
+    __shared__ list_entry lists[WAVES_PER_BLOCK][Acc::CAP * GROUP];
     const u32 lane = threadIdx.x & 63u;
     const u32 g = virtual_block() * WAVES_PER_BLOCK + wave_in_block();
     if (g >= group_end) return;
-    visit_group<SELF>(t, qv, g, radius, acc, lane);
+    visit_group<SELF>(t, qv, g, radius, acc, lists[wave_in_block()], lane);
 }
 
 template <bool SELF, class Acc>
@@ -401,23 +484,26 @@ inline float h_over_4_squared(float h)
 
 }  // namespace
 
-size_t leaf_attribute_bytes(const Index& ix, int components)
+size_t leaf_record_bytes(u64 points, int components)
 {
-    return static_cast<size_t>(ix.nleaves) * LEAF * sizeof(float) * static_cast<size_t>(components);
+    return static_cast<size_t>((points + LEAF - 1) / LEAF) * LEAF * (components == 3 ? sizeof(Rec8) : sizeof(Rec4));
 }
 
-int launch_leaf_attributes(Index& ix, const float* d_attr, int components, float* d_leaf_attr)
+int launch_leaf_records(Index& ix, const float* d_attr, int components, void* d_records)
 {
     const u32 nslots = ix.nleaves * LEAF;
     if (nslots == 0) return PCPX_OK;
     const u32 blocks = (nslots + 255) / 256;
+    float* out = static_cast<float*>(d_records);
     if (components == 3)
-        k_leaf_attributes<3><<<blocks, 256, 0, ix.stream>>>(ix.d_leaves, nslots, d_attr, d_leaf_attr);
+        k_leaf_records<3><<<blocks, 256, 0, ix.stream>>>(ix.d_leaves, nslots, d_attr, out);
     else if (components == 1)
-        k_leaf_attributes<1><<<blocks, 256, 0, ix.stream>>>(ix.d_leaves, nslots, d_attr, d_leaf_attr);
+        k_leaf_records<1><<<blocks, 256, 0, ix.stream>>>(ix.d_leaves, nslots, d_attr, out);
+    else if (components == 0)
+        k_leaf_records<0><<<blocks, 256, 0, ix.stream>>>(ix.d_leaves, nslots, nullptr, out);
     else
         return PCPX_ERR_INVALID;
-    return check_hip(hipGetLastError(), "k_leaf_attributes launch", __FILE__, __LINE__);
+    return check_hip(hipGetLastError(), "k_leaf_records launch", __FILE__, __LINE__);
 }
 
 int launch_fill_f32(float* d_p, u64 n, float v, hipStream_t s)
@@ -434,50 +520,51 @@ int launch_take_rows(const float* d_xyz, u64 n, const u64* d_sample, u64 m, floa
     return check_hip(hipGetLastError(), "k_take_rows launch", __FILE__, __LINE__);
 }
 
-int launch_bilateral(Index& ix, const float* d_leaf_normals, float sigmaf, float sigmag, bool normals_mode, float* d_out)
+int launch_bilateral(Index& ix, const void* d_records, float sigmaf, float sigmag, bool normals_mode, float* d_out)
 {
     const float radius = 2.f * sigmaf;  // bilateral_filter.hpp:73 / :143
     const QueryView none{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    const Attr3* nrm = reinterpret_cast<const Attr3*>(d_leaf_normals);
+    const Rec8* nrm = static_cast<const Rec8*>(d_records);
     if (normals_mode) {
         BilateralNormals acc{};
-        acc.nrm = nrm;
+        acc.recs = nrm;
         acc.f = gauss_of(sigmaf);
         acc.g = gauss_of(sigmag);
         acc.out = d_out;
         return launch_accumulate<true>(ix, none, radius, acc, "bilateral normals launch");
     }
     BilateralPoints acc{};
-    acc.nrm = nrm;
+    acc.recs = nrm;
     acc.f = gauss_of(sigmaf);
     acc.g = gauss_of(sigmag);
     acc.out = d_out;
     return launch_accumulate<true>(ix, none, radius, acc, "bilateral points launch");
 }
 
-int launch_wlop_density(Index& ix, float h, float* d_out)
+int launch_wlop_density(Index& ix, float h, const void* d_records, float* d_out)
 {
     const QueryView none{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     WlopDensity acc{};
+    acc.recs = static_cast<const Rec4*>(d_records);
     acc.h16 = h_over_4_squared(h);
     acc.out = d_out;
     return launch_accumulate<true>(ix, none, h, acc, "wlop density launch");
 }
 
-int launch_wlop_median(Index& cloud, const QueryView& samples, float h, const float* d_leaf_vj, float* d_median)
+int launch_wlop_median(Index& cloud, const QueryView& samples, float h, const void* d_records_vj, float* d_median)
 {
     WlopMedian acc{};
-    acc.vj = reinterpret_cast<const Attr1*>(d_leaf_vj);
+    acc.recs = static_cast<const Rec4*>(d_records_vj);
     acc.h16 = h_over_4_squared(h);
     acc.out = d_median;
     return launch_accumulate<false>(cloud, samples, h, acc, "wlop median launch");
 }
 
-int launch_wlop_repulsion(Index& samples, float h, float mu, const float* d_leaf_wi, const float* d_median, float* d_out)
+int launch_wlop_repulsion(Index& samples, float h, float mu, const void* d_records_wi, const float* d_median, float* d_out)
 {
     const QueryView none{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     WlopRepulsion acc{};
-    acc.wi = reinterpret_cast<const Attr1*>(d_leaf_wi);
+    acc.recs = static_cast<const Rec4*>(d_records_wi);
     acc.h16 = h_over_4_squared(h);
     acc.mu = mu;
     acc.median = d_median;

@@ -245,14 +245,14 @@ int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_r
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
 int launch_normals_csr(const float* d_xyz, const u64* d_offsets, u64 nrows, float* d_out, hipStream_t s);
 // filter.hip: the loops that consume sphere ranges (bilateral filter, WLOP), fused into the range walk
-size_t leaf_attribute_bytes(const Index& ix, int components);
-int launch_leaf_attributes(Index& ix, const float* d_attr, int components, float* d_leaf_attr);  // rows (input order) -> leaf order
+size_t leaf_record_bytes(u64 points, int components);  // components: 3 (32-byte records), 1 or 0 (16-byte records)
+int launch_leaf_records(Index& ix, const float* d_attr, int components, void* d_records);  // point + attribute row, leaf order
 int launch_fill_f32(float* d_p, u64 n, float v, hipStream_t s);
 int launch_take_rows(const float* d_xyz, u64 n, const u64* d_sample, u64 m, float* d_out, hipStream_t s);
-int launch_bilateral(Index& ix, const float* d_leaf_normals, float sigmaf, float sigmag, bool normals_mode, float* d_out);
-int launch_wlop_density(Index& ix, float h, float* d_out);
-int launch_wlop_median(Index& cloud, const QueryView& samples, float h, const float* d_leaf_vj, float* d_median);
-int launch_wlop_repulsion(Index& samples, float h, float mu, const float* d_leaf_wi, const float* d_median, float* d_out);
+int launch_bilateral(Index& ix, const void* d_records, float sigmaf, float sigmag, bool normals_mode, float* d_out);
+int launch_wlop_density(Index& ix, float h, const void* d_records, float* d_out);
+int launch_wlop_median(Index& cloud, const QueryView& samples, float h, const void* d_records_vj, float* d_median);
+int launch_wlop_repulsion(Index& samples, float h, float mu, const void* d_records_wi, const float* d_median, float* d_out);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
 int prepare_queue(Index& ix);  // zeroes the work-queue counters of the persistent kernels (stream-ordered)
 

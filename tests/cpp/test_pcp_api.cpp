@@ -11,8 +11,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <execution>
+#include <array>
 #include <iterator>
+#include <numeric>
 #include <random>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -368,6 +371,94 @@ static void device_resident_scenarios()
     REQUIRE(back.size() == 6u && back[5] == 6.f);
 }
 
+// the two consumers of kd-tree sphere ranges, written as test/algorithm/bilateral_filter.cpp and
+// test/algorithm/wlop.cpp write them against the reference's headers
+static void filter_scenarios()
+{
+    // nine points on the x axis, the third lifted and the seventh lowered by 0.01, normals up except at those two
+    std::vector<pcp::point_t> points;
+    for (int i = 0; i < 9; ++i) points.push_back(pcp::point_t{-0.1f + 0.025f * static_cast<float>(i), 0.f, 0.f});
+    points[2].z(0.01f);
+    points[6].z(-0.01f);
+    points[4].x(0.f);
+    std::vector<pcp::normal_t> normals(9, pcp::normal_t{0.f, 0.f, 1.f});
+    normals[2] = pcp::normal_t{-0.19611614f, 0.f, 0.98058068f};
+    normals[6] = pcp::normal_t{0.19611614f, 0.f, 0.98058068f};
+    std::vector<std::size_t> indices(points.size());
+    std::iota(indices.begin(), indices.end(), 0u);
+    auto const point_map      = [&](std::size_t const i) { return points[i]; };
+    auto const normal_map     = [&](std::size_t const i) { return normals[i]; };
+    auto const coordinate_map = [&](std::size_t const i) { return std::array<float, 3u>{points[i].x(), points[i].y(), points[i].z()}; };
+    auto const mean_distance  = [&](std::size_t k) {
+        pcp::kdtree::construction_params_t params;
+        params.compute_max_depth = true;
+        pcp::basic_linked_kdtree_t<std::size_t, 3u, decltype(coordinate_map)> kdtree{indices.begin(), indices.end(), coordinate_map, params};
+        auto const knn_map = [&](std::size_t const i) { return kdtree.nearest_neighbours(i, k); };
+        return pcp::algorithm::average_distance_to_neighbors(indices.begin(), indices.end(), point_map, knn_map);
+    };
+    {
+        pcp::algorithm::bilateral::params_t params;
+        params.K      = 2u;
+        params.sigmaf = static_cast<double>(mean_distance(2u));
+        params.sigmag = params.sigmaf / 8.;
+        std::vector<pcp::point_t> filtered_points{};
+        pcp::algorithm::bilateral_filter_points(indices.begin(), indices.end(), std::back_inserter(filtered_points), point_map, normal_map, params);
+        REQUIRE(filtered_points.size() == points.size());
+        REQUIRE(points[2].z() > filtered_points[2].z());  // the lifted point comes down
+        REQUIRE(points[6].z() < filtered_points[6].z());  // the lowered one comes up
+        std::vector<pcp::normal_t> filtered_normals{};
+        pcp::algorithm::bilateral_filter_normals(indices.begin(), indices.end(), std::back_inserter(filtered_normals), point_map, normal_map, params);
+        REQUIRE(filtered_normals.size() == indices.size());
+        for (auto const& n : filtered_normals) REQUIRE(std::abs(n.nx() * n.nx() + n.ny() * n.ny() + n.nz() * n.nz() - 1.f) < 1e-5f);
+        // writing through a plain iterator into preallocated storage
+        std::vector<pcp::point_t> again(points.size());
+        auto const last = pcp::algorithm::bilateral_filter_points(indices.begin(), indices.end(), again.begin(), point_map, normal_map, params);
+        REQUIRE(last == again.end());
+        for (std::size_t i = 0; i < again.size(); ++i) REQUIRE(again[i].z() == filtered_points[i].z());
+        bool threw = false;
+        params.K = 0u;
+        try { pcp::algorithm::bilateral_filter_points(indices.begin(), indices.end(), again.begin(), point_map, normal_map, params); }
+        catch (std::invalid_argument const&) { threw = true; }
+        REQUIRE(threw);
+    }
+    {
+        // a random cloud resampled to half its size
+        std::mt19937 gen(11);
+        std::uniform_real_distribution<float> dis(-10.f, 10.f);
+        std::size_t const n = 1000u;
+        std::vector<pcp::point_t> cloud(n);
+        std::generate(cloud.begin(), cloud.end(), [&]() { return pcp::point_t{dis(gen), dis(gen), dis(gen)}; });
+        std::vector<std::size_t> ids(n);
+        std::iota(ids.begin(), ids.end(), 0u);
+        auto const pmap = [&](std::size_t const i) { return cloud[i]; };
+        auto const cmap = [&](std::size_t const i) { return std::array<float, 3u>{cloud[i].x(), cloud[i].y(), cloud[i].z()}; };
+        pcp::kdtree::construction_params_t kp;
+        kp.compute_max_depth = true;
+        pcp::basic_linked_kdtree_t<std::size_t, 3u, decltype(cmap)> kdtree{ids.begin(), ids.end(), cmap, kp};
+        auto const knn_map = [&](std::size_t const i) { return kdtree.nearest_neighbours(i, 15u); };
+        pcp::algorithm::wlop::params_t params;
+        params.k       = 2u;
+        params.I       = n / 2;
+        params.h       = static_cast<double>(pcp::algorithm::average_distance_to_neighbors(ids.begin(), ids.end(), pmap, knn_map));
+        params.uniform = true;
+        std::vector<pcp::point_t> downsampled_points{};
+        pcp::algorithm::wlop::wlop(ids.begin(), ids.end(), std::back_inserter(downsampled_points), pmap, params);
+        REQUIRE(downsampled_points.size() == params.I);
+        bool bad = false;
+        for (auto const& p : downsampled_points)
+            bad |= !std::isfinite(p.x()) || !std::isfinite(p.y()) || !std::isfinite(p.z());
+        REQUIRE(!bad);
+        // the reproducible overload: the same seed points give the same answer
+        std::vector<std::uint64_t> sample(params.I);
+        std::iota(sample.begin(), sample.end(), std::uint64_t{250});
+        std::vector<pcp::point_t> a, b;
+        pcp::algorithm::wlop::wlop(ids.begin(), ids.end(), std::back_inserter(a), pmap, params, sample);
+        pcp::algorithm::wlop::wlop(ids.begin(), ids.end(), std::back_inserter(b), pmap, params, sample);
+        REQUIRE(a.size() == sample.size());
+        for (std::size_t i = 0; i < a.size(); ++i) REQUIRE(a[i].x() == b[i].x() && a[i].y() == b[i].y() && a[i].z() == b[i].z());
+    }
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1 && std::strcmp(argv[1], "--compile-only") == 0) return 0;
@@ -378,6 +469,7 @@ int main(int argc, char** argv)
         kdtree_scenarios();
         normal_scenarios();
         device_resident_scenarios();
+        filter_scenarios();
     }
     catch (std::exception const& e)
     {
