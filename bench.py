@@ -386,6 +386,15 @@ def main():
             extra.update(json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1]))
         except Exception as e:  # a side measurement must not take the bench line down
             extra["host_api_error"] = repr(e)[:200]
+        if args.workload == "uniform_10m_k15":
+            # the in-library consumers of sphere ranges on the same cloud (bilateral filter, WLOP), own process
+            # for the same reason
+            try:
+                child = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "filter_bench.py"),
+                                        str(n), "2"], capture_output=True, text=True, timeout=600)
+                extra["range_consumers"] = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
+            except Exception as e:
+                extra["range_consumers_error"] = repr(e)[:200]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
