@@ -262,3 +262,38 @@ def test_wlop_edge_cases(pkg, oracle):
     with pytest.raises(pkg.PcpxError):
         pkg.wlop(pts, mu=0.4, h=0.0, k=1, sample=sample)
     assert pkg.wlop(pts, mu=0.4, h=0.1, k=1, sample=np.zeros(0, np.uint64)).shape == (0, 3)
+
+
+def test_filters_at_scale(pkg, oracle):
+    """600 k points (75 000 leaves, 9 375 query groups): deep trees, walks whose leaves lie more than one list epoch
+    (8 192 leaves) apart, many resident waves -- every row of one bilateral iteration (points and normals) and of one WLOP
+    iteration against the oracle, plus a range wide enough (~ 2 500 points) to flush every lane's list dozens of times.
+    (The same at 2 M points: positions 8.9e-7, normals 2.7e-7 over all but 9 ill-conditioned rows, WLOP 2.0e-6.)"""
+    n = 600_000
+    pts = pkg.synthetic.uniform_cloud(n, 46)
+    tree = pkg.LinkedOctree(pts)
+    nrm = tree.normals_knn_self(15)
+    sigmaf = 0.005 * (n / 1e7) ** (-1.0 / 3.0)  # ~42 points per range
+    got = pkg.bilateral_filter_points(pts, nrm, sigmaf, sigmaf / 4, K=1)
+    exp = oracle.bilateral_filter_points(pts, nrm, sigmaf, sigmaf / 4, K=1, nthreads=16)
+    err = np.abs(got - exp).max()
+    print("600 k bilateral points: |gpu-oracle| max %.2e" % err)
+    assert err <= POS_TOL
+    gn = pkg.bilateral_filter_normals(pts, nrm, sigmaf, sigmaf / 4, K=1)
+    en = oracle.bilateral_filter_normals(pts, nrm, sigmaf, sigmaf / 4, K=1, nthreads=16)
+    c = 1.0 - np.sum(gn.astype(np.float64) * en, axis=1)
+    print("600 k bilateral normals: 1-cos max %.2e, rows beyond tolerance %d" % (c.max(), int((c > COS_TOL).sum())))
+    assert (c > COS_TOL).mean() <= 1e-4  # (the odd row where the reference's J n cancels to rounding noise)
+    m = 60_000
+    sample = np.random.default_rng(3).permutation(n)[:m].astype(np.uint64)
+    h = 0.02 * (n / 1e7) ** (-1.0 / 3.0)
+    gw = pkg.wlop(pts, mu=0.45, h=h, k=1, uniform=True, sample=sample)
+    ew = oracle.wlop(pts, sample, 0.45, h, 1, uniform=True, nthreads=16)
+    print("600 k / 60 k WLOP: |gpu-oracle| max %.2e" % np.abs(gw - ew).max())
+    assert np.abs(gw - ew).max() <= POS_TOL
+    sub = np.ascontiguousarray(pts[:30_000])
+    subn = np.ascontiguousarray(nrm[:30_000])
+    gwide = pkg.bilateral_filter_points(sub, subn, 0.15, 0.03, K=1)
+    ewide = oracle.bilateral_filter_points(sub, subn, 0.15, 0.03, K=1, nthreads=16)
+    print("wide ranges: |gpu-oracle| max %.2e" % np.abs(gwide - ewide).max())
+    assert np.abs(gwide - ewide).max() <= 2 * POS_TOL  # (sums of thousands of terms)
