@@ -20,7 +20,8 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("batch_query_rate.json", "batch_query_rate.json"), ("latency.json", "latency.json"),
                   ("shard_rate.json", "shard_rate.json"), ("pcie_rate.json", "pcie_rate.json"),
                   ("rebuild_10m.json", "rebuild_10m.json"), ("rebuild_50m.json", "rebuild_50m.json"),
-                  ("valu_issue_rates.txt", "valu_issue_rates.txt")):
+                  ("valu_issue_rates.txt", "valu_issue_rates.txt"), ("filter_bench.json", "filter_bench.json"),
+                  ("fuzz_filters.json", "fuzz_filters.json")):
     if os.path.exists(os.path.join(src, name)):
         cp(name, out)
 # (bench.py starts one child process for the host-pointer ABI side measurement; rocprofv3 writes a file per process: the
@@ -36,6 +37,12 @@ if rstats:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), rstats[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rebuild_kernel_stats.txt"), "w").write(
         "rocprofv3 --kernel-trace --stats -- python3 tools/rebuild_loop.py 1e7 10   (12 rebuilds of 10 M points, auto bounding box)\n" + txt)
+fstats = sorted(glob.glob(os.path.join(src, "trace_filter", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+if fstats:
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), fstats[0]], capture_output=True, text=True).stdout
+    open(os.path.join(dst, tag + "_filter_kernel_stats.txt"), "w").write(
+        "rocprofv3 --kernel-trace --stats -- python3 tools/filter_bench.py 1e7 1   (10 M uniform points, ranges of radius 0.01 / WLOP h = 0.02, "
+        "4 iterations per call, 2 calls)\n" + txt)
 pmc = os.path.join(src, "pmc", "pmc_summary.json")
 if os.path.exists(pmc):
     shutil.copyfile(pmc, os.path.join(dst, tag + "_pmc_summary.json"))

@@ -39,4 +39,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 echo "rebuild done"
 # 8. instruction issue costs
 hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && timeout -k 10 120 /tmp/valu_rate > "$out/valu_issue_rates.txt" 2>&1
+# 9. the range consumers (bilateral filter, WLOP): throughput and per-kernel times; randomised parity
+timeout -k 10 400 python3 tools/filter_bench.py 1e7 3 > "$out/filter_bench.json" 2>> "$out/bench.err" || echo "filter bench failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_filter" -- python3 tools/filter_bench.py 1e7 1 > "$out/filter_under_prof.json" 2>> "$out/bench.err"
+timeout -k 10 300 python3 tests/fuzz_filters.py 90 4242 > "$out/fuzz_filters.log" 2>&1; tail -1 "$out/fuzz_filters.log" > "$out/fuzz_filters.json"
 echo "all done"
