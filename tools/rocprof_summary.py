@@ -5,7 +5,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
     n = r["Name"]
-    m = re.search(r"pcpx::\(anonymous namespace\)::(k_[a-z_0-9]+(<[^>]*>)?)", n)
+    n = n.replace("pcpx::(anonymous namespace)::", "")  # (also inside template argument lists)
+    m = re.search(r"\b(k_[a-z_0-9]+(<[^>(]*>)?)", n)
     if m: n = m.group(1)
     elif "radix_sort_onesweep_iteration" in n: n = "rocprim::radix_sort_onesweep_iteration"
     elif "onesweep_histograms" in n: n = "rocprim::radix_sort_onesweep_histograms"
