@@ -311,6 +311,9 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane)
 {
     const float inf = std::numeric_limits<float>::infinity();
+    // `lane` is made opaque here: otherwise the sixteen `l < lane` masks below are loop invariants of the persistent
+    // kernel and hipcc keeps them in 32 SGPRs for its whole lifetime
+    asm volatile("" : "+v"(lane));
     const bool sample = (lane & 3u) == 1u;
     const float x = (valid && tau < inf) ? tau : inf;
     const u64 finite = __builtin_amdgcn_ballot_w64(sample && x < inf);
@@ -345,11 +348,18 @@ struct MultiPass {
 
 // One query group (64 Morton-consecutive queries, one per lane) from start to finish.
 template <int KCAP, bool SELF, bool STATS, bool MULTI>
-__device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k, const float eps,
+__device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k_arg, const float eps,
                                           const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
                                           u64* __restrict__ col, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
+    // k is made opaque per group: everything derived from it alone -- the initial best-list (slots below KCAP - k hold 0, the
+    // others PAD_KEY) and the epilogue's per-slot predicates -- is otherwise a loop invariant of the persistent kernel and is
+    // held in 4 x KCAP SGPRs from the first group to the last; the walk's own scalars then spill into VGPR lanes, and those
+    // VGPRs are what pushed the k <= 16 kernel into scratch
+    u32 k_here = k_arg;
+    asm volatile("" : "+s"(k_here));
+    const u32 k = k_here;
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
@@ -360,7 +370,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     if (STATS) tc0 = __builtin_amdgcn_s_memtime();
 
     // ---- my query ----
-    const u32 p = g * GROUP + lane;
+    u32 p_here = g * GROUP + lane;
+    asm volatile("" : "+v"(p_here));  // (opaque: or the lane-only pieces of every address formed from p stay pinned in VGPR pairs across groups)
+    const u32 p = p_here;
     const u32 nq = SELF ? t.n : qv.nq;
     const bool valid = p < nq;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -630,7 +642,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 
     if (!valid) return;
     // output row = original index of the query (read here, not at the start: one VGPR less through the search loop)
-    const u32 row = SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
+    // (the query's position is formed again rather than kept: as a 64-bit record offset it sat in a VGPR pair all through the search)
+    u32 p_row = g * GROUP + lane;
+    asm volatile("" : "+v"(p_row));
+    const u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : qv.row[p_row];
     u32 found = 0;
     u32 okmask = 0;
     const u64 ob = static_cast<u64>(row) * k;
