@@ -9,7 +9,8 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
 def cp(a, b):
-    shutil.copyfile(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))
+    if os.path.exists(os.path.join(src, a)):  # (the script also runs on the GPU box half way through the collection)
+        shutil.copyfile(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))
 
 cp("bench.json", "bench.json")
 cp("bench_under_rocprofv3.json", "bench_under_rocprofv3.json")

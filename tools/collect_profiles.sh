@@ -7,15 +7,17 @@ tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# 1. the bench line (default workload, CPU baseline included; --with-1m adds the configs[1] side figure)
-timeout -k 10 400 python3 bench.py --with-1m > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
-echo "bench done"
-# 2. the default command (python3 bench.py) under rocprofv3 --kernel-trace --stats
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py > "$out/bench_under_rocprofv3.json" 2> "$out/trace.err" || { echo "trace failed"; tail -5 "$out/trace.err"; exit 1; }
-echo "trace done"
-# 3. PMC passes (separate runs per counter group, --kernel-trace only)
+# 1. PMC passes (separate runs per counter group, --kernel-trace only)
 bash tools/pmc_passes.sh "$out/pmc" --steps 3 --warmup 1 > "$out/pmc.txt" 2>&1 || { echo "pmc failed"; tail -5 "$out/pmc.txt"; exit 1; }
 echo "pmc done"
+# (the HBM traffic file bench.py quotes under roofline.traffic is made from these passes before the bench line is taken)
+python3 tools/collect_profiles.py "$tag" > /dev/null 2>&1
+# 2. the bench line (default workload, CPU baseline included; --with-1m adds the configs[1] side figure)
+timeout -k 10 400 python3 bench.py --with-1m > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
+echo "bench done"
+# 3. the default command (python3 bench.py) under rocprofv3 --kernel-trace --stats
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py > "$out/bench_under_rocprofv3.json" 2> "$out/trace.err" || { echo "trace failed"; tail -5 "$out/trace.err"; exit 1; }
+echo "trace done"
 # 4. traversal statistics + per-phase clocks (diagnostic build of the kernel)
 timeout -k 10 200 python3 tools/knn_stats.py 1e7 uniform 15 > "$out/stats_uniform.json" 2>> "$out/stats.err" &&
 timeout -k 10 200 python3 tools/knn_stats.py 1e7 clustered 15 > "$out/stats_clustered.json" 2>> "$out/stats.err" || { echo "stats failed"; exit 1; }
