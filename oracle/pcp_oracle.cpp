@@ -1017,11 +1017,16 @@ inline void normalized3(T const v[3], T out[3])
 }
 
 // bilateral::detail::compute_ni (bilateral_filter.hpp:103-269)
+// `cancellation` (optional): the result direction is v = k * sum_j c_j - (sum_i w_i proj_i) * (sum_j g_j) with c_j = (neighbour j's
+// Jacobian terms) n and g_j = (its grad_k terms) . n; reported is (k * sum_j |c_j| + |sum_i w_i proj_i| * sum_j |g_j|) / |v| -- by how
+// much the magnitudes that are added and subtracted exceed what is left, i.e. the amplification of the terms' rounding errors in
+// the vector that is then normalised (the tests use it to tell rows on which the reference's formula itself is unstable)
 template <class T>
 V3<T> bilateral_ni(std::vector<u32> const& nb, V3<T> const& s, V3<T> const& ns, std::vector<V3<T>> const& pts,
-                   std::vector<V3<T>> const& nrm, T sigmaf, T sigmag)
+                   std::vector<V3<T>> const& nrm, T sigmaf, T sigmag, float* cancellation = nullptr)
 {
     T Jsum[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double abs_c = 0, abs_g = 0;  // (only for `cancellation`)
     T pifg[3] = {0, 0, 0};
     T gradk[3] = {0, 0, 0};
     T k = 0;
@@ -1059,6 +1064,19 @@ V3<T> bilateral_ni(std::vector<u32> const& nb, V3<T> const& s, V3<T> const& ns, 
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c)
                 Jsum[r][c] += ((Jpi[r][c] * wf) * wg + (sps[r] * gradf[c]) * wg) + (sps[r] * wf) * gradg[c];
+        if (cancellation) {
+            double const nv[3] = {double(ns.x), double(ns.y), double(ns.z)};
+            double cj2 = 0, gj = 0;
+            for (int r = 0; r < 3; ++r) {
+                double cr = 0;
+                for (int c = 0; c < 3; ++c)
+                    cr += (double(Jpi[r][c]) * wf * wg + double(sps[r]) * gradf[c] * wg + double(sps[r]) * wf * gradg[c]) * nv[c];
+                cj2 += cr * cr;
+                gj += (double(gradf[r]) * wg + double(wf) * gradg[r]) * nv[r];
+            }
+            abs_c += std::sqrt(cj2);
+            abs_g += std::abs(gj);
+        }
     }
     T const ks2_inv = T(1) / (k * k);
     T J[3][3];
@@ -1066,6 +1084,21 @@ V3<T> bilateral_ni(std::vector<u32> const& nb, V3<T> const& s, V3<T> const& ns, 
         for (int c = 0; c < 3; ++c) J[r][c] = ks2_inv * (Jsum[r][c] * k - pifg[r] * gradk[c]);
     T const v[3] = {sum3(J[0][0] * ns.x, J[0][1] * ns.y, J[0][2] * ns.z), sum3(J[1][0] * ns.x, J[1][1] * ns.y, J[1][2] * ns.z),
                     sum3(J[2][0] * ns.x, J[2][1] * ns.y, J[2][2] * ns.z)};
+    if (cancellation) {
+        double const nv[3] = {double(ns.x), double(ns.y), double(ns.z)};
+        double const gdotn = double(gradk[0]) * nv[0] + double(gradk[1]) * nv[1] + double(gradk[2]) * nv[2];
+        double np2 = 0, nd = 0;
+        for (int r = 0; r < 3; ++r) {
+            double const an = double(k) * (double(Jsum[r][0]) * nv[0] + double(Jsum[r][1]) * nv[1] + double(Jsum[r][2]) * nv[2]);
+            double const bn = double(pifg[r]) * gdotn;
+            np2 += double(pifg[r]) * double(pifg[r]);
+            nd += (an - bn) * (an - bn);
+        }
+        double const magnitude = double(k) * abs_c + std::sqrt(np2) * abs_g;
+        // (+inf also when the magnitudes themselves sit in float32's denormal range -- influence weights exp(-r^2 / 2 sigmag^2) of
+        //  1e-30 and less: there float32 has no relative precision left whatever the order of summation)
+        *cancellation = (nd > 0 && magnitude > 1e-28) ? static_cast<float>(magnitude / std::sqrt(nd)) : std::numeric_limits<float>::infinity();
+    }
     T o[3];
     normalized3(v, o);
     return V3<T>{o[0], o[1], o[2]};
@@ -1083,7 +1116,7 @@ std::vector<V3<T>> widen(float const* a, u64 n)
 // (:460-574: one kd-tree, the normals iterate)
 template <class T>
 void bilateral_filter(float const* xyz, float const* normals, u64 n, double sigmaf_, double sigmag_, u64 K, bool do_points,
-                      float* out, int nthreads)
+                      float* out, int nthreads, float* cancellation = nullptr)
 {
     T const sigmaf = static_cast<T>(static_cast<float>(sigmaf_)), sigmag = static_cast<T>(static_cast<float>(sigmag_));
     float const radius = 2.f * static_cast<float>(sigmaf_);  // :73 two * sigmaf, in the point's scalar type
@@ -1095,7 +1128,7 @@ void bilateral_filter(float const* xyz, float const* normals, u64 n, double sigm
         parallel_for(n, nthreads, [&](u64 i) {
             std::vector<u32> const nb = filter_range(*tree, fpts[i], radius);
             tmp[i] = do_points ? bilateral_pi<T>(nb, pts[i], pts, nrm, sigmaf, sigmag)
-                               : bilateral_ni<T>(nb, pts[i], nrm[i], pts, nrm, sigmaf, sigmag);
+                               : bilateral_ni<T>(nb, pts[i], nrm[i], pts, nrm, sigmaf, sigmag, cancellation ? cancellation + i : nullptr);
         });
         if (do_points) {
             pts = tmp;
@@ -1231,10 +1264,11 @@ void orc_bilateral_filter_points(float const* xyz, float const* normals, u64 n, 
     else bilateral_filter<float>(xyz, normals, n, sigmaf, sigmag, K, true, out_xyz, nthreads);
 }
 void orc_bilateral_filter_normals(float const* xyz, float const* normals, u64 n, double sigmaf, double sigmag, u64 K,
-                                  float* out_normals, int f64_yardstick, int nthreads)
+                                  float* out_normals, int f64_yardstick, int nthreads, float* opt_out_cancellation)
 {
-    if (f64_yardstick) bilateral_filter<double>(xyz, normals, n, sigmaf, sigmag, K, false, out_normals, nthreads);
-    else bilateral_filter<float>(xyz, normals, n, sigmaf, sigmag, K, false, out_normals, nthreads);
+    // opt_out_cancellation (n floats or NULL): the cancellation factor of every row in the last iteration (bilateral_ni)
+    if (f64_yardstick) bilateral_filter<double>(xyz, normals, n, sigmaf, sigmag, K, false, out_normals, nthreads, opt_out_cancellation);
+    else bilateral_filter<float>(xyz, normals, n, sigmaf, sigmag, K, false, out_normals, nthreads, opt_out_cancellation);
 }
 // pcp::algorithm::wlop::wlop with the initial sample given
 void orc_wlop(float const* xyz, u64 J, u64 const* sample, u64 I, double mu, double h, u64 K, int uniform, float* out_xyz,

@@ -265,14 +265,16 @@ def bilateral_filter_points(xyz, normals, sigmaf, sigmag, K=1, f64_yardstick=Fal
     return out
 
 
-def bilateral_filter_normals(xyz, normals, sigmaf, sigmag, K=1, f64_yardstick=False, nthreads=1):
-    """pcp::algorithm::bilateral_filter_normals (bilateral_filter.hpp:460-574)."""
+def bilateral_filter_normals(xyz, normals, sigmaf, sigmag, K=1, f64_yardstick=False, nthreads=1, want_cancellation=False):
+    """pcp::algorithm::bilateral_filter_normals (bilateral_filter.hpp:460-574).  want_cancellation: also the per-row factor by
+    which the quotient rule's two terms exceed their difference in the last iteration (rows where the formula is unstable)."""
     xyz = _f32(xyz).reshape(-1, 3)
     nrm = _f32(normals).reshape(-1, 3)
     out = np.empty_like(nrm)
+    cf = np.zeros(len(xyz), np.float32) if want_cancellation else None
     lib().orc_bilateral_filter_normals(_p(xyz, _f32p), _p(nrm, _f32p), C.c_uint64(len(xyz)), C.c_double(sigmaf), C.c_double(sigmag),
-                                       C.c_uint64(K), _p(out, _f32p), C.c_int(int(f64_yardstick)), C.c_int(nthreads))
-    return out
+                                       C.c_uint64(K), _p(out, _f32p), C.c_int(int(f64_yardstick)), C.c_int(nthreads), _p(cf, _f32p))
+    return (out, cf) if want_cancellation else out
 
 
 def wlop(xyz, sample, mu, h, K, uniform=True, f64_yardstick=False, nthreads=1):

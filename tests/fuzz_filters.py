@@ -4,7 +4,9 @@ exact ties, duplicates, huge dynamic range), sizes, radii, normals (unit, unnorm
 _normals and WLOP, one iteration from identical inputs, against the oracle.  Test infrastructure (uses the oracle).
 A row counts as ill-conditioned -- and is only counted, not judged -- when the oracle's own float32 result is further than
 HALF the tolerance (half the tolerated angle: a quarter of the 1 - cos bound) from its float64 evaluation: there the
-reference's arithmetic has no stable answer to be equal to (e.g. all normals (0, 0, 1): the reference's J n cancels to rounding noise).
+reference's arithmetic has no stable answer to be equal to (e.g. all normals (0, 0, 1): the reference's J n cancels to rounding noise),
+or when the float64 evaluation reports that the magnitudes added and subtracted for the row exceed what is left of them by more than
+CANCEL_MAX, or sit in float32's denormal range (oracle: bilateral_ni's cancellation factor).
 usage: python tests/fuzz_filters.py [seconds] [seed]"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +19,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
 rng = np.random.default_rng(seed)
 POS_TOL, COS_TOL = 4e-6, 1e-4
+CANCEL_MAX = 3000.0  # rows whose added and subtracted magnitudes exceed the result by more than this (oracle, float64) are not judged
 SIZES = [1, 2, 8, 9, 65, 300, 2000, 9000, 20000]
 
 
@@ -88,10 +91,16 @@ while time.time() < t_end:
             raise AssertionError("bilateral points: %d rows differ, worst %.3g (extent %.3g)" % (int(bad.sum()), float(np.nanmax(d[bad])), ext))
         gn = pkg.bilateral_filter_normals(pts, nrm, sigmaf, sigmag, K=1)
         en = O.bilateral_filter_normals(pts, nrm, sigmaf, sigmag, K=1, nthreads=8)
-        yn = O.bilateral_filter_normals(pts, nrm, sigmaf, sigmag, K=1, f64_yardstick=True, nthreads=8)
-        with np.errstate(invalid="ignore"):
-            c = 1 - np.sum(gn.astype(np.float64) * en, axis=1)
-            unstable = ~((1 - np.sum(en.astype(np.float64) * yn, axis=1)) <= 0.25 * COS_TOL)
+        yn, cf = O.bilateral_filter_normals(pts, nrm, sigmaf, sigmag, K=1, f64_yardstick=True, nthreads=8, want_cancellation=True)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            # directions are compared (unit vectors formed here in float64): where |J n|^2 underflows in float32 the reference's
+            # normalize() leaves the vector short or untouched (Eigen: divide only if the squared norm is > 0), on both sides
+            def unit(a):
+                a = a.astype(np.float64)
+                return a / np.linalg.norm(a, axis=1, keepdims=True)
+            ug, ue, uy = unit(gn), unit(en), unit(yn)
+            c = 1 - np.sum(ug * ue, axis=1)
+            unstable = ~((1 - np.sum(ue * uy, axis=1)) <= 0.25 * COS_TOL) | ~(cf <= CANCEL_MAX)
             both_degenerate = (np.isnan(gn).any(axis=1) & np.isnan(en).any(axis=1)) | ((np.abs(gn).max(axis=1) == 0) & (np.abs(en).max(axis=1) == 0))
             bad = ~((c <= COS_TOL) | unstable | both_degenerate)
         ill += int(unstable.sum()); rows += n
