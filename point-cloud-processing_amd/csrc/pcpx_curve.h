@@ -33,6 +33,19 @@ __host__ __device__ __forceinline__ u64 spread21(u32 v)
     return x;
 }
 
+// bit i of the low 10 bits of v -> bit 3i
+__host__ __device__ __forceinline__ u32 spread10(u32 v)
+{
+    u32 x = v & 0x3FFu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+// the same for 3 bits
+__host__ __device__ __forceinline__ u32 spread3(u32 v) { return (v | (v << 2) | (v << 4)) & 0x49u; }
+
 __device__ __forceinline__ u32 quant21(float v, float lo, float hi)
 {
     float ext = hi - lo;
@@ -61,15 +74,25 @@ __host__ __device__ __forceinline__ u64 hilbert_index(u32 x, u32 y, u32 z)
     }
     X[1] ^= X[0];
     X[2] ^= X[1];
-    u32 t = 0;
-#pragma unroll
-    for (int b = BITS - 1; b > 0; --b) {
-        const u32 Q = 1u << b;
-        t ^= (X[2] & Q) ? (Q - 1u) : 0u;
-    }
+    // Skilling's tail "for every set bit b >= 1 of X[2]: t ^= 2^b - 1" makes bit j of t the parity of the bits of X[2] above j:
+    // a prefix XOR from the top, shifted down by one (5 shift-xor steps instead of BITS - 1 test-and-xor steps)
+    u32 t = X[2];
+    t ^= t >> 1;
+    t ^= t >> 2;
+    t ^= t >> 4;
+    t ^= t >> 8;
+    if (BITS > 16) t ^= t >> 16;
+    t >>= 1;
     X[0] ^= t;
     X[1] ^= t;
     X[2] ^= t;
+    if (BITS <= 13) {
+        // interleave in 32-bit pieces (the vector ALU has no 64-bit shifts-with-or): the low 10 bits of every axis give the low 30
+        // bits of the index, the bits above them the rest
+        const u32 lo = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+        const u32 hi = (spread3(X[0] >> 10) << 2) | (spread3(X[1] >> 10) << 1) | spread3(X[2] >> 10);
+        return (static_cast<u64>(hi) << 30) | lo;
+    }
     return (spread21(X[0]) << 2) | (spread21(X[1]) << 1) | spread21(X[2]);
 }
 
