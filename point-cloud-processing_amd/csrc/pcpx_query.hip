@@ -125,19 +125,22 @@ __device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
 #define PCPX_BUF16 10  // 10 rows x 512 B = 5 KB per wave = 7 waves/SIMD.  Measured on MI355X (10 M uniform / clustered, k=15, chunk-of-8 compaction, no trash row): 6 waves/SIMD 12 rows 1268 / 1135, 7 waves 11 rows 1263 / 1130, 7 waves 10 rows 1281 / 1150, 7 waves 9 rows 1236 / 1110
 #endif
 #ifndef PCPX_BUF32
-#define PCPX_BUF32 16
+#define PCPX_BUF32 14  // with the chunk-of-8 compaction (50 M points, k = 32, rebuild in the step, Mq/s): 16 rows 1036, 14 rows 1049, 12 rows 1037
 #endif
 #ifndef PCPX_COMPACT_BY8
 #define PCPX_COMPACT_BY8 1     // k <= 16 kernel: compaction in chunks of 8 keys (80 VGPRs, 6 waves/SIMD): 1171 -> 1250 Mq/s
 #endif
-// (the k <= 32 kernel keeps the 16-key compaction: the chunked form measured worse in round 1 -- 720 vs 735 Mq/s, 5 waves/SIMD
-//  spill 308 B -- and relies on the empty-slots-hold-PAD_KEY invariant that only the k <= 16 kernels establish; under the Hilbert
-//  order, 10 M points k = 32: 16 rows 1021 Mq/s, 14 rows 995, 12 rows 969, 5 waves/SIMD 570)
+// (the multi-pass kernels -- k > 32 -- keep the 16-key compaction and the C++ accept path with its trash row.  The single-pass
+//  k <= 32 kernel used to as well: the chunked form measured worse in round 1 (720 vs 735 Mq/s, 308 B of scratch); since the
+//  persistent loop's invariants no longer pin registers it is the better one: PCPX_BY8_K32.)
 #ifndef PCPX_BUF8
 #define PCPX_BUF8 10   // k <= 8: 10 rows x 512 B = 5 KB per wave, 8 waves/SIMD (10 M uniform, k = 8, Mq/s, chunk-of-8 compaction: 7 waves 9 rows 1506, 7/10 1530, 8/9 1553, 8/10 1581; the k <= 16 kernel of the time did 1337)
 #endif
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
+#endif
+#ifndef PCPX_BY8_K32
+#define PCPX_BY8_K32 1  // the chunk-of-8 compaction (with its PAD invariant established) for the single-pass k <= 32 kernel too: 50 M points, k = 32: 994 -> 1041 Mq/s, scratch 40 -> 32 B/lane
 #endif
 // rows of LDS per wave: the C++ accept path (multi-pass kernels only) stores rejected keys to a trash row, row BUF;
 // the exec-masked path stores nothing for a rejected candidate
@@ -477,7 +480,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 st_c3 += any_lane(cnt > 3) ? 0u : 1u;
                 st_c4 += any_lane(cnt > 4) ? 0u : 1u;
             }
-            if (PCPX_COMPACT_BY8 && KCAP <= 16) compact_by8<KCAP, BUF>(best, col, cnt);
+            if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF>(best, col, cnt);
             else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = wave_in_block();
     u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI) * 64 + lane;
-    if (PCPX_COMPACT_BY8 && !MULTI && KCAP <= 16) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
+    if (PCPX_COMPACT_BY8 && !MULTI && (KCAP <= 16 || PCPX_BY8_K32)) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
 #pragma unroll
         for (int j = 0; j < BUF; ++j) col[j * 64] = PAD_KEY;
     }
