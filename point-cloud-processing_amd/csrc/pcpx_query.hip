@@ -305,12 +305,21 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 // PCPX_CAP_MULT x the median of the finite seeded taus of a sample of the wave's valid lanes (every fourth lane:
 // 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
 // The cap only steers the work, never the result (a lane that fails the cap goes round again).
-#ifndef PCPX_CAP_MULT
-#define PCPX_CAP_MULT 1.25f  // measured, 10 M points, Hilbert order, 2 extra seed leaves, Mq/s uniform / clustered: 1.25: 1873 / 1610, 1.375: 1865 / 1579, 1.5: 1855 / 1578, 1.75: 1841 / 1588, 2: 1834 / 1587 (round 1, Z-order: 1: 1131 / 960, 1.25: 1175 / 1035, 1.375: 1168 / 1053, 1.5: 1164 / 1057)
+// measured, 10 M points, Hilbert order, Mq/s uniform / clustered at k = 15 with 2 extra seed leaves: 1.25: 1873 / 1610, 1.375: 1865 / 1579,
+// 1.5: 1855 / 1578, 1.75: 1841 / 1588, 2: 1834 / 1587 (round 1, Z-order: 1: 1131 / 960, 1.25: 1175 / 1035, 1.375: 1168 / 1053, 1.5: 1164 / 1057);
+// per kernel with its own seed range (1.125 / 1.25 / 1.375 / 1.5): k = 8: 2340 / 2420 / 2454 / 2449, k = 15: 1935 / 1925 / 1924 / 1918,
+// k = 32: 1081 / 1073 / 1064 / 1062
+#ifdef PCPX_CAP_MULT
+template <int KCAP>
+constexpr float cap_mult() { return PCPX_CAP_MULT; }
+#else
+template <int KCAP>
+constexpr float cap_mult() { return KCAP <= 8 ? 1.375f : KCAP <= 16 ? 1.25f : 1.125f; }
 #endif
 #ifndef PCPX_CAP_GROW
 #define PCPX_CAP_GROW 4.f  // radius^2 growth per further round
 #endif
+template <int KCAP>
 __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane)
 {
     const float inf = std::numeric_limits<float>::infinity();
@@ -324,7 +333,7 @@ __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane
     if (nfinite == 0) {  // no finite sample: any finite lane, or none
         const u64 any = __builtin_amdgcn_ballot_w64(x < inf);
         if (any == 0) return inf;
-        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(any)))) * PCPX_CAP_MULT;
+        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(any)))) * cap_mult<KCAP>();
     }
     u32 rank = 0;
 #pragma unroll
@@ -334,7 +343,7 @@ __device__ __forceinline__ float wave_radius_cap(float tau, bool valid, u32 lane
     }
     const u64 is_med = __builtin_amdgcn_ballot_w64(sample && x < inf && rank == nfinite / 2);
     const float med = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), static_cast<u32>(__builtin_ctzll(is_med))));
-    return med * PCPX_CAP_MULT;
+    return med * cap_mult<KCAP>();
 }
 
 // k > 32: pass p of a multi-pass search returns the (at most 32) smallest keys strictly greater than the
@@ -424,14 +433,18 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     else s0 = qv.seed[g];
     s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
     if (s0 > s1) s0 = s1;
-#ifndef PCPX_SEED_EXTRA
-#define PCPX_SEED_EXTRA 2  // leaves before and after the group's own chunk that are also processed before the walk: they are
-                           // Morton neighbours the walk would visit anyway, and seeing them first tightens tau sooner
-                           // (Mq/s uniform / clustered, cap x1.25: 0: 1144 / 1014, 1: 1160 / 1035, 2: 1174 / 1032, 4: 1173 / 1030, 8: 1155 / 1005)
+    // leaves before and after the group's own chunk that are also processed before the walk: they are curve neighbours the walk
+    // would visit anyway, and seeing them first tightens tau sooner.  How many pays depends on k (10 M uniform points, Hilbert
+    // order, Mq/s with 0 / 1 / 2 / 3 / 4 extra leaves on either side): k = 8: 2414 / 2381 / 2349 / 2310 / 2274;
+    // k = 15: 1859 / 1900 / 1922 / 1921 / 1916; k = 32 (rebuild in the step): 1002 / 1033 / 1053 / 1063 / 1068
+#ifdef PCPX_SEED_EXTRA
+    constexpr u32 seed_extra = PCPX_SEED_EXTRA;
+#else
+    constexpr u32 seed_extra = KCAP <= 8 ? 0u : KCAP <= 16 ? 2u : 4u;
 #endif
-    if (PCPX_SEED_EXTRA > 0) {
-        s0 = s0 > PCPX_SEED_EXTRA ? s0 - PCPX_SEED_EXTRA : 0u;
-        s1 = s1 + PCPX_SEED_EXTRA < t.nleaves ? s1 + PCPX_SEED_EXTRA : t.nleaves;
+    if (seed_extra > 0) {
+        s0 = s0 > seed_extra ? s0 - seed_extra : 0u;
+        s1 = s1 + seed_extra < t.nleaves ? s1 + seed_extra : t.nleaves;
     }
 
     // Single loop, single back-edge: each iteration fetches the next leaf (seed chunk first, then the
@@ -440,7 +453,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     wk.pend = 0;
     wk.ploc = 0;
     wk.l = 0;
-    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = PCPX_CAP_MULT (1.375) x the
+    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = cap_mult (1.125 ... 1.375) x the
     // wave's median seeded tau: a lane whose 64-point seed chunk lies across a Morton-curve jump starts with a
     // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
     // 7 ms groups against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all
@@ -548,7 +561,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             if (!walking) {
                 walking = true;
                 if (STATS) st_seed_app = st_app;
-                cap = wave_radius_cap(tau, valid, lane);
+                cap = wave_radius_cap<KCAP>(tau, valid, lane);
                 tau = active ? fminf(tau, cap) : -1.f;
                 bool root_leaf = wk.start(t, need, st_expand);
                 (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
