@@ -170,7 +170,7 @@ void estimate_normals_impl(ForwardIter1 begin, ForwardIter1 end, PointViewMap co
             }
             std::size_t const rows = off.size() - 1;
             nrm.assign(rows * 3, 0.f);
-            gpu::check(pcpx_estimate_normals_batch(xyz.data(), off.data(), rows, 0, nrm.data()), "pcpx_estimate_normals_batch");
+            gpu::check(pcpx_estimate_normals_batch(xyz.data(), off.data(), rows, gpu::default_device().load(), nrm.data()), "pcpx_estimate_normals_batch");
             std::size_t i = 0;
             for (ForwardIter1 it = first; it != begin; ++it, ++i) emit(*it, make_normal<Normal>(nrm.data() + 3 * i));
         }

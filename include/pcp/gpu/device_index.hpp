@@ -8,6 +8,7 @@
 #include "pcpx.h"
 
 #include <array>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -24,6 +25,14 @@ inline void check(int status, char const* what)
 {
     if (status != PCPX_OK)
         throw std::runtime_error(std::string(what) + ": pcpx status " + std::to_string(status) + ": " + pcpx_last_error());
+}
+
+// The device the most recently built index lives on: what the entry points WITHOUT a handle use when they are called on
+// behalf of a tree they cannot see (estimate_normals with an arbitrary knn_map lambda).
+inline std::atomic<int>& default_device()
+{
+    static std::atomic<int> d{0};
+    return d;
 }
 
 // k-nearest-neighbour rows of a batch: row q = idx[q*k .. q*k + count[q])
@@ -135,7 +144,11 @@ class device_index_t
             }
         }
         if (h_) check(pcpx_index_rebuild(h_, xyz, n, grid6 ? &p : nullptr), "pcpx_index_rebuild");
-        else check(pcpx_index_create(xyz, n, grid6 ? &p : nullptr, device, &h_), "pcpx_index_create");
+        else
+        {
+            check(pcpx_index_create(xyz, n, grid6 ? &p : nullptr, device, &h_), "pcpx_index_create");
+            default_device().store(device);
+        }
         check(pcpx_index_size(h_, &n_), "pcpx_index_size");
         forget();
         xyz_  = xyz;  // the owner keeps the coordinates alive and rebuilds after any change (see the containers)
@@ -165,7 +178,10 @@ class device_index_t
     // k nearest neighbours of EVERY indexed point are computed in one launch and kept on the host; a later call whose
     // target has exactly the coordinates of an indexed point is answered from those rows (the row of a point depends on
     // its coordinates only: the eps-box test excludes by position, not by index), any other target takes the
-    // single-query path.  Same results either way.  The same is done for sphere ranges of one radius.
+    // single-query path.  Same distances either way; which of several points tying EXACTLY with the k-th distance is
+    // returned is unspecified (the cached rows come from the throughput kernel, an uncached call from the latency
+    // kernel).  The same is done for sphere ranges of one radius.  If the one-off batch fill fails (out of memory, a device
+    // error) the cache is marked failed and every later call takes the single-query path: the failure is not retried.
     static constexpr unsigned batch_after         = 16;
     static constexpr std::uint64_t max_cache_ints = 1ull << 28;  // 1 GiB of indices at most
 
@@ -183,9 +199,18 @@ class device_index_t
                 knn_.eps = eps;
                 if (!knn_.failed && ++knn_.calls >= batch_after && xyz_ && n_in_ * k <= max_cache_ints)
                 {
-                    build_lookup();
-                    knn_.rows = knn_self(k, eps, n_in_);
-                    knn_.ready = true;
+                    knn_.failed = true;  // (cleared on success: a throw below downgrades to the single-query path for good)
+                    try
+                    {
+                        build_lookup();
+                        knn_.rows   = knn_self(k, eps, n_in_);
+                        knn_.ready  = true;
+                        knn_.failed = false;
+                    }
+                    catch (...)
+                    {
+                        knn_.rows = {};
+                    }
                 }
             }
             if (knn_.ready && knn_.k == k && knn_.eps == eps)
@@ -219,20 +244,29 @@ class device_index_t
                 range_.radius = r;
                 if (!range_.failed && ++range_.calls >= batch_after && xyz_ && n_in_ > 0)
                 {
-                    build_lookup();
-                    std::vector<std::uint32_t> counts(static_cast<std::size_t>(n_in_));
-                    check(pcpx_range_count_batch(h_, xyz_, n_in_, r, counts.data()), "pcpx_range_count_batch");
-                    std::uint64_t total = 0;
-                    for (auto v : counts) total += v;
-                    if (total <= max_cache_ints)
+                    range_.failed = true;  // (cleared on success)
+                    try
                     {
-                        range_.off.assign(static_cast<std::size_t>(n_in_) + 1, 0);
-                        range_.idx.resize(static_cast<std::size_t>(total));
-                        check(pcpx_range_sphere_batch(h_, xyz_, nullptr, r, n_in_, range_.off.data(), range_.idx.data(), total),
-                              "pcpx_range_sphere_batch");
-                        range_.ready = true;
+                        build_lookup();
+                        std::vector<std::uint32_t> counts(static_cast<std::size_t>(n_in_));
+                        check(pcpx_range_count_batch(h_, xyz_, n_in_, r, counts.data()), "pcpx_range_count_batch");
+                        std::uint64_t total = 0;
+                        for (auto v : counts) total += v;
+                        if (total <= max_cache_ints)
+                        {
+                            range_.off.assign(static_cast<std::size_t>(n_in_) + 1, 0);
+                            range_.idx.resize(static_cast<std::size_t>(total));
+                            check(pcpx_range_sphere_batch(h_, xyz_, nullptr, r, n_in_, range_.off.data(), range_.idx.data(), total),
+                                  "pcpx_range_sphere_batch");
+                            range_.ready  = true;
+                            range_.failed = false;
+                        }
                     }
-                    else range_.failed = true;
+                    catch (...)
+                    {
+                        range_.off = {};
+                        range_.idx = {};
+                    }
                 }
             }
             if (range_.ready && range_.radius == r)

@@ -68,6 +68,30 @@ void DevPool::release(void* p)
     for (auto& b : blocks)
         if (b.p == p) {
             b.used = false;
+            break;
+        }
+    // a cap on what sits idle: calls with differing sizes each leave a block behind (a block is reused only for a request of
+    // at least half its size); beyond MAX_IDLE the largest idle blocks go back to the driver
+    constexpr size_t MAX_IDLE = size_t(16) << 30;  // (of 288 GB)
+    for (;;) {
+        size_t idle = 0;
+        int largest = -1;
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (!blocks[i].used) {
+                idle += blocks[i].bytes;
+                if (largest < 0 || blocks[i].bytes > blocks[static_cast<size_t>(largest)].bytes) largest = static_cast<int>(i);
+            }
+        if (idle <= MAX_IDLE || largest < 0) break;
+        (void)hipFree(blocks[static_cast<size_t>(largest)].p);
+        blocks.erase(blocks.begin() + largest);
+    }
+}
+void DevPool::discard(void* p)
+{
+    for (size_t i = 0; i < blocks.size(); ++i)
+        if (blocks[i].p == p) {
+            (void)hipFree(p);
+            blocks.erase(blocks.begin() + static_cast<long>(i));
             return;
         }
 }
@@ -119,12 +143,18 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     DevPool* pool = nullptr;
-    explicit DevBuf(DevPool& owner) : pool(&owner) {}
+    bool one_off = false;  // true: the block goes back to the driver, not into the pool's cache (the n x 12-byte staging copy
+                           // of a build from host memory would otherwise stay cached for the handle's lifetime)
+    explicit DevBuf(DevPool& owner, bool one_off_ = false) : pool(&owner), one_off(one_off_) {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf()
+    ~DevBuf() { reset(); }
+    void reset()
     {
-        if (p) pool->release(p);
+        if (!p) return;
+        if (one_off) pool->discard(p);
+        else pool->release(p);
+        p = nullptr;
     }
     int alloc(size_t bytes)
     {
@@ -246,6 +276,7 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_xyz);
     for (int b = 0; b < 2; ++b) (void)hipFree(ix->d_codes[b]);
     (void)hipFree(ix->d_perm);
+    (void)hipFree(ix->d_rec);
     (void)hipFree(ix->d_sort_tmp);
     (void)hipFree(ix->d_leaves);
     (void)hipFree(ix->d_nodes);
@@ -322,24 +353,26 @@ static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_bui
         }
         ix->own_stream = true;
     }
-    DevBuf staged(ix->pool);
-    const float* d_src = xyz;
-    if (!on_device && n > 0) {
-        if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) {
-            free_index(ix);
-            return st;
+    {
+        // (inner scope: the staging block belongs to the handle's pool and must be gone before a failure path deletes the handle)
+        DevBuf staged(ix->pool, true);
+        const float* d_src = xyz;
+        if (!on_device && n > 0) {
+            st = staged.alloc(n * 3 * sizeof(float));
+            if (st == PCPX_OK) st = check_hip(hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice), "H2D copy of points", __FILE__, __LINE__);
+            d_src = staged.as<float>();
         }
-        hipError_t e = hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            free_index(ix);
-            return check_hip(e, "H2D copy of points", __FILE__, __LINE__);
-        }
-        d_src = staged.as<float>();
+        if (st == PCPX_OK) st = build_index(*ix, d_src, n, params);
+        const std::string why = g_err;
+        // (also on failure: work of a partial build may still be reading the staging block)
+        const int sync = check_hip(hipStreamSynchronize(ix->stream), "build sync", __FILE__, __LINE__);
+        if (st == PCPX_OK) st = sync;
+        else g_err = why;
     }
-    st = build_index(*ix, d_src, n, params);
-    if (st == PCPX_OK) st = check_hip(hipStreamSynchronize(ix->stream), "build sync", __FILE__, __LINE__);
     if (st != PCPX_OK) {
+        const std::string why = g_err;  // (free_index's own HIP calls must not replace the reason)
         free_index(ix);
+        g_err = why;
         return st;
     }
     *out = reinterpret_cast<pcpx_index*>(ix);
@@ -364,15 +397,16 @@ int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_b
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !xyz) return PCPX_ERR_INVALID;
-    DevBuf staged(ix->pool);
+    DevBuf staged(ix->pool, true);
     if (n > 0) {
         if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
         PCPX_HIP(hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
     }
     st = build_index(*ix, staged.as<float>(), n, params);
-    if (st != PCPX_OK) return st;
-    PCPX_HIP(hipStreamSynchronize(ix->stream));
-    return PCPX_OK;
+    const std::string why = g_err;
+    const int sync = check_hip(hipStreamSynchronize(ix->stream), "build sync", __FILE__, __LINE__);  // (before the staging block goes)
+    if (st != PCPX_OK) g_err = why;
+    return st != PCPX_OK ? st : sync;
 }
 int pcpx_index_rebuild_dev(pcpx_index* h, const float* d_xyz, uint64_t n, const pcpx_build_params* params)
 {

@@ -15,6 +15,12 @@ namespace pcpx {
 
 namespace {
 
+#ifndef PCPX_BUILD_RECORDS
+#define PCPX_BUILD_RECORDS 1  // 1: the sort's first pass moves a {x, y, z, id} record per point into its top-digit bucket and the leaf
+                              // fill gathers from there; 0: the leaf fill gathers the coordinates from the input-order copy
+#endif
+constexpr size_t SCALARS = 288;  // u32 words of Index::d_scalars: [0, 6) encoded box, [6] inserted points, [7] sort failure, [8, 14) box, [16, 273) k_codes' counters
+
 // order-preserving float <-> uint encoding for atomic min/max
 __device__ __forceinline__ u32 enc_f(float f)
 {
@@ -110,34 +116,56 @@ __global__ void k_bbox_decode(const u32* enc6, float* out6)
     if (threadIdx.x < 6) out6[threadIdx.x] = dec_f(enc6[threadIdx.x]);
 }
 
-// Curve key (pcpx_curve.h) of every point inside the grid; points outside (or NaN) get PAD_CODE and sort to the
-// end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive containment,
-// include/pcp/common/axis_aligned_bounding_box.hpp:111-125).
-__global__ __launch_bounds__(256) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6, int idx_bits,
-                                               u64* __restrict__ codes)
+// Sort word (pcpx_curve.h) of every point: curve key of a point inside the grid, the all-ones key for a point outside it
+// (or NaN) -- it sorts to the end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive
+// containment, include/pcp/common/axis_aligned_bounding_box.hpp:111-125).  The same sweep over the coordinates
+//   * keeps the index's own copy of the cloud (the reference's containers copy their elements too, linked_kdtree.hpp:107;
+//     round 2 spent a separate 120 MB device copy on it),
+//   * counts the words' top digit for the sort's first pass (round 2: a separate sweep over the words),
+//   * counts the points outside the grid (round 2: a one-thread binary search kernel after the sort).
+// ctl: [0, 256) top-digit counts, [256] points outside; zeroed by the caller.
+constexpr int CODES_BLOCK = 1024;
+__global__ __launch_bounds__(CODES_BLOCK) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6, int idx_bits,
+                                                        u64* __restrict__ codes, float* __restrict__ xyz_copy, u32* __restrict__ ctl)
 {
-    u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
-    if (i < n) {
-        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
+    __shared__ u32 hist[256];
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
+    const u64 stride = static_cast<u64>(gridDim.x) * CODES_BLOCK;
+    u32 outside = 0;
+    for (u64 i = blockIdx.x * static_cast<u64>(CODES_BLOCK) + threadIdx.x; i < n; i += stride) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (xyz_copy) {
+            xyz_copy[3 * i] = x;
+            xyz_copy[3 * i + 1] = y;
+            xyz_copy[3 * i + 2] = z;
+        }
         const bool ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
-        codes[i] = ok ? sort_word(curve_key(x, y, z, b0, b1, b2, b3, b4, b5), i, idx_bits) : (OUTSIDE_BIT | i);
+        const u64 word = ok ? sort_word(curve_key_inside(x, y, z, b0, b1, b2, b3, b4, b5, idx_bits), i, idx_bits) : outside_word(i, idx_bits);
+        codes[i] = word;
+        outside += ok ? 0u : 1u;
+        atomicAdd(&hist[static_cast<u32>(word >> 56)], 1u);
+    }
+    const u64 some_outside = __builtin_amdgcn_ballot_w64(outside != 0u);
+    if (some_outside) {  // rare: one atomic per wave that saw any
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) outside += __shfl_xor(outside, off);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&ctl[256], outside);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const u32 c = hist[threadIdx.x];
+        if (c) atomicAdd(&ctl[threadIdx.x], c);
     }
 }
 
-// number of inserted points = position of the first outside word in the sorted words (one thread: a binary
-// search; a per-wave atomic counter in k_codes serialises at ~90 atomics/us and cost 1.8 ms at 10 M points)
-__global__ void k_count_valid(const u64* __restrict__ sorted_codes, u32 n, u32* __restrict__ out, const u32* __restrict__ sort_failed)
+// what the host needs after the sort: [0] inserted points, [1] the sort's failure flag
+__global__ void k_build_result(u32 n, const u32* __restrict__ outside, const u32* __restrict__ sort_failed, u32* __restrict__ out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    out[1] = *sort_failed;  // travels to the host with the count
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-        u32 m = lo + ((hi - lo) >> 1);
-        if ((sorted_codes[m] & OUTSIDE_BIT) == 0ull) lo = m + 1;
-        else hi = m;
-    }
-    *out = lo;
+    if (threadIdx.x != 0) return;
+    out[0] = n - *outside;
+    out[1] = sort_failed ? *sort_failed : 0u;
 }
 
 __device__ __forceinline__ NodeBox padding_node()
@@ -166,54 +194,7 @@ __device__ __forceinline__ float leaf_max(float v)
     return v;
 }
 
-// Leaf records (16 B per point, coalesced) from the sorted words -- the point's index is the word's low bits -- plus, in
-// the same pass, the sorted position -> input index table and the leaf's tight box (bottom level of the tree: min / max
-// over the leaf's 8 lanes).  Only REAL nodes are written, and the up to three padding siblings that complete the last
-// group of four (what a query can ever read): round 1 filled the whole power-of-four level, 134 MB at 10 M points.
-// nslots = 8 x (leaves rounded up to a multiple of 4).
-__global__ __launch_bounds__(256) void k_fill_leaves(const float* __restrict__ xyz, const u64* __restrict__ sorted_codes, int idx_bits,
-                                                     u32 n, u32 nleaves, u32 nslots, Leaf* __restrict__ leaves, u32* __restrict__ perm,
-                                                     NodeBox* __restrict__ level, bool write_padding)
-{
-    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nslots) return;
-    float x = __builtin_nanf(""), y = x, z = x;
-    u32 id = INVALID_ID;
-    if (p < n) {
-        id = static_cast<u32>(sorted_codes[p] & ((1ull << idx_bits) - 1ull));
-        x = xyz[3 * static_cast<u64>(id)];
-        y = xyz[3 * static_cast<u64>(id) + 1];
-        z = xyz[3 * static_cast<u64>(id) + 2];
-        perm[p] = id;
-    }
-    const u32 leaf = p / LEAF;
-    const int s = p % LEAF;
-    if (leaf < nleaves) {
-        Leaf& lf = leaves[leaf];
-        lf.x[s] = x;
-        lf.y[s] = y;
-        lf.z[s] = z;
-        lf.id[s] = id;
-    }
-    const float inf = std::numeric_limits<float>::infinity();
-    // (every lane of the 8-lane group takes part in the reduction, whatever it holds; nslots is a multiple of 8)
-    const float lx = leaf_min(p < n ? x : inf), ly = leaf_min(p < n ? y : inf), lz = leaf_min(p < n ? z : inf);
-    const float hx = leaf_max(p < n ? x : -inf), hy = leaf_max(p < n ? y : -inf), hz = leaf_max(p < n ? z : -inf);
-    if (s == 0) {
-        if (leaf < nleaves) {
-            NodeBox nb;
-            nb.lo[0] = lx; nb.lo[1] = ly; nb.lo[2] = lz;
-            nb.hi[0] = hx; nb.hi[1] = hy; nb.hi[2] = hz;
-            nb.poison = 0.f;
-            nb.pad = 0.f;
-            level[leaf] = nb;
-        } else if (write_padding) {
-            level[leaf] = padding_node();
-        }
-    }
-}
-
-// one level up: node i = union of its 4 children (padding children are skipped)
+// node i of a level = union of its 4 children (padding children are skipped; no real child: a padding node)
 __device__ __forceinline__ NodeBox union_of_children(const NodeBox* __restrict__ child4)
 {
     float inf = std::numeric_limits<float>::infinity();
@@ -240,30 +221,123 @@ __device__ __forceinline__ NodeBox union_of_children(const NodeBox* __restrict__
     return nb;
 }
 
-// level d from level d + 1: the `nreal` real parents, then padding up to the next multiple of four (nwrite entries)
-__global__ __launch_bounds__(256) void k_upper_boxes(const NodeBox* __restrict__ child, NodeBox* __restrict__ parent,
-                                                     u32 nreal, u32 nwrite)
+// Shape of the implicit tree (heap order; only REAL nodes -- and the up to three padding siblings that complete the last
+// group of four of a level, the only padding a query can read -- are ever written).  real(d) = ceil(nleaves / 4^(depth - d)).
+struct TreeShape {
+    u32 nleaves;
+    int depth;
+    __host__ __device__ u32 nreal(int d) const
+    {
+        const int sh = 2 * (depth - d);
+        return static_cast<u32>((static_cast<u64>(nleaves) + (1ull << sh) - 1ull) >> sh);
+    }
+    __host__ __device__ u32 nwrite(int d) const { return d == 0 ? 1u : (nreal(d) + 3u) & ~3u; }
+    __host__ __device__ static u64 level_start(int d) { return ((1ull << (2 * d)) - 1ull) / 3ull; }
+};
+
+// Leaf records (16 B per point, coalesced) from the sorted words -- a word's low bits name the point's 16-byte record
+// {x, y, z, id}, which the sort's first pass left in the point's top-digit bucket: the gather of a block stays inside an
+// L2-sized window (round 2 gathered 12-byte coordinates from all over the cloud: 686 MB fetched for 120 MB) -- plus, in
+// the same pass, the sorted position -> input index table, the leaf's tight box (min / max over the leaf's 8 lanes) and
+// the three tree levels above the leaves (a block owns 64 leaves = one level-(depth - 3) node).
+// Blocks are dealt so that each XCD works through one contiguous eighth of the sorted order.
+constexpr int FILL_BLOCK = 512;
+constexpr int FILL_LEAVES = FILL_BLOCK / LEAF;  // 64
+__global__ __launch_bounds__(FILL_BLOCK) void k_fill_leaves(const float4* __restrict__ rec, const float* __restrict__ xyz,
+                                                            const u64* __restrict__ sorted_codes, int idx_bits, u32 n, TreeShape ts,
+                                                            u32 nblocks, Leaf* __restrict__ leaves, u32* __restrict__ perm,
+                                                            NodeBox* __restrict__ nodes)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nwrite) return;
-    parent[i] = i < nreal ? union_of_children(child + static_cast<u64>(i) * W) : padding_node();
+    __shared__ NodeBox lvl0[FILL_LEAVES];      // leaf boxes of the block
+    __shared__ NodeBox lvl1[FILL_LEAVES / 4];
+    __shared__ NodeBox lvl2[FILL_LEAVES / 16];
+    const u32 per = gridDim.x >> 3;  // the grid is a multiple of 8
+    const u32 vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const u32 p = vb * FILL_BLOCK + threadIdx.x;
+    if (vb >= nblocks) return;  // (the grid is rounded up to a multiple of 8; a block may exist only for the padding nodes it owns)
+    float x = __builtin_nanf(""), y = x, z = x;
+    u32 id = INVALID_ID;
+    if (p < n) {
+        const u64 at = sorted_codes[p] & ((1ull << idx_bits) - 1ull);
+        if (rec) {
+            const float4 r = rec[at];
+            x = r.x;
+            y = r.y;
+            z = r.z;
+            id = __float_as_uint(r.w);
+        } else {
+            id = static_cast<u32>(at);
+            x = xyz[3 * at];
+            y = xyz[3 * at + 1];
+            z = xyz[3 * at + 2];
+        }
+        perm[p] = id;
+    }
+    const u32 leaf = p / LEAF;
+    const int s = p % LEAF;
+    if (leaf < ts.nleaves) {
+        Leaf& lf = leaves[leaf];
+        lf.x[s] = x;
+        lf.y[s] = y;
+        lf.z[s] = z;
+        lf.id[s] = id;
+    }
+    const float inf = std::numeric_limits<float>::infinity();
+    // (every lane of the 8-lane group takes part in the reduction, whatever it holds)
+    const float lx = leaf_min(p < n ? x : inf), ly = leaf_min(p < n ? y : inf), lz = leaf_min(p < n ? z : inf);
+    const float hx = leaf_max(p < n ? x : -inf), hy = leaf_max(p < n ? y : -inf), hz = leaf_max(p < n ? z : -inf);
+    if (s == 0) {
+        NodeBox nb = padding_node();
+        if (leaf < ts.nleaves) {
+            nb.lo[0] = lx; nb.lo[1] = ly; nb.lo[2] = lz;
+            nb.hi[0] = hx; nb.hi[1] = hy; nb.hi[2] = hz;
+            nb.poison = 0.f;
+        }
+        lvl0[threadIdx.x / LEAF] = nb;
+        if (leaf < ts.nwrite(ts.depth)) nodes[TreeShape::level_start(ts.depth) + leaf] = nb;
+    }
+    // the three levels above: 16, 4 and 1 node of this block
+    const u32 l0 = vb * FILL_LEAVES;  // the block's first leaf
+    __syncthreads();
+    if (ts.depth >= 1 && threadIdx.x < FILL_LEAVES / 4) {
+        const u32 i = (l0 >> 2) + threadIdx.x;
+        const NodeBox nb = i < ts.nreal(ts.depth - 1) ? union_of_children(lvl0 + 4 * threadIdx.x) : padding_node();
+        lvl1[threadIdx.x] = nb;
+        if (i < ts.nwrite(ts.depth - 1)) nodes[TreeShape::level_start(ts.depth - 1) + i] = nb;
+    }
+    __syncthreads();
+    if (ts.depth >= 2 && threadIdx.x < FILL_LEAVES / 16) {
+        const u32 i = (l0 >> 4) + threadIdx.x;
+        const NodeBox nb = i < ts.nreal(ts.depth - 2) ? union_of_children(lvl1 + 4 * threadIdx.x) : padding_node();
+        lvl2[threadIdx.x] = nb;
+        if (i < ts.nwrite(ts.depth - 2)) nodes[TreeShape::level_start(ts.depth - 2) + i] = nb;
+    }
+    __syncthreads();
+    if (ts.depth >= 3 && threadIdx.x == 0) {
+        const u32 i = l0 >> 6;
+        if (i < ts.nwrite(ts.depth - 3)) nodes[TreeShape::level_start(ts.depth - 3) + i] = i < ts.nreal(ts.depth - 3) ? union_of_children(lvl2) : padding_node();
+    }
 }
 
-// The top of the tree in ONE launch: levels dtop-1 ... 0 (at most 1024 nodes each) by a single workgroup, a device-scope
-// fence and a barrier between levels (round 1 launched every level separately: ten tiny kernels, 12 us each).
-// real(d) = ceil(nleaves / 4^(depth - d)) nodes of level d are real.
-constexpr int TOP_LEVELS = 6;  // levels 0..5 are the workgroup's
-__global__ __launch_bounds__(1024) void k_upper_boxes_top(NodeBox* __restrict__ nodes, int dtop, int depth, u32 nleaves)
+// Up to five levels in one launch: a block owns the 1024 nodes of level c below one node of level c - 5 and computes
+// the 256 + 64 + 16 + 4 + 1 nodes above them (as many of those levels as exist: `levels`), the lower ones through LDS.
+// (round 2: one launch per level, then a single workgroup walking the top six levels: 76 us at 10 M points)
+constexpr int UPPER_BLOCK = 256;
+__global__ __launch_bounds__(UPPER_BLOCK) void k_upper_levels(NodeBox* __restrict__ nodes, TreeShape ts, int c, int levels)
 {
-    for (int d = dtop - 1; d >= 0; --d) {
-        const int sh = 2 * (depth - d);
-        const u32 nreal = static_cast<u32>((static_cast<u64>(nleaves) + (1ull << sh) - 1ull) >> sh);
-        const u32 nwrite = d == 0 ? 1u : (nreal + 3u) & ~3u;
-        const NodeBox* child = nodes + ((1ull << (2 * (d + 1))) - 1) / 3;
-        NodeBox* parent = nodes + ((1ull << (2 * d)) - 1) / 3;
-        for (u32 i = threadIdx.x; i < nwrite; i += blockDim.x)
-            parent[i] = i < nreal ? union_of_children(child + static_cast<u64>(i) * W) : padding_node();
-        __threadfence();
+    __shared__ NodeBox buf[2][UPPER_BLOCK];
+    const NodeBox* child = nodes + TreeShape::level_start(c) + static_cast<u64>(blockIdx.x) * (UPPER_BLOCK * 4);
+    u32 width = UPPER_BLOCK;  // nodes of this block at the level being computed
+    for (int j = 1; j <= levels; ++j, width >>= 2) {
+        const int d = c - j;
+        NodeBox* out = buf[j & 1];
+        if (threadIdx.x < width) {
+            const u32 i = blockIdx.x * width + threadIdx.x;
+            NodeBox nb = padding_node();
+            if (i < ts.nreal(d)) nb = union_of_children(j == 1 ? child + 4 * threadIdx.x : buf[(j - 1) & 1] + 4 * threadIdx.x);
+            out[threadIdx.x] = nb;
+            if (i < ts.nwrite(d)) nodes[TreeShape::level_start(d) + i] = nb;
+        }
         __syncthreads();
     }
 }
@@ -277,12 +351,18 @@ inline int depth_for(u64 nleaves)
     return d;
 }
 
+// (out of memory: the handle's pool of staging blocks may be sitting on gigabytes -- give them back and try once more)
 template <class T>
-int dev_alloc(T*& p, size_t count)
+int dev_alloc(T*& p, size_t count, DevPool* pool)
 {
     p = nullptr;
     if (count == 0) count = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipErrorOutOfMemory && pool && pool->cached_bytes() > 0) {
+        (void)hipGetLastError();
+        pool->trim();
+        e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
     if (e != hipSuccess) {
         p = nullptr;
         (void)hipGetLastError();
@@ -317,6 +397,11 @@ int ensure_scratch(Index& ix, size_t bytes)
         ix.scratch_bytes = 0;
     }
     hipError_t e = hipMalloc(&ix.d_scratch, bytes);
+    if (e == hipErrorOutOfMemory && ix.pool.cached_bytes() > 0) {
+        (void)hipGetLastError();
+        ix.pool.trim();
+        e = hipMalloc(&ix.d_scratch, bytes);
+    }
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu bytes) for query scratch failed: %s", bytes, hipGetErrorString(e));
         return PCPX_ERR_ALLOC;
@@ -352,6 +437,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
             float* xyz = nullptr;
             u64* codes[2] = {nullptr, nullptr};
             u32* perm = nullptr;
+            float4* rec = nullptr;
             Leaf* leaves = nullptr;
             NodeBox* nodes = nullptr;
             void* sort_tmp = nullptr;
@@ -362,28 +448,26 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
                 (void)hipFree(xyz);
                 (void)hipFree(codes[0]); (void)hipFree(codes[1]);
                 (void)hipFree(perm);
+                (void)hipFree(rec);
                 (void)hipFree(leaves); (void)hipFree(nodes); (void)hipFree(sort_tmp);
             }
         } nw;
         int st;
-        if ((st = dev_alloc(nw.xyz, cap * 3)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.xyz, cap * 3, &ix.pool)) != PCPX_OK) return st;
         for (int b = 0; b < 2; ++b)
-            if ((st = dev_alloc(nw.codes[b], cap)) != PCPX_OK) return st;
-        if ((st = dev_alloc(nw.perm, cap)) != PCPX_OK) return st;
+            if ((st = dev_alloc(nw.codes[b], cap, &ix.pool)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.perm, cap, &ix.pool)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.rec, cap, &ix.pool)) != PCPX_OK) return st;
         u32 nl = static_cast<u32>((cap + LEAF - 1) / LEAF);
-        if ((st = dev_alloc(nw.leaves, nl)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.leaves, nl, &ix.pool)) != PCPX_OK) return st;
         u64 nodes = level_start(depth_for(nl) + 1);
-        if ((st = dev_alloc(nw.nodes, nodes)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.nodes, nodes, &ix.pool)) != PCPX_OK) return st;
         size_t tb = 0;
         if ((st = sort_keys_u64(nullptr, tb, nullptr, nullptr, cap, s)) != PCPX_OK) return st;
         {
-            hipError_t e = hipMalloc(&nw.sort_tmp, tb ? tb : 16);
-            if (e != hipSuccess) {
-                nw.sort_tmp = nullptr;
-                set_error("hipMalloc(%zu bytes) for the sort's temporary storage failed: %s", tb, hipGetErrorString(e));
-                (void)hipGetLastError();
-                return PCPX_ERR_ALLOC;
-            }
+            char* tmp = nullptr;
+            if ((st = dev_alloc(tmp, tb ? tb : 16, &ix.pool)) != PCPX_OK) return st;
+            nw.sort_tmp = tmp;
         }
         (void)hipFree(ix.d_xyz);
         for (int b = 0; b < 2; ++b) {
@@ -392,6 +476,8 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         }
         (void)hipFree(ix.d_perm);
         ix.d_perm = nw.perm;
+        (void)hipFree(ix.d_rec);
+        ix.d_rec = nw.rec;
         (void)hipFree(ix.d_leaves);
         (void)hipFree(ix.d_nodes);
         (void)hipFree(ix.d_sort_tmp);
@@ -411,36 +497,40 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     }
     if (!ix.d_scalars) {
         int st;
-        if ((st = dev_alloc(ix.d_scalars, 16)) != PCPX_OK) return st;
+        if ((st = dev_alloc(ix.d_scalars, SCALARS, &ix.pool)) != PCPX_OK) return st;
     }
     ix.n_in = n;
-    if (n > 0 && d_xyz_src != ix.d_xyz)
-        PCPX_HIP(hipMemcpyAsync(ix.d_xyz, d_xyz_src, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const bool copy_cloud = n > 0 && d_xyz_src != ix.d_xyz;  // (the copy rides on k_codes' sweep over the coordinates)
 
     float* d_box = reinterpret_cast<float*>(ix.d_scalars + 8);
     if (use_grid) {
         float g[6] = {params->grid_min[0], params->grid_min[1], params->grid_min[2],
                       params->grid_max[0], params->grid_max[1], params->grid_max[2]};
         PCPX_HIP(hipMemcpyAsync(d_box, g, sizeof(g), hipMemcpyHostToDevice, s));
-        PCPX_HIP(hipMemsetAsync(ix.d_scalars + 6, 0, sizeof(u32), s));
         PCPX_HIP(hipStreamSynchronize(s));  // g is a stack temporary
     } else {
-        int st = device_bbox(ix.d_xyz, n, s, ix.d_scalars, d_box);
+        int st = device_bbox(d_xyz_src, n, s, ix.d_scalars, d_box);
         if (st != PCPX_OK) return st;
     }
     u32 nvalid = 0;
+    u32* d_ctl = ix.d_scalars + 16;  // [0, 256) counts of the words' top digit, [256] points outside the grid
+    PCPX_HIP(hipMemsetAsync(d_ctl, 0, 257 * sizeof(u32), s));
     if (n > 0) {
-        unsigned blocks = static_cast<unsigned>((n + 255) / 256);
+        u64 blocks = (n + CODES_BLOCK - 1) / CODES_BLOCK;
+        if (blocks > 512) blocks = 512;  // two resident blocks per CU; few blocks = few flushes of the digit counts
         ix.idx_bits = index_bits_for(n);
-        k_codes<<<blocks, 256, 0, s>>>(ix.d_xyz, n, d_box, ix.idx_bits, ix.d_codes[0]);
+        k_codes<<<static_cast<unsigned>(blocks), CODES_BLOCK, 0, s>>>(d_xyz_src, n, d_box, ix.idx_bits, ix.d_codes[0], copy_cloud ? ix.d_xyz : nullptr, d_ctl);
         PCPX_HIP(hipGetLastError());
         size_t tb = ix.sort_tmp_bytes;
-        int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT);
+        SortPayload pl;
+        pl.xyz = PCPX_BUILD_RECORDS ? d_xyz_src : nullptr;
+        pl.rec = ix.d_rec;
+        pl.idx_bits = ix.idx_bits;
+        pl.top_hist_ready = d_ctl;
+        int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
         if (st != PCPX_OK) return st;
-        k_count_valid<<<1, 64, 0, s>>>(ix.d_codes[1], static_cast<u32>(n), ix.d_scalars + 6, sort_failure_flag(ix.d_sort_tmp));
-    } else {
-        PCPX_HIP(hipMemsetAsync(ix.d_scalars + 6, 0, 2 * sizeof(u32), s));
     }
+    k_build_result<<<1, 64, 0, s>>>(static_cast<u32>(n), d_ctl + 256, n > 0 ? sort_failure_flag(ix.d_sort_tmp) : nullptr, ix.d_scalars + 6);
     float hb[8];
     PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, 8 * sizeof(u32), hipMemcpyDeviceToHost, s));
     PCPX_HIP(hipStreamSynchronize(s));
@@ -473,20 +563,30 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         return PCPX_ERR_INVALID;
     }
     if (nleaves > 0) {
-        // bottom level + leaf records in one pass, then the upper levels: real nodes only (+ the padding siblings of the
-        // last group of four, the only padding a query can read)
-        const u32 leaves_written = depth > 0 ? ((nleaves + 3u) & ~3u) : nleaves;
-        const u32 nslots = leaves_written * LEAF;
-        k_fill_leaves<<<(nslots + 255) / 256, 256, 0, s>>>(ix.d_xyz, ix.d_codes[1], ix.idx_bits, nvalid, nleaves, nslots, ix.d_leaves, ix.d_perm,
-                                                            ix.d_nodes + level_start(depth), depth > 0);
-        int d = depth - 1;
-        for (; d >= TOP_LEVELS; --d) {  // the wide levels: one launch each
-            const int sh = 2 * (depth - d);
-            const u32 nreal = static_cast<u32>((static_cast<u64>(nleaves) + (1ull << sh) - 1ull) >> sh);
-            const u32 nwrite = (nreal + 3u) & ~3u;
-            k_upper_boxes<<<(nwrite + 255) / 256, 256, 0, s>>>(ix.d_nodes + level_start(d + 1), ix.d_nodes + level_start(d), nreal, nwrite);
+        // leaf records, leaf boxes and the three levels above them in one pass, then up to five levels per launch: real
+        // nodes only (+ the padding siblings of the last group of four of a level, the only padding a query can read)
+        const TreeShape ts{nleaves, depth};
+        const u32 nslots = ts.nwrite(depth) * LEAF;
+        u32 fblocks = (nslots + FILL_BLOCK - 1) / FILL_BLOCK;
+        for (int j = 1; j <= 3 && j <= depth; ++j) {  // a block owns 64 >> 2j nodes of level depth - j
+            const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
+            const u32 need = (ts.nwrite(depth - j) + per_block - 1) / per_block;
+            if (need > fblocks) fblocks = need;
         }
-        if (d >= 0) k_upper_boxes_top<<<1, 1024, 0, s>>>(ix.d_nodes, d + 1, depth, nleaves);
+        const u32 fgrid = (fblocks + 7u) & ~7u;
+        k_fill_leaves<<<fgrid, FILL_BLOCK, 0, s>>>(PCPX_BUILD_RECORDS ? reinterpret_cast<const float4*>(ix.d_rec) : nullptr, ix.d_xyz, ix.d_codes[1], ix.idx_bits,
+                                                    nvalid, ts, fblocks, ix.d_leaves, ix.d_perm, ix.d_nodes);
+        for (int c = depth - 3; c > 0;) {
+            const int levels = c < 5 ? c : 5;
+            u32 ublocks = 1;
+            for (int j = 1; j <= levels; ++j) {
+                const u32 per_block = static_cast<u32>(UPPER_BLOCK) >> (2 * (j - 1));
+                const u32 need = (ts.nwrite(c - j) + per_block - 1) / per_block;
+                if (need > ublocks) ublocks = need;
+            }
+            k_upper_levels<<<ublocks, UPPER_BLOCK, 0, s>>>(ix.d_nodes, ts, c, levels);
+            c -= levels;
+        }
         PCPX_HIP(hipGetLastError());
     }
     return PCPX_OK;

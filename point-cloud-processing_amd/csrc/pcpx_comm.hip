@@ -15,6 +15,7 @@
 
 #include <mutex>
 #include <new>
+#include <string>
 
 namespace pcpx {
 
@@ -28,6 +29,7 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;  // the loader's message, captured where the load failed
 };
 
 Rccl& rccl()
@@ -38,6 +40,8 @@ Rccl& rccl()
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char* e = dlerror();  // (one call: it also clears the message)
+            if (e) r.why = e;
         }
         if (!r.lib) return;
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
@@ -46,6 +50,7 @@ Rccl& rccl()
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+        if (!r.ok) r.why = "symbols missing";
     });
     return r;
 }
@@ -53,7 +58,7 @@ Rccl& rccl()
 int need_rccl()
 {
     if (rccl().ok) return PCPX_OK;
-    set_error("pcpx: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    set_error("pcpx: librccl.so.1 could not be loaded (%s)", rccl().why.empty() ? "unknown reason" : rccl().why.c_str());
     return PCPX_ERR_UNSUPPORTED;
 }
 
@@ -165,6 +170,12 @@ int pcpx_comm_wrap(void* nccl_comm, int world, int rank, int device, pcpx_comm**
     *out = nullptr;
     int st = need_rccl();
     if (st != PCPX_OK) return st;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        (void)hipGetLastError();
+        set_error("pcpx_comm_wrap: device %d is not available", device);
+        return PCPX_ERR_DEVICE;
+    }
     DeviceGuard guard(device);
     Comm* cm = nullptr;
     if ((st = make_comm(static_cast<ncclComm_t>(nccl_comm), false, world, rank, device, &cm)) != PCPX_OK) return st;

@@ -10,9 +10,12 @@
 //
 // Sort word: 13 bits per axis of the 21-bit quantisation (the reference's octant bits, x most significant,
 // include/pcp/octree/linked_octree_node.hpp:258-265, are where the grid comes from) -> 39-bit Hilbert index in bits
-// [24, 63); bit 63 marks a point outside the voxel grid (it sorts last); the element's index sits in the low bits and
-// overwrites as many low key bits as it needs (a 13-bit index is a refinement of the 12-bit one, so dropping low bits
-// only coarsens the cells).  One 8-byte word per element is all the radix sort moves; it looks at bits [24, 64): 5 passes.
+// [25, 64), so that the word's top byte -- the digit the radix sort partitions by first -- is the curve's top 8 bits: 256
+// spatially compact buckets of about equal size for a uniform cloud.  The element's index sits in the low bits and
+// overwrites as many low key bits as it needs (a 13-bit index is a refinement of the 12-bit one, so dropping low bits only
+// coarsens the cells).  A point outside the voxel grid gets the all-ones key and sorts last; an inserted point's key is
+// kept off that value (bit 24 is zero below 16.7 M points; beyond, the curve's very last cell is merged with its
+// predecessor).  One 8-byte word per element is all the radix sort moves; it looks at bits [24, 64): 5 passes.
 #ifndef PCPX_CURVE_H
 #define PCPX_CURVE_H
 
@@ -96,12 +99,22 @@ __host__ __device__ __forceinline__ u64 hilbert_index(u32 x, u32 y, u32 z)
     return (spread21(X[0]) << 2) | (spread21(X[1]) << 1) | spread21(X[2]);
 }
 
-// curve key (bits [24, 63)) of a point inside the grid box6 = {min xyz, max xyz}
+// curve key (bits [25, 64)) of a point inside the grid box6 = {min xyz, max xyz}
 __device__ __forceinline__ u64 curve_key(float x, float y, float z, float b0, float b1, float b2, float b3, float b4, float b5)
 {
     const u32 qx = quant21(x, b0, b3) >> (21 - CURVE_BITS), qy = quant21(y, b1, b4) >> (21 - CURVE_BITS),
               qz = quant21(z, b2, b5) >> (21 - CURVE_BITS);
     return hilbert_index(qx, qy, qz) << CURVE_FIRST_BIT;
+}
+// the same for a point the index inserts: never the all-ones pattern above the word's index bits, which marks a point
+// outside the grid
+__device__ __forceinline__ u64 curve_key_inside(float x, float y, float z, float b0, float b1, float b2, float b3, float b4, float b5, int idx_bits)
+{
+    const u32 qx = quant21(x, b0, b3) >> (21 - CURVE_BITS), qy = quant21(y, b1, b4) >> (21 - CURVE_BITS),
+              qz = quant21(z, b2, b5) >> (21 - CURVE_BITS);
+    const u64 hmax = ((1ull << (3 * CURVE_BITS)) - 1ull) - (idx_bits >= CURVE_FIRST_BIT ? (1ull << (idx_bits - CURVE_FIRST_BIT)) : 0ull);
+    const u64 h = hilbert_index(qx, qy, qz);
+    return (h < hmax ? h : hmax) << CURVE_FIRST_BIT;
 }
 // the sort word of element `index`: its key with the low idx_bits replaced by the index
 __device__ __forceinline__ u64 sort_word(u64 key, u64 index, int idx_bits)
@@ -109,7 +122,8 @@ __device__ __forceinline__ u64 sort_word(u64 key, u64 index, int idx_bits)
     const u64 low = (1ull << idx_bits) - 1ull;
     return (key & ~low) | index;
 }
-constexpr u64 OUTSIDE_BIT = 1ull << 63;
+// the word of an element outside the grid (or NaN): greater than every inserted point's word
+__device__ __forceinline__ u64 outside_word(u64 index, int idx_bits) { return (~0ull << idx_bits) | index; }
 
 }  // namespace pcpx
 

@@ -1,8 +1,8 @@
 // pcpx_internal.h -- shared between the build, query and API translation units of libpcpx.so.
 //
 // Index layout in HBM (see DESIGN.md "Data layout"):
-//   * points are sorted by a 63-bit Morton code (21 bits/axis, x most significant like the
-//     reference's octant bits, include/pcp/octree/linked_octree_node.hpp:258-265);
+//   * points are sorted along a Hilbert curve over the voxel grid (pcpx_curve.h; the grid is the reference's,
+//     include/pcp/octree/linked_octree_node.hpp:258-265);
 //   * the sorted order is cut into LEAVES of LEAF consecutive points, stored SoA per leaf
 //     {x[LEAF], y[LEAF], z[LEAF], id[LEAF]} so that one leaf is one contiguous 16*LEAF-byte record
 //     that a wavefront fetches with scalar (SMEM) loads and broadcasts to its 64 lanes;
@@ -34,13 +34,12 @@ constexpr int GROUP = 64;  // queries per wavefront
 constexpr int LEAVES_PER_GROUP = GROUP / LEAF;
 constexpr int MAXDEPTH = 15;  // 4^15 leaves of 8 points: far beyond 2^32 points
 constexpr u32 INVALID_ID = 0xFFFFFFFFu;
-constexpr u64 PAD_CODE = ~0ull;
 // The curve order only has to make leaves spatially compact: any order gives a correct tree (boxes come from the
-// points).  A sort word is {bit 63: outside the grid, bits [24, 63): 39-bit curve key (13 bits per axis: cells of 1/8192
-// of the grid extent), low bits: the element's index}; the radix sort looks at bits [24, 64) only -- 5 passes -- and the
-// index overwrites as many of the key's low bits as it needs (more than 24 only beyond 16.7 M elements: 12 key bits per
-// axis up to 134 M, 11 up to 1 G); see pcpx_curve.h.
-constexpr int CURVE_FIRST_BIT = 24;
+// points).  A sort word is {bits [25, 64): 39-bit curve key (13 bits per axis: cells of 1/8192 of the grid extent), low
+// bits: the element's index; all ones above the index: outside the grid}; the radix sort looks at bits [24, 64) only -- 5
+// passes -- and the index overwrites as many of the key's low bits as it needs (more than 25 only beyond 33 M elements:
+// 12 key bits per axis up to 268 M); see pcpx_curve.h.
+constexpr int CURVE_FIRST_BIT = 25;
 #ifndef PCPX_SORT_FIRST_BIT
 #define PCPX_SORT_FIRST_BIT 24
 #endif
@@ -116,6 +115,7 @@ struct DevPool {
     std::vector<Block> blocks;
     void* acquire(size_t bytes);  // nullptr (and the thread's error text set) when the device is out of memory
     void release(void* p);
+    void discard(void* p);        // returns a handed-out block to the driver instead of caching it
     void trim();                  // frees every block that is not handed out
     size_t cached_bytes() const;
     ~DevPool();
@@ -147,13 +147,14 @@ struct Index {
     float* d_xyz = nullptr;      // n_in x 3, input order
     u64* d_codes[2] = {nullptr, nullptr};  // sort words: [0] input order, [1] sorted
     u32* d_perm = nullptr;                 // sorted position -> input index
+    float4* d_rec = nullptr;               // {x, y, z, input index} per point, grouped by the sort word's top digit (the leaf fill's source)
     int idx_bits = 1;                      // low bits of a sort word that hold the input index
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     Leaf* d_leaves = nullptr;
     NodeBox* d_nodes = nullptr;
     u64 nodes_cap = 0;           // nodes
-    u32* d_scalars = nullptr;    // [0..6) encoded bbox, [6] valid count, 6 floats decoded bbox at [8..14)
+    u32* d_scalars = nullptr;    // [0..6) encoded bbox, [6] valid count, [7] sort failure, 6 floats decoded bbox at [8..14), [16, 273) k_codes' counters
     u32 nleaves = 0;
     int depth = 0;
     u32 leaf0 = 0;
@@ -216,10 +217,18 @@ int check_hip(hipError_t e, const char* what, const char* file, int line);
 // build.hip
 int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
 int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6);
-// stable LSD radix sort of 64-bit words by their bits [first_bit, 64) (first_bit a multiple of 8); words that agree on
+// stable radix sort of 64-bit words by their bits [first_bit, 64) (first_bit a multiple of 8); words that agree on
 // those bits keep their input order.  sort_failure_flag: device word of the temporary storage that the sort sets if its
 // look-back ever gave up (it never should); read it after synchronising the stream.
-int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit = 0);
+// payload (optional): what the index build hangs on the sort's first pass.
+struct SortPayload {
+    const float* xyz = nullptr;           // n x 3 in the words' input order: with `rec` and `idx_bits`, the first pass moves {x, y, z, index}
+    float4* rec = nullptr;                //   of every element to its word's position after that pass and writes that position into the
+    int idx_bits = 0;                     //   word's low idx_bits (which held the element's index)
+    const u32* top_hist_ready = nullptr;  // 256 counts of the words' top digit (bits [56, 64)), if the caller has them already
+};
+int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit = 0,
+                  const SortPayload* payload = nullptr);
 const u32* sort_failure_flag(void* tmp);
 int ensure_scratch(Index& ix, size_t bytes);
 

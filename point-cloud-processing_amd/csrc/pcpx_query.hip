@@ -902,6 +902,11 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
             ix.multi_bytes = 0;
         }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix.d_multi), need);
+        if (e == hipErrorOutOfMemory && ix.pool.cached_bytes() > 0) {  // the handle's staging pool may hold what is missing
+            (void)hipGetLastError();
+            ix.pool.trim();
+            e = hipMalloc(reinterpret_cast<void**>(&ix.d_multi), need);
+        }
         if (e != hipSuccess) {
             set_error("hipMalloc(%zu bytes) for the k > 32 key buffer failed: %s", need, hipGetErrorString(e));
             return PCPX_ERR_ALLOC;

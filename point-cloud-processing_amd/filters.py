@@ -41,6 +41,8 @@ def wlop(points, I=None, mu=0.45, h=0.0, k=10, uniform=True, sample=None, seed=N
     if sample is None:
         if I is None:
             raise ValueError("give I or sample")
+        if not 0 < int(I) <= len(pts):  # (the reference asserts J >= I, wlop.hpp:300)
+            raise ValueError("I must be between 1 and the number of points")
         sample = np.random.default_rng(seed).permutation(len(pts))[len(pts) - int(I):]
     sample = np.ascontiguousarray(sample, dtype=np.uint64)
     out = np.empty((len(sample), 3), np.float32)
