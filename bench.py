@@ -269,6 +269,8 @@ def main():
                     help="skip the side measurements (rebuild, range count, host-pointer ABI rates, normal evidence): the "
                          "process then launches nothing but the timed steps, which is what the profiling scripts want")
     ap.add_argument("--host-api-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--with-range-consumers", action="store_true",
+                    help="also run tools/filter_bench.py (bilateral filter, WLOP: extras outside the hot path) and report it under extra")
     ap.add_argument("--with-1m", action="store_true",
                     help="also time configs[1] (1 M points, k=15) and report it under extra; off by default so that the "
                          "default command launches k_knn on the headline workload only (its rocprofv3 average then "
@@ -386,7 +388,7 @@ def main():
             extra.update(json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1]))
         except Exception as e:  # a side measurement must not take the bench line down
             extra["host_api_error"] = repr(e)[:200]
-        if args.workload == "uniform_10m_k15":
+        if args.workload == "uniform_10m_k15" and args.with_range_consumers:
             # the in-library consumers of sphere ranges on the same cloud (bilateral filter, WLOP), own process
             # for the same reason
             try:

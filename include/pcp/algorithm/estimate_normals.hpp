@@ -264,8 +264,9 @@ void propagate_normal_orientations(ForwardIter1 begin, ForwardIter1 end, IndexMa
         target.reserve(n * knn_map.k);
         for (std::size_t i = 0; i < n; ++i)
         {
-            for (std::uint32_t j = 0; j < rows.count[i]; ++j)
-                target.push_back(static_cast<std::size_t>(index_map(knn_map.tree->element(rows.idx[i * knn_map.k + j]))));
+            std::uint32_t const* row = rows.row(i);
+            for (std::uint32_t j = 0; j < rows.size_of_row(i); ++j)
+                target.push_back(static_cast<std::size_t>(index_map(knn_map.tree->element(row[j]))));
             first[i + 1] = target.size();
         }
     }

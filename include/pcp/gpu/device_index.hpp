@@ -36,11 +36,17 @@ inline std::atomic<int>& default_device()
 }
 
 // k-nearest-neighbour rows of a batch: row q = idx[q*k .. q*k + count[q])
+// (self queries of the whole index may come back in the index's curve order -- that form overlaps the copies with the
+//  kernels, pcpx_normals_knn_self_curve_order -- with the table that says where the row of input point i is)
 struct knn_result_t
 {
     std::uint32_t k = 0;
     std::vector<std::uint32_t> idx;
     std::vector<std::uint32_t> count;
+    std::vector<std::uint32_t> position_of;  // empty: row i belongs to query / input point i
+    std::size_t row_of(std::size_t i) const { return position_of.empty() ? i : position_of[i]; }
+    std::uint32_t const* row(std::size_t i) const { return idx.data() + row_of(i) * k; }
+    std::uint32_t size_of_row(std::size_t i) const { return count[row_of(i)]; }
 };
 
 // A typed block of device memory (hipMalloc behind the C ABI: this header does not need a HIP toolchain).
@@ -218,8 +224,8 @@ class device_index_t
                 std::int64_t const i = find(q);
                 if (i >= 0)
                 {
-                    auto const* row = knn_.rows.idx.data() + static_cast<std::size_t>(i) * k;
-                    out.assign(row, row + knn_.rows.count[static_cast<std::size_t>(i)]);
+                    auto const* row = knn_.rows.row(static_cast<std::size_t>(i));
+                    out.assign(row, row + knn_.rows.size_of_row(static_cast<std::size_t>(i)));
                     return out;
                 }
             }
@@ -307,7 +313,16 @@ class device_index_t
         r.k = k;
         r.idx.resize(static_cast<std::size_t>(rows) * k);
         r.count.assign(static_cast<std::size_t>(rows), 0u);
-        if (rows && k) check(pcpx_knn_self(h_, k, eps, r.idx.data(), r.count.data(), nullptr), "pcpx_knn_self");
+        if (!(rows && k)) return r;
+        if (n_ == n_in_ && rows == n_in_)
+        {
+            // every input point is indexed: rows in curve order + the table of positions; the rows reach the host while later
+            // slices are still being computed (access through row(i) / size_of_row(i))
+            r.position_of.resize(static_cast<std::size_t>(rows));
+            check(pcpx_normals_knn_self_curve_order(h_, k, eps, nullptr, r.idx.data(), r.count.data(), nullptr, r.position_of.data()),
+                  "pcpx_normals_knn_self_curve_order");
+        }
+        else check(pcpx_knn_self(h_, k, eps, r.idx.data(), r.count.data(), nullptr), "pcpx_knn_self");
         return r;
     }
     // CSR lists of the points inside each sphere (per-sphere radii)

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define PCPX_ABI_VERSION 2
+#define PCPX_ABI_VERSION 3
 
 typedef enum pcpx_status {
     PCPX_OK = 0,
@@ -65,7 +65,7 @@ typedef struct pcpx_index pcpx_index; /* opaque: device buffers + stream */
 /* Build flags */
 #define PCPX_BUILD_USE_GRID 1u /* voxel_grid given: points outside it are silently dropped         \
                                   (linked_octree_node.hpp:174-175, linked_octree.hpp:83-91);        \
-                                  also the Morton quantisation box (e.g. the union of per-rank      \
+                                  also the curve-key quantisation box (e.g. the union of per-rank      \
                                   boxes after the RCCL all-gather).  Otherwise the tight bounding   \
                                   box of the input is used (linked_octree.hpp:103-121).           */
 
@@ -106,7 +106,7 @@ int pcpx_knn_self(pcpx_index* idx, uint32_t k, float eps, uint32_t* out_idx, uin
 /* Arbitrary query points. */
 int pcpx_knn_batch(pcpx_index* idx, const float* q_xyz, uint64_t nq, uint32_t k, float eps,
                    uint32_t* out_idx, uint32_t* out_count, float* out_d2);
-/* Device-pointer form.  Only Morton-sorted positions [sorted_first, sorted_first+sorted_count) are
+/* Device-pointer form.  Only curve-sorted positions [sorted_first, sorted_first+sorted_count) are
  * processed (rows of the other points are left untouched) -- the per-rank query shard of the
  * multi-GPU path; pass 0, UINT64_MAX for all.  sorted_first must be a multiple of 64. */
 int pcpx_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
@@ -136,6 +136,14 @@ int pcpx_range_aabb_batch(pcpx_index* idx, const float* boxes6, uint64_t nb, uin
  * as in the reference (test/algorithm/estimate_normals.cpp:58-59). */
 int pcpx_normals_knn_self(pcpx_index* idx, uint32_t k, float eps, float* out_normals, uint32_t* opt_out_idx,
                           uint32_t* opt_out_count);
+/* The same with the rows in CURVE ORDER (additive; no reference counterpart): row p belongs to the p-th inserted point of
+ * the index's sorted order, i.e. to input point opt_out_perm[p] (pcpx_index_size rows); neighbour indices inside the rows
+ * are input indices as everywhere.  opt_out_position_of (n entries, 0xFFFFFFFF for a point outside the voxel grid) is the
+ * inverse: the row of input point i.  The library computes the rows slice by slice along the curve and copies a finished
+ * slice to the host while the next ones are computed, which the input-order form cannot do (its rows are scattered over
+ * the whole output): use this form when the rows are consumed through a table anyway. */
+int pcpx_normals_knn_self_curve_order(pcpx_index* idx, uint32_t k, float eps, float* opt_out_normals, uint32_t* out_idx,
+                                      uint32_t* out_count, uint32_t* opt_out_perm, uint32_t* opt_out_position_of);
 int pcpx_normals_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first,
                               uint64_t sorted_count, float* d_out_normals, uint32_t* d_opt_out_idx,
                               uint32_t* d_opt_out_count);
@@ -274,11 +282,11 @@ int pcpx_index_synchronize(pcpx_index* idx);
 /* Per-kernel device time, measured with hipEvents recorded on the index's stream around every kernel
  * family launched between pcpx_profile_begin and pcpx_profile_end (which synchronises the stream). */
 typedef enum pcpx_kernel_family {
-    PCPX_K_BUILD = 0,   /* bbox + Morton codes + sort + leaves + boxes (one interval per build) */
+    PCPX_K_BUILD = 0,   /* bbox + curve keys + sort + leaves + boxes (one interval per build) */
     PCPX_K_KNN = 1,     /* k_knn */
     PCPX_K_NORMALS = 2, /* k_normals */
     PCPX_K_RANGE = 3,   /* k_range / k_range_aabb */
-    PCPX_K_QUERY_PREP = 4, /* query Morton sort + seeds of *_batch calls */
+    PCPX_K_QUERY_PREP = 4, /* query curve sort + seeds of *_batch calls */
     PCPX_K_FAMILIES = 5
 } pcpx_kernel_family;
 typedef struct pcpx_profile {

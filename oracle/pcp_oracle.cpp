@@ -120,14 +120,17 @@ struct Sphere {
 };
 
 // include/pcp/common/intersections.hpp:87-102 and :113-130.  NOTE the reference compares the
-// squared distance against `radius`, not radius^2 -- restated as is.
+// squared distance against `radius`, not radius^2 -- restated as is.  Test switch (orc_set_geometric_prune): the same
+// traversal with the comparison against radius^2, so that a test can show that what the reference's range search misses
+// for radius > 1 is exactly what this comparison prunes (tests/test_gpu_parity.py: ranges wider than 1).
+static bool g_geometric_prune = false;
 inline bool intersects(Box const& b, Sphere const& s)
 {
     bool const in = (s.c.x >= b.min.x && s.c.x <= b.max.x) && (s.c.y >= b.min.y && s.c.y <= b.max.y) &&
                     (s.c.z >= b.min.z && s.c.z <= b.max.z);
     if (in) return true;
     P3 const np = b.nearest(s.c);
-    return sqdist(np, s.c) <= s.r;
+    return sqdist(np, s.c) <= (g_geometric_prune ? s.r * s.r : s.r);
 }
 // include/pcp/common/intersections.hpp:25-32 and :43-54
 inline bool intersects(Box const& a, Box const& b)
@@ -594,6 +597,9 @@ void parallel_for(u64 n, int nthreads, F&& f)
 
 extern "C" {
 
+void orc_set_geometric_prune(int on) { g_geometric_prune = on != 0; }
+
+
 void orc_bbox(float const* xyz, u64 n, float out[6])
 {
     Box b = bounding_box(reinterpret_cast<P3 const*>(xyz), n);
@@ -607,22 +613,52 @@ void orc_bbox(float const* xyz, u64 n, float out[6])
 void orc_knn_bruteforce(float const* xyz, u64 n, float const* qxyz, u64 nq, u32 k, float eps, u32* out_idx,
                         u32* out_cnt, float* out_d2, int nthreads)
 {
+    // Every (query, point) pair is evaluated; only the bookkeeping is organised for speed: a thread takes a block of
+    // queries and sweeps the cloud in cache-sized tiles for all of them (the cloud is streamed from memory once per block,
+    // not once per query), and a pair becomes a candidate only if its distance is within the query's current k-th best
+    // (candidates are cut back to the k smallest (d2, index) pairs whenever 4k have piled up).  The result is the first k
+    // of all pairs outside the eps-box in ascending (d2, index) order, exactly as if all of them had been sorted.
     P3 const* pts = reinterpret_cast<P3 const*>(xyz);
     P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
-    parallel_for(nq, nthreads, [&](u64 q) {
-        std::vector<std::pair<float, u32>> cand;
-        cand.reserve(n);
-        for (u64 i = 0; i < n; ++i) {
-            if (vec_equal(pts[i], qs[q], eps)) continue;
-            cand.emplace_back(sqdist(qs[q], pts[i]), static_cast<u32>(i));
+    constexpr u64 QB = 16, TILE = 8192;
+    u64 const nblocks = (nq + QB - 1) / QB;
+    parallel_for(nblocks, nthreads, [&](u64 blk) {
+        u64 const q0 = blk * QB, q1 = std::min(nq, q0 + QB);
+        std::vector<std::pair<float, u32>> cand[QB];
+        float tau[QB];
+        for (u64 j = 0; j < QB; ++j) tau[j] = std::numeric_limits<float>::infinity();
+        u64 const cap = std::max<u64>(4 * static_cast<u64>(k), 64);
+        for (u64 t0 = 0; t0 < n; t0 += TILE) {
+            u64 const t1 = std::min(n, t0 + TILE);
+            for (u64 q = q0; q < q1; ++q) {
+                auto& c = cand[q - q0];
+                float const tq = tau[q - q0];
+                P3 const qp = qs[q];
+                for (u64 i = t0; i < t1; ++i) {
+                    float const d2 = sqdist(qp, pts[i]);
+                    if (!(d2 <= tq)) continue;  // (NaN distances are never candidates, as with the full sort: they compare false)
+                    if (vec_equal(pts[i], qp, eps)) continue;
+                    c.emplace_back(d2, static_cast<u32>(i));
+                }
+                if (c.size() >= cap && k > 0) {
+                    std::nth_element(c.begin(), c.begin() + static_cast<std::ptrdiff_t>(k - 1), c.end());
+                    c.resize(k);
+                    float kth = c[0].first;
+                    for (auto const& e : c) kth = std::max(kth, e.first);
+                    tau[q - q0] = kth;
+                }
+            }
         }
-        u64 const m = std::min<u64>(k, cand.size());
-        std::partial_sort(cand.begin(), cand.begin() + static_cast<std::ptrdiff_t>(m), cand.end());
-        for (u64 j = 0; j < k; ++j) {
-            out_idx[q * k + j] = j < m ? cand[j].second : 0xFFFFFFFFu;
-            if (out_d2) out_d2[q * k + j] = j < m ? cand[j].first : std::numeric_limits<float>::infinity();
+        for (u64 q = q0; q < q1; ++q) {
+            auto& c = cand[q - q0];
+            u64 const m = std::min<u64>(k, c.size());
+            std::partial_sort(c.begin(), c.begin() + static_cast<std::ptrdiff_t>(m), c.end());
+            for (u64 j = 0; j < k; ++j) {
+                out_idx[q * k + j] = j < m ? c[j].second : 0xFFFFFFFFu;
+                if (out_d2) out_d2[q * k + j] = j < m ? c[j].first : std::numeric_limits<float>::infinity();
+            }
+            out_cnt[q] = static_cast<u32>(m);
         }
-        out_cnt[q] = static_cast<u32>(m);
     });
 }
 
@@ -632,11 +668,21 @@ void orc_range_count_bruteforce(float const* xyz, u64 n, float const* qxyz, u64 
 {
     P3 const* pts = reinterpret_cast<P3 const*>(xyz);
     P3 const* qs = reinterpret_cast<P3 const*>(qxyz);
-    parallel_for(nq, nthreads, [&](u64 q) {
-        Sphere s{qs[q], r};
-        u32 c = 0;
-        for (u64 i = 0; i < n; ++i) c += s.contains(pts[i]) ? 1u : 0u;
-        out_cnt[q] = c;
+    constexpr u64 QB = 16, TILE = 8192;  // (blocks of queries over cache-sized tiles of the cloud, as above)
+    u64 const nblocks = (nq + QB - 1) / QB;
+    parallel_for(nblocks, nthreads, [&](u64 blk) {
+        u64 const q0 = blk * QB, q1 = std::min(nq, q0 + QB);
+        u32 c[QB] = {};
+        for (u64 t0 = 0; t0 < n; t0 += TILE) {
+            u64 const t1 = std::min(n, t0 + TILE);
+            for (u64 q = q0; q < q1; ++q) {
+                Sphere const s{qs[q], r};
+                u32 acc = 0;
+                for (u64 i = t0; i < t1; ++i) acc += s.contains(pts[i]) ? 1u : 0u;
+                c[q - q0] += acc;
+            }
+        }
+        for (u64 q = q0; q < q1; ++q) out_cnt[q] = c[q - q0];
     });
 }
 

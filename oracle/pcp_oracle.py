@@ -74,6 +74,12 @@ def knn_bruteforce(xyz, queries, k, eps=1e-5, nthreads=1, want_d2=False):
     return (idx, cnt, d2) if want_d2 else (idx, cnt)
 
 
+def set_geometric_prune(on):
+    """Test switch: the restated trees' box-sphere test compares with radius^2 instead of the reference's `radius`
+    (include/pcp/common/intersections.hpp:101,129).  Off by default: the oracle is the reference."""
+    lib().orc_set_geometric_prune(C.c_int(1 if on else 0))
+
+
 def range_count_bruteforce(xyz, queries, r, nthreads=1):
     xyz = _f32(xyz).reshape(-1, 3)
     q = _f32(queries).reshape(-1, 3)

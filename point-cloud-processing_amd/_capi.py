@@ -10,7 +10,7 @@ f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 
-ABI_VERSION = 2  # include/pcpx.h PCPX_ABI_VERSION
+ABI_VERSION = 3  # include/pcpx.h PCPX_ABI_VERSION
 PCPX_OK = 0
 PCPX_ERR_INVALID = -1
 PCPX_ERR_DEVICE = -2
@@ -70,6 +70,7 @@ SIGNATURES = {
                                           C.c_void_p, C.c_uint64]),
     "pcpx_range_aabb_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pcpx_normals_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcpx_normals_knn_self_curve_order": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcpx_normals_knn_self_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
     "pcpx_tangent_planes_knn_self": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]),

@@ -15,14 +15,16 @@ LIB = os.path.join(HERE, "libpcpx.so")
 SOURCES = ["pcpx_query.hip", "pcpx_few.hip", "pcpx_range.hip", "pcpx_filter.hip", "pcpx_normals.hip", "pcpx_prep.hip", "pcpx_orient.hip", "pcpx_build.hip", "pcpx_sort.hip",
            "pcpx_comm.hip", "pcpx_api.hip"]
 HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(CSRC, "pcpx_device.h"), os.path.join(CSRC, "pcpx_eig3.h"), os.path.join(CSRC, "pcpx_curve.h"),
+           os.path.join(CSRC, "pcpx_curve_table.h"),
            os.path.join(INCLUDE, "pcpx.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the reference evaluates dx*dx+dy*dy+dz*dz without FMA; neighbour order and the
 # eigen-solver restatement are only bit-comparable with it if the GPU does not fuse either.
 # -fno-slp-vectorize: SLP packs the scalar f32 distance code into v_pk_* ops plus v_mov shuffles; packed
 # f32 is not faster than scalar VALU on gfx950 and the shuffles cost ~4 % (measured, tools/ab_variants.py).
+# -Wall -Werror=uninitialized: a self-initialised index (`u32 tid = tid;`) once reached the GPU as a wild address.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=" + ARCH,
-         "-I" + INCLUDE]
+         "-Wall", "-Werror=uninitialized", "-I" + INCLUDE]
 
 
 def _hipcc():

@@ -3,6 +3,7 @@
 // enqueue on the index's stream.  No CPU fallback exists: every compute call needs a HIP device.
 #include "pcpx_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdlib>
@@ -284,6 +285,7 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_scratch);
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
+    if (ix->copy_stream) (void)hipStreamDestroy(ix->copy_stream);
     if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;  // (the pool and the pinned stage free their memory in their destructors, while the device is still current)
 }
@@ -923,6 +925,72 @@ int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_norma
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
     return self_queries_to_host(ix, k, eps, out_normals, opt_out_idx, opt_out_count, nullptr);
+}
+
+// Rows in curve order: the kernel writes the rows of a slice of the sorted order into one contiguous piece of every output
+// array, so a finished slice travels to the host while the later slices are still being computed (the input-order form
+// scatters rows over the whole output: its copy cannot start before the last kernel has ended).
+int pcpx_normals_knn_self_curve_order(pcpx_index* h, uint32_t k, float eps, float* opt_out_normals, uint32_t* out_idx, uint32_t* out_count,
+                                      uint32_t* opt_out_perm, uint32_t* opt_out_position_of)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    if (k == 0 || !out_idx || !out_count) return PCPX_ERR_INVALID;
+    const u64 rows = ix->n;  // inserted points only: a point outside the voxel grid has no position on the curve
+    if (opt_out_position_of && ix->n != ix->n_in) std::memset(opt_out_position_of, 0xFF, ix->n_in * sizeof(u32));
+    if (rows == 0) return PCPX_OK;
+    if (!ix->copy_stream) PCPX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+    DevBuf dn(ix->pool), di(ix->pool), dc(ix->pool), dinv(ix->pool);
+    if (opt_out_normals && (st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
+    if ((st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK || (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
+    if (opt_out_position_of && (st = dinv.alloc(ix->n_in * sizeof(u32))) != PCPX_OK) return st;
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    KnnOutputs o;
+    o.idx = di.as<u32>();
+    o.cnt = dc.as<u32>();
+    o.normals = dn.as<float>();
+    o.by_position = 1;
+    const u64 groups = (rows + GROUP - 1) / GROUP;
+    constexpr int MAX_SLICES = 8;
+    const int slices = static_cast<int>(groups < 8 * 1024 ? 1 : MAX_SLICES);  // (a slice should still fill the chip a few times over)
+    hipEvent_t done[MAX_SLICES] = {};
+    struct EventGuard {
+        hipEvent_t* e;
+        ~EventGuard()
+        {
+            for (int i = 0; i < MAX_SLICES; ++i)
+                if (e[i]) (void)hipEventDestroy(e[i]);
+        }
+    } guard{done};
+    // all the kernels first (enqueueing does not block) ...
+    u64 g_first[MAX_SLICES + 1];
+    for (int s = 0; s <= slices; ++s) g_first[s] = groups * static_cast<u64>(s) / static_cast<u64>(slices);
+    for (int s = 0; s < slices; ++s) {
+        if ((st = launch_knn(*ix, qv, true, g_first[s], g_first[s + 1] - g_first[s], k, eps, o)) != PCPX_OK) return st;
+        PCPX_HIP(hipEventCreateWithFlags(&done[s], hipEventDisableTiming));
+        PCPX_HIP(hipEventRecord(done[s], ix->stream));
+    }
+    if (opt_out_position_of) {
+        if (ix->n != ix->n_in) PCPX_HIP(hipMemsetAsync(dinv.p, 0xFF, ix->n_in * sizeof(u32), ix->stream));
+        if ((st = launch_invert_perm(ix->d_perm, rows, dinv.as<u32>(), ix->stream)) != PCPX_OK) return st;
+    }
+    // ... then the copies, slice by slice, on the second stream, each behind its slice's kernel
+    if (opt_out_perm) PCPX_HIP(hipMemcpyAsync(opt_out_perm, ix->d_perm, rows * sizeof(u32), hipMemcpyDeviceToHost, ix->copy_stream));
+    for (int s = 0; s < slices; ++s) {
+        const u64 r0 = g_first[s] * GROUP, r1 = std::min<u64>(rows, g_first[s + 1] * GROUP);
+        PCPX_HIP(hipStreamWaitEvent(ix->copy_stream, done[s], 0));
+        PCPX_HIP(hipMemcpyAsync(out_idx + r0 * k, di.as<u32>() + r0 * k, (r1 - r0) * k * sizeof(u32), hipMemcpyDeviceToHost, ix->copy_stream));
+        PCPX_HIP(hipMemcpyAsync(out_count + r0, dc.as<u32>() + r0, (r1 - r0) * sizeof(u32), hipMemcpyDeviceToHost, ix->copy_stream));
+        if (opt_out_normals)
+            PCPX_HIP(hipMemcpyAsync(opt_out_normals + 3 * r0, dn.as<float>() + 3 * r0, (r1 - r0) * 3 * sizeof(float), hipMemcpyDeviceToHost, ix->copy_stream));
+    }
+    PCPX_HIP(hipStreamSynchronize(ix->copy_stream));
+    if (opt_out_position_of) PCPX_HIP(hipMemcpyAsync(opt_out_position_of, dinv.p, ix->n_in * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
 }
 
 int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t* count, uint64_t nq, uint32_t k,

@@ -3,9 +3,10 @@
 // Replaces the reference's sequential octree insertion (include/pcp/octree/linked_octree_node.hpp:143-331)
 // and recursive nth_element kd-tree build (include/pcp/kdtree/linked_kdtree.hpp:343-424).  Only query
 // RESULTS are observable through the reference API, not the tree shape, so the structure here is a
-// Morton-sorted implicit AABB tree (pcpx_internal.h) built by:
-//   bbox reduce -> 63-bit Morton codes (+ out-of-grid drop) -> radix sort of (code, index) (pcpx_sort.hip)
-//   -> leaf records (SoA, NaN padded) -> leaf AABBs -> bottom-up sweep of the W-ary levels.
+// curve-sorted implicit AABB tree (pcpx_internal.h, pcpx_curve.h) built by:
+//   bbox reduce -> one sort word per point: 39-bit Hilbert key + index (+ out-of-grid drop) -> radix sort, whose first pass
+//   also moves a {x, y, z, id} record per point into its top-digit bucket (pcpx_sort.hip) -> leaf records (SoA, NaN padded),
+//   leaf AABBs and three tree levels in one pass -> the remaining levels, five per launch.
 #include "pcpx_curve.h"
 
 #include <cmath>
@@ -19,7 +20,7 @@ namespace {
 #define PCPX_BUILD_RECORDS 1  // 1: the sort's first pass moves a {x, y, z, id} record per point into its top-digit bucket and the leaf
                               // fill gathers from there; 0: the leaf fill gathers the coordinates from the input-order copy
 #endif
-constexpr size_t SCALARS = 288;  // u32 words of Index::d_scalars: [0, 6) encoded box, [6] inserted points, [7] sort failure, [8, 14) box, [16, 273) k_codes' counters
+constexpr size_t SCALARS = 16;  // u32 words of Index::d_scalars: [0, 6) encoded box, [6] points outside the grid, [7] sort failure, [8, 14) box
 
 // order-preserving float <-> uint encoding for atomic min/max
 __device__ __forceinline__ u32 enc_f(float f)
@@ -70,12 +71,20 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, u64
     const float4* v = reinterpret_cast<const float4*>(xyz + 3 * head);
     const u64 gtid = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
     const u64 gstride = static_cast<u64>(gridDim.x) * blockDim.x;
-    for (u64 q = gtid; q < nquad; q += gstride) {
+    // two quads per trip: six 16-byte loads in flight per lane (with three the launch was pure load latency: 90 % of the waves'
+    // time waiting at 16 waves per CU, profiles/r03_pmc_rebuild.json)
+    for (u64 q = gtid; q < nquad; q += 2 * gstride) {
+        const u64 q2 = q + gstride < nquad ? q + gstride : q;  // (the last trip may repeat its quad: min/max do not mind)
         const float4 a = v[3 * q], b = v[3 * q + 1], c = v[3 * q + 2];
+        const float4 d = v[3 * q2], e = v[3 * q2 + 1], f = v[3 * q2 + 2];
         bbox_point(mn, mx, a.x, a.y, a.z);
         bbox_point(mn, mx, a.w, b.x, b.y);
         bbox_point(mn, mx, b.z, b.w, c.x);
         bbox_point(mn, mx, c.y, c.z, c.w);
+        bbox_point(mn, mx, d.x, d.y, d.z);
+        bbox_point(mn, mx, d.w, e.x, e.y);
+        bbox_point(mn, mx, e.z, e.w, f.x);
+        bbox_point(mn, mx, f.y, f.z, f.w);
     }
     // the peeled points and the tail (fewer than 8 in all): the first threads of the grid take one each
     const u64 tail0 = head + 4 * nquad;
@@ -116,56 +125,73 @@ __global__ void k_bbox_decode(const u32* enc6, float* out6)
     if (threadIdx.x < 6) out6[threadIdx.x] = dec_f(enc6[threadIdx.x]);
 }
 
+// First launch of a build: the encoded box starts at (+max, -max), the counters of Index::d_scalars at zero.
+__global__ void k_build_begin(u32* __restrict__ scalars)
+{
+    const u32 t = threadIdx.x;
+    if (t < 3) scalars[t] = enc_f(std::numeric_limits<float>::max());
+    else if (t < 6) scalars[t] = enc_f(std::numeric_limits<float>::lowest());
+    else if (t < 8) scalars[t] = 0u;  // [6] points outside the grid, [7] the sort's failure flag
+}
+
 // Sort word (pcpx_curve.h) of every point: curve key of a point inside the grid, the all-ones key for a point outside it
 // (or NaN) -- it sorts to the end: the "silently not inserted" rule of linked_octree_node.hpp:174-175 (inclusive
 // containment, include/pcp/common/axis_aligned_bounding_box.hpp:111-125).  The same sweep over the coordinates
 //   * keeps the index's own copy of the cloud (the reference's containers copy their elements too, linked_kdtree.hpp:107;
 //     round 2 spent a separate 120 MB device copy on it),
-//   * counts the words' top digit for the sort's first pass (round 2: a separate sweep over the words),
-//   * counts the points outside the grid (round 2: a one-thread binary search kernel after the sort).
-// ctl: [0, 256) top-digit counts, [256] points outside; zeroed by the caller.
+//   * counts the words' top digit per tile of the sort's first pass (round 2: a separate sweep over the words), which is what lets
+//     that pass run without a look-back chain (pcpx_sort.hip),
+//   * counts the points outside the grid (round 2: a one-thread binary search kernel after the sort),
+//   * decodes the bounding box the reduction left in its order-preserving integer form (round 2: a launch of its own).
+// scalars: Index::d_scalars.
 constexpr int CODES_BLOCK = 1024;
-__global__ __launch_bounds__(CODES_BLOCK) void k_codes(const float* __restrict__ xyz, u64 n, const float* __restrict__ box6, int idx_bits,
-                                                        u64* __restrict__ codes, float* __restrict__ xyz_copy, u32* __restrict__ ctl)
+__global__ __launch_bounds__(CODES_BLOCK) void k_codes(const float* __restrict__ xyz, u64 n, u32* __restrict__ scalars, bool decode_box, int idx_bits,
+                                                        u64* __restrict__ codes, float* __restrict__ xyz_copy, u32* __restrict__ tile_hist)
 {
     __shared__ u32 hist[256];
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const float b0 = box6[0], b1 = box6[1], b2 = box6[2], b3 = box6[3], b4 = box6[4], b5 = box6[5];
-    const u64 stride = static_cast<u64>(gridDim.x) * CODES_BLOCK;
+    __shared__ u32 htab[HILBERT_TABLE_WORDS];
+    float* box6 = reinterpret_cast<float*>(scalars + 8);
+    float b[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) b[a] = decode_box ? dec_f(scalars[a]) : box6[a];
+    if (decode_box && blockIdx.x == 0 && threadIdx.x < 6) box6[threadIdx.x] = dec_f(scalars[threadIdx.x]);
+    hilbert_table_to_lds(htab);
+    const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+    const CurveGrid grid = curve_grid(b0, b1, b2, b3, b4, b5);
     u32 outside = 0;
-    for (u64 i = blockIdx.x * static_cast<u64>(CODES_BLOCK) + threadIdx.x; i < n; i += stride) {
-        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        if (xyz_copy) {
-            xyz_copy[3 * i] = x;
-            xyz_copy[3 * i + 1] = y;
-            xyz_copy[3 * i + 2] = z;
+    // a block works through whole tiles of the sort (SORT_TILE_WORDS consecutive points), so that the counts it leaves behind are
+    // the sort's per-tile counts of the top digit
+    const u64 ntiles = (n + SORT_TILE_WORDS - 1) / SORT_TILE_WORDS;
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SORT_TILE_WORDS / CODES_BLOCK; ++it) {
+            const u64 i = tile * SORT_TILE_WORDS + static_cast<u64>(it) * CODES_BLOCK + threadIdx.x;
+            if (i < n) {
+                const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+                if (xyz_copy) {
+                    xyz_copy[3 * i] = x;
+                    xyz_copy[3 * i + 1] = y;
+                    xyz_copy[3 * i + 2] = z;
+                }
+                const bool ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
+                const u64 word = ok ? sort_word(curve_key_inside(x, y, z, grid, htab, idx_bits), i, idx_bits) : outside_word(i, idx_bits);
+                codes[i] = word;
+                outside += ok ? 0u : 1u;
+                atomicAdd(&hist[static_cast<u32>(word >> 56)], 1u);
+            }
         }
-        const bool ok = (x >= b0 && y >= b1 && z >= b2) && (x <= b3 && y <= b4 && z <= b5);
-        const u64 word = ok ? sort_word(curve_key_inside(x, y, z, b0, b1, b2, b3, b4, b5, idx_bits), i, idx_bits) : outside_word(i, idx_bits);
-        codes[i] = word;
-        outside += ok ? 0u : 1u;
-        atomicAdd(&hist[static_cast<u32>(word >> 56)], 1u);
+        __syncthreads();
+        if (threadIdx.x < 256) tile_hist[tile * 256 + threadIdx.x] = hist[threadIdx.x];
+        __syncthreads();
     }
     const u64 some_outside = __builtin_amdgcn_ballot_w64(outside != 0u);
     if (some_outside) {  // rare: one atomic per wave that saw any
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) outside += __shfl_xor(outside, off);
-        if ((threadIdx.x & 63u) == 0) atomicAdd(&ctl[256], outside);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&scalars[6], outside);
     }
-    __syncthreads();
-    if (threadIdx.x < 256) {
-        const u32 c = hist[threadIdx.x];
-        if (c) atomicAdd(&ctl[threadIdx.x], c);
-    }
-}
-
-// what the host needs after the sort: [0] inserted points, [1] the sort's failure flag
-__global__ void k_build_result(u32 n, const u32* __restrict__ outside, const u32* __restrict__ sort_failed, u32* __restrict__ out)
-{
-    if (threadIdx.x != 0) return;
-    out[0] = n - *outside;
-    out[1] = sort_failed ? *sort_failed : 0u;
 }
 
 __device__ __forceinline__ NodeBox padding_node()
@@ -239,83 +265,114 @@ struct TreeShape {
 // {x, y, z, id}, which the sort's first pass left in the point's top-digit bucket: the gather of a block stays inside an
 // L2-sized window (round 2 gathered 12-byte coordinates from all over the cloud: 686 MB fetched for 120 MB) -- plus, in
 // the same pass, the sorted position -> input index table, the leaf's tight box (min / max over the leaf's 8 lanes) and
-// the three tree levels above the leaves (a block owns 64 leaves = one level-(depth - 3) node).
+// the three tree levels above the leaves (a block owns 128 leaves = two level-(depth - 3) nodes).  A thread takes four
+// points, 256 positions apart, so that four gathers are in flight per lane.
 // Blocks are dealt so that each XCD works through one contiguous eighth of the sorted order.
-constexpr int FILL_BLOCK = 512;
-constexpr int FILL_LEAVES = FILL_BLOCK / LEAF;  // 64
+constexpr int FILL_BLOCK = 256;
+#ifndef PCPX_FILL_PER_THREAD
+#define PCPX_FILL_PER_THREAD 4
+#endif
+constexpr int FILL_PER_THREAD = PCPX_FILL_PER_THREAD;
+constexpr int FILL_SLOTS = FILL_BLOCK * FILL_PER_THREAD;  // 1024
+constexpr int FILL_LEAVES = FILL_SLOTS / LEAF;            // 128
 __global__ __launch_bounds__(FILL_BLOCK) void k_fill_leaves(const float4* __restrict__ rec, const float* __restrict__ xyz,
                                                             const u64* __restrict__ sorted_codes, int idx_bits, u32 n, TreeShape ts,
                                                             u32 nblocks, Leaf* __restrict__ leaves, u32* __restrict__ perm,
                                                             NodeBox* __restrict__ nodes)
 {
-    __shared__ NodeBox lvl0[FILL_LEAVES];      // leaf boxes of the block
-    __shared__ NodeBox lvl1[FILL_LEAVES / 4];
-    __shared__ NodeBox lvl2[FILL_LEAVES / 16];
+    __shared__ __attribute__((aligned(16))) NodeBox lvl0[FILL_LEAVES];      // leaf boxes of the block
+    __shared__ __attribute__((aligned(16))) NodeBox lvl1[FILL_LEAVES / 4];
+    __shared__ __attribute__((aligned(16))) NodeBox lvl2[FILL_LEAVES / 16];
+    __shared__ __attribute__((aligned(16))) u32 rec_stage[FILL_BLOCK / 64][FILL_PER_THREAD][64 * 4];  // per wave and trip: 8 leaf records
     const u32 per = gridDim.x >> 3;  // the grid is a multiple of 8
     const u32 vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    const u32 p = vb * FILL_BLOCK + threadIdx.x;
     if (vb >= nblocks) return;  // (the grid is rounded up to a multiple of 8; a block may exist only for the padding nodes it owns)
-    float x = __builtin_nanf(""), y = x, z = x;
-    u32 id = INVALID_ID;
-    if (p < n) {
-        const u64 at = sorted_codes[p] & ((1ull << idx_bits) - 1ull);
+    const u32 p0 = vb * FILL_SLOTS + threadIdx.x;
+    const u64 low = (1ull << idx_bits) - 1ull;
+    u64 at[FILL_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < FILL_PER_THREAD; ++u) {
+        const u32 p = p0 + u * FILL_BLOCK;
+        at[u] = sorted_codes[p < n ? p : (n ? n - 1u : 0u)] & low;
+    }
+    float x[FILL_PER_THREAD], y[FILL_PER_THREAD], z[FILL_PER_THREAD];
+    u32 id[FILL_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < FILL_PER_THREAD; ++u) {
         if (rec) {
-            const float4 r = rec[at];
-            x = r.x;
-            y = r.y;
-            z = r.z;
-            id = __float_as_uint(r.w);
+            const float4 r = rec[at[u]];
+            x[u] = r.x;
+            y[u] = r.y;
+            z[u] = r.z;
+            id[u] = __float_as_uint(r.w);
         } else {
-            id = static_cast<u32>(at);
-            x = xyz[3 * at];
-            y = xyz[3 * at + 1];
-            z = xyz[3 * at + 2];
+            id[u] = static_cast<u32>(at[u]);
+            x[u] = xyz[3 * at[u]];
+            y[u] = xyz[3 * at[u] + 1];
+            z[u] = xyz[3 * at[u] + 2];
         }
-        perm[p] = id;
     }
-    const u32 leaf = p / LEAF;
-    const int s = p % LEAF;
-    if (leaf < ts.nleaves) {
-        Leaf& lf = leaves[leaf];
-        lf.x[s] = x;
-        lf.y[s] = y;
-        lf.z[s] = z;
-        lf.id[s] = id;
-    }
-    const float inf = std::numeric_limits<float>::infinity();
-    // (every lane of the 8-lane group takes part in the reduction, whatever it holds)
-    const float lx = leaf_min(p < n ? x : inf), ly = leaf_min(p < n ? y : inf), lz = leaf_min(p < n ? z : inf);
-    const float hx = leaf_max(p < n ? x : -inf), hy = leaf_max(p < n ? y : -inf), hz = leaf_max(p < n ? z : -inf);
-    if (s == 0) {
-        NodeBox nb = padding_node();
-        if (leaf < ts.nleaves) {
-            nb.lo[0] = lx; nb.lo[1] = ly; nb.lo[2] = lz;
-            nb.hi[0] = hx; nb.hi[1] = hy; nb.hi[2] = hz;
-            nb.poison = 0.f;
+    const float inf = std::numeric_limits<float>::infinity(), nan = __builtin_nanf("");
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < FILL_PER_THREAD; ++u) {
+        const u32 p = p0 + u * FILL_BLOCK;
+        const bool live = p < n;
+        if (live) perm[p] = id[u];
+        // The wave's 64 points are 8 whole leaf records = 1 KB of contiguous memory.  Written field by field straight from
+        // the registers every store instruction touches eight 32-byte pieces of eight different lines (that is what the
+        // kernel was waiting on: profiles/r03_pmc_rebuild.json); through LDS every lane stores 16 contiguous bytes and the
+        // wave one contiguous kilobyte.  (Wave-private LDS region: no barrier, a wave's LDS operations execute in order.)
+        u32* stage = rec_stage[w][u];
+        const u32 ls = (lane >> 3) * 32u + (lane & 7u);  // slot s of leaf (lane >> 3) of the wave: x at +0, y +8, z +16, id +24
+        stage[ls] = __float_as_uint(live ? x[u] : nan);
+        stage[ls + 8] = __float_as_uint(live ? y[u] : nan);
+        stage[ls + 16] = __float_as_uint(live ? z[u] : nan);
+        stage[ls + 24] = live ? id[u] : INVALID_ID;
+        __builtin_amdgcn_wave_barrier();  // (scheduling fence only: the reads below see the other lanes' writes)
+        const u32 wave_leaf0 = (p - lane) / LEAF;  // first leaf of the wave's 64 points
+        const uint4 piece = *reinterpret_cast<const uint4*>(stage + 4 * lane);
+        if (wave_leaf0 + (lane >> 3) < ts.nleaves) reinterpret_cast<uint4*>(leaves + wave_leaf0)[lane] = piece;
+        // (every lane of the 8-lane group takes part in the reduction, whatever it holds)
+        const float lx = leaf_min(live ? x[u] : inf), ly = leaf_min(live ? y[u] : inf), lz = leaf_min(live ? z[u] : inf);
+        const float hx = leaf_max(live ? x[u] : -inf), hy = leaf_max(live ? y[u] : -inf), hz = leaf_max(live ? z[u] : -inf);
+        if ((p % LEAF) == 0) {
+            NodeBox nb = padding_node();
+            if (p / LEAF < ts.nleaves) {
+                nb.lo[0] = lx; nb.lo[1] = ly; nb.lo[2] = lz;
+                nb.hi[0] = hx; nb.hi[1] = hy; nb.hi[2] = hz;
+                nb.poison = 0.f;
+            }
+            lvl0[(threadIdx.x + u * FILL_BLOCK) / LEAF] = nb;
         }
-        lvl0[threadIdx.x / LEAF] = nb;
-        if (leaf < ts.nwrite(ts.depth)) nodes[TreeShape::level_start(ts.depth) + leaf] = nb;
     }
-    // the three levels above: 16, 4 and 1 node of this block
+    // the block's leaf boxes, then the three levels above (32, 8 and 2 nodes per 128 leaves): every level leaves LDS as
+    // 16-byte pieces of one contiguous run of the heap
     const u32 l0 = vb * FILL_LEAVES;  // the block's first leaf
+    auto store_level = [&](const NodeBox* boxes, u32 count, int level, u32 first) {
+        const u32 nw = ts.nwrite(level);
+        uint4* dst = reinterpret_cast<uint4*>(nodes + TreeShape::level_start(level) + first);
+        for (u32 t = threadIdx.x; t < 2 * count; t += FILL_BLOCK)
+            if (first + (t >> 1) < nw) dst[t] = reinterpret_cast<const uint4*>(boxes)[t];
+    };
     __syncthreads();
+    store_level(lvl0, FILL_LEAVES, ts.depth, l0);
     if (ts.depth >= 1 && threadIdx.x < FILL_LEAVES / 4) {
         const u32 i = (l0 >> 2) + threadIdx.x;
-        const NodeBox nb = i < ts.nreal(ts.depth - 1) ? union_of_children(lvl0 + 4 * threadIdx.x) : padding_node();
-        lvl1[threadIdx.x] = nb;
-        if (i < ts.nwrite(ts.depth - 1)) nodes[TreeShape::level_start(ts.depth - 1) + i] = nb;
+        lvl1[threadIdx.x] = i < ts.nreal(ts.depth - 1) ? union_of_children(lvl0 + 4 * threadIdx.x) : padding_node();
     }
     __syncthreads();
+    if (ts.depth >= 1) store_level(lvl1, FILL_LEAVES / 4, ts.depth - 1, l0 >> 2);
     if (ts.depth >= 2 && threadIdx.x < FILL_LEAVES / 16) {
         const u32 i = (l0 >> 4) + threadIdx.x;
-        const NodeBox nb = i < ts.nreal(ts.depth - 2) ? union_of_children(lvl1 + 4 * threadIdx.x) : padding_node();
-        lvl2[threadIdx.x] = nb;
-        if (i < ts.nwrite(ts.depth - 2)) nodes[TreeShape::level_start(ts.depth - 2) + i] = nb;
+        lvl2[threadIdx.x] = i < ts.nreal(ts.depth - 2) ? union_of_children(lvl1 + 4 * threadIdx.x) : padding_node();
     }
     __syncthreads();
-    if (ts.depth >= 3 && threadIdx.x == 0) {
-        const u32 i = l0 >> 6;
-        if (i < ts.nwrite(ts.depth - 3)) nodes[TreeShape::level_start(ts.depth - 3) + i] = i < ts.nreal(ts.depth - 3) ? union_of_children(lvl2) : padding_node();
+    if (ts.depth >= 2) store_level(lvl2, FILL_LEAVES / 16, ts.depth - 2, l0 >> 4);
+    if (ts.depth >= 3 && threadIdx.x < FILL_LEAVES / 64) {
+        const u32 i = (l0 >> 6) + threadIdx.x;
+        if (i < ts.nwrite(ts.depth - 3))
+            nodes[TreeShape::level_start(ts.depth - 3) + i] = i < ts.nreal(ts.depth - 3) ? union_of_children(lvl2 + 4 * threadIdx.x) : padding_node();
     }
 }
 
@@ -374,15 +431,19 @@ int dev_alloc(T*& p, size_t count, DevPool* pool)
 
 }  // namespace
 
+static void launch_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6)
+{
+    u64 blocks = (n / 4 + 255) / 256;  // a thread takes four points per trip
+    if (blocks > 1024) blocks = 1024;   // (every block ends with six atomics on the same six words: 2048 blocks spent a third of the
+                                        //  10 M-point launch there)
+    if (blocks < 1) blocks = 1;
+    k_bbox<<<static_cast<unsigned>(blocks), 256, 0, s>>>(d_xyz, n, d_enc6);
+}
+
 int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6)
 {
     k_bbox_init<<<1, 64, 0, s>>>(d_enc6, d_enc6 + 6);
-    if (n > 0) {
-        u64 blocks = (n / 4 + 255) / 256;  // a thread takes four points per trip
-        if (blocks > 2048) blocks = 2048;   // 8 blocks per CU
-        if (blocks < 1) blocks = 1;
-        k_bbox<<<static_cast<unsigned>(blocks), 256, 0, s>>>(d_xyz, n, d_enc6);
-    }
+    if (n > 0) launch_bbox(d_xyz, n, s, d_enc6);
     k_bbox_decode<<<1, 64, 0, s>>>(d_enc6, d_out6);
     return check_hip(hipGetLastError(), "bbox kernels", __FILE__, __LINE__);
 }
@@ -502,49 +563,54 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     ix.n_in = n;
     const bool copy_cloud = n > 0 && d_xyz_src != ix.d_xyz;  // (the copy rides on k_codes' sweep over the coordinates)
 
+    // d_scalars: [0, 6) the box in its order-preserving integer form, [6] points outside the grid, [7] the sort's failure
+    // flag, [8, 14) the box
     float* d_box = reinterpret_cast<float*>(ix.d_scalars + 8);
+    k_build_begin<<<1, 64, 0, s>>>(ix.d_scalars);
     if (use_grid) {
         float g[6] = {params->grid_min[0], params->grid_min[1], params->grid_min[2],
                       params->grid_max[0], params->grid_max[1], params->grid_max[2]};
         PCPX_HIP(hipMemcpyAsync(d_box, g, sizeof(g), hipMemcpyHostToDevice, s));
         PCPX_HIP(hipStreamSynchronize(s));  // g is a stack temporary
-    } else {
-        int st = device_bbox(d_xyz_src, n, s, ix.d_scalars, d_box);
-        if (st != PCPX_OK) return st;
+    } else if (n > 0) {
+        launch_bbox(d_xyz_src, n, s, ix.d_scalars);
     }
     u32 nvalid = 0;
-    u32* d_ctl = ix.d_scalars + 16;  // [0, 256) counts of the words' top digit, [256] points outside the grid
-    PCPX_HIP(hipMemsetAsync(d_ctl, 0, 257 * sizeof(u32), s));
-    if (n > 0) {
-        u64 blocks = (n + CODES_BLOCK - 1) / CODES_BLOCK;
-        if (blocks > 512) blocks = 512;  // two resident blocks per CU; few blocks = few flushes of the digit counts
+    {
+        u64 blocks = (n + SORT_TILE_WORDS - 1) / SORT_TILE_WORDS;  // a block takes whole tiles
+        if (blocks > 512) blocks = 512;  // two resident blocks per CU
+        if (blocks < 1) blocks = 1;       // (n = 0: the launch still decodes the box)
         ix.idx_bits = index_bits_for(n);
-        k_codes<<<static_cast<unsigned>(blocks), CODES_BLOCK, 0, s>>>(d_xyz_src, n, d_box, ix.idx_bits, ix.d_codes[0], copy_cloud ? ix.d_xyz : nullptr, d_ctl);
+        k_codes<<<static_cast<unsigned>(blocks), CODES_BLOCK, 0, s>>>(d_xyz_src, n, ix.d_scalars, !use_grid, ix.idx_bits, ix.d_codes[0],
+                                                                     copy_cloud ? ix.d_xyz : nullptr, sort_tile_hist_buffer(ix.d_sort_tmp, n));
         PCPX_HIP(hipGetLastError());
+    }
+    if (n > 0) {
         size_t tb = ix.sort_tmp_bytes;
         SortPayload pl;
         pl.xyz = PCPX_BUILD_RECORDS ? d_xyz_src : nullptr;
         pl.rec = ix.d_rec;
         pl.idx_bits = ix.idx_bits;
-        pl.top_hist_ready = d_ctl;
+        pl.tile_hist_ready = sort_tile_hist_buffer(ix.d_sort_tmp, n);
+        pl.failed_flag = ix.d_scalars + 7;
         int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
         if (st != PCPX_OK) return st;
     }
-    k_build_result<<<1, 64, 0, s>>>(static_cast<u32>(n), d_ctl + 256, n > 0 ? sort_failure_flag(ix.d_sort_tmp) : nullptr, ix.d_scalars + 6);
     float hb[8];
     PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, 8 * sizeof(u32), hipMemcpyDeviceToHost, s));
     PCPX_HIP(hipStreamSynchronize(s));
-    std::memcpy(&nvalid, &hb[0], sizeof(u32));
-    std::memcpy(ix.bbox, &hb[2], 6 * sizeof(float));
     {
-        u32 sort_failed = 0;
+        u32 outside = 0, sort_failed = 0;
+        std::memcpy(&outside, &hb[0], sizeof(u32));
         std::memcpy(&sort_failed, &hb[1], sizeof(u32));
+        std::memcpy(ix.bbox, &hb[2], 6 * sizeof(float));
         if (n > 0 && sort_failed) {
             ix.n = ix.n_in = 0;
             ix.nleaves = 0;
             set_error("pcpx: internal error, the radix sort's look-back gave up");
             return PCPX_ERR_DEVICE;
         }
+        nvalid = static_cast<u32>(n) - outside;
     }
     ix.n = nvalid;
 
@@ -567,8 +633,8 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         // nodes only (+ the padding siblings of the last group of four of a level, the only padding a query can read)
         const TreeShape ts{nleaves, depth};
         const u32 nslots = ts.nwrite(depth) * LEAF;
-        u32 fblocks = (nslots + FILL_BLOCK - 1) / FILL_BLOCK;
-        for (int j = 1; j <= 3 && j <= depth; ++j) {  // a block owns 64 >> 2j nodes of level depth - j
+        u32 fblocks = (nslots + FILL_SLOTS - 1) / FILL_SLOTS;
+        for (int j = 1; j <= 3 && j <= depth; ++j) {  // a block owns 128 >> 2j nodes of level depth - j
             const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
             const u32 need = (ts.nwrite(depth - j) + per_block - 1) / per_block;
             if (need > fblocks) fblocks = need;

@@ -19,6 +19,7 @@
 #ifndef PCPX_CURVE_H
 #define PCPX_CURVE_H
 
+#include "pcpx_curve_table.h"
 #include "pcpx_internal.h"
 
 namespace pcpx {
@@ -48,15 +49,6 @@ __host__ __device__ __forceinline__ u32 spread10(u32 v)
 }
 // the same for 3 bits
 __host__ __device__ __forceinline__ u32 spread3(u32 v) { return (v | (v << 2) | (v << 4)) & 0x49u; }
-
-__device__ __forceinline__ u32 quant21(float v, float lo, float hi)
-{
-    float ext = hi - lo;
-    float t = ext > 0.f ? (v - lo) / ext : 0.f;
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    u32 q = static_cast<u32>(t * 2097152.f);
-    return q > 2097151u ? 2097151u : q;
-}
 
 // Hilbert index of the cell (x, y, z), BITS bits per axis (J. Skilling, "Programming the Hilbert curve", AIP Conf.
 // Proc. 707, 2004: axes -> transposed index by undoing the excess work of the Gray code, then the bits are interleaved).
@@ -99,21 +91,74 @@ __host__ __device__ __forceinline__ u64 hilbert_index(u32 x, u32 y, u32 z)
     return (spread21(X[0]) << 2) | (spread21(X[1]) << 1) | spread21(X[2]);
 }
 
-// curve key (bits [25, 64)) of a point inside the grid box6 = {min xyz, max xyz}
-__device__ __forceinline__ u64 curve_key(float x, float y, float z, float b0, float b1, float b2, float b3, float b4, float b5)
+// The same index through the generated state machine (pcpx_curve_table.h): the Morton code of the cell, six bits at a
+// time, each step one table look-up {index bits, next state}.  ~70 vector instructions and 7 LDS reads per cell instead of
+// ~260 (the arithmetic form walks 12 levels x 3 axes of dependent bit-twiddling; profiles/r02_pmc_rebuild.json: 367
+// instructions per point in k_codes, compute bound).  `tab`: HILBERT_TABLE_WORDS words, the layout of PCPX_HILBERT_TABLE_INIT
+// (in a kernel: a copy in LDS, hilbert_table_to_lds).  tests/cpp/test_curve.hip checks it against hilbert_index<13>.
+__host__ __device__ __forceinline__ u64 hilbert_index_table(u32 x, u32 y, u32 z, const u32* __restrict__ tab)
 {
-    const u32 qx = quant21(x, b0, b3) >> (21 - CURVE_BITS), qy = quant21(y, b1, b4) >> (21 - CURVE_BITS),
-              qz = quant21(z, b2, b5) >> (21 - CURVE_BITS);
-    return hilbert_index(qx, qy, qz) << CURVE_FIRST_BIT;
+    static_assert(CURVE_BITS == 13, "the table walk below is laid out for 13 levels: 1 + 6 x 2");
+    const u32 lo = (spread10(x) << 2) | (spread10(y) << 1) | spread10(z);                    // levels 9 .. 0
+    const u32 hi = (spread3(x >> 10) << 2) | (spread3(y >> 10) << 1) | spread3(z >> 10);     // levels 12, 11, 10
+    u32 e = tab[hi >> 6];                                                                    // level 12
+    u32 h_hi = e & 63u;
+    e = tab[8u + ((e & 0xFFFFFF00u) >> 2) + (hi & 63u)];                                     // levels 11, 10
+    h_hi = (h_hi << 6) | (e & 63u);
+    u32 h_lo = 0;
+#pragma unroll
+    for (int t = 4; t >= 0; --t) {
+        e = tab[8u + ((e & 0xFFFFFF00u) >> 2) + ((lo >> (6 * t)) & 63u)];
+        h_lo = (h_lo << 6) | (e & 63u);
+    }
+    return (static_cast<u64>(h_hi) << 30) | h_lo;
+}
+
+#ifdef __HIPCC__
+// the tables of hilbert_index_table, read by every kernel that makes curve keys (each copies them into LDS once per block)
+static __device__ const u32 hilbert_table_dev[HILBERT_TABLE_WORDS] = {PCPX_HILBERT_TABLE_INIT};
+__device__ __forceinline__ void hilbert_table_to_lds(u32* lds_tab)
+{
+    for (u32 i = threadIdx.x; i < static_cast<u32>(HILBERT_TABLE_WORDS); i += blockDim.x) lds_tab[i] = hilbert_table_dev[i];
+    __syncthreads();
+}
+#endif
+
+// Quantisation of one axis to CURVE_BITS bits: cell = floor((v - lo) x scale), scale = 2^CURVE_BITS / extent (0 for a flat
+// axis), clamped into the grid (a query may lie outside; NaN -> cell 0).
+struct CurveGrid {
+    float lo[3], scale[3];
+};
+__device__ __forceinline__ CurveGrid curve_grid(float b0, float b1, float b2, float b3, float b4, float b5)
+{
+    CurveGrid g;
+    const float lo[3] = {b0, b1, b2}, hi[3] = {b3, b4, b5};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = hi[a] - lo[a];
+        g.lo[a] = lo[a];
+        g.scale[a] = ext > 0.f ? static_cast<float>(1 << CURVE_BITS) / ext : 0.f;
+    }
+    return g;
+}
+__device__ __forceinline__ u32 curve_cell(float v, float lo, float scale)
+{
+    const float t = fminf(fmaxf((v - lo) * scale, 0.f), static_cast<float>((1 << CURVE_BITS) - 1));
+    return static_cast<u32>(t);
+}
+
+// curve key (bits [25, 64)) of a point on the grid g
+__device__ __forceinline__ u64 curve_key(float x, float y, float z, const CurveGrid& g, const u32* __restrict__ lds_tab)
+{
+    return hilbert_index_table(curve_cell(x, g.lo[0], g.scale[0]), curve_cell(y, g.lo[1], g.scale[1]), curve_cell(z, g.lo[2], g.scale[2]), lds_tab)
+           << CURVE_FIRST_BIT;
 }
 // the same for a point the index inserts: never the all-ones pattern above the word's index bits, which marks a point
 // outside the grid
-__device__ __forceinline__ u64 curve_key_inside(float x, float y, float z, float b0, float b1, float b2, float b3, float b4, float b5, int idx_bits)
+__device__ __forceinline__ u64 curve_key_inside(float x, float y, float z, const CurveGrid& g, const u32* __restrict__ lds_tab, int idx_bits)
 {
-    const u32 qx = quant21(x, b0, b3) >> (21 - CURVE_BITS), qy = quant21(y, b1, b4) >> (21 - CURVE_BITS),
-              qz = quant21(z, b2, b5) >> (21 - CURVE_BITS);
     const u64 hmax = ((1ull << (3 * CURVE_BITS)) - 1ull) - (idx_bits >= CURVE_FIRST_BIT ? (1ull << (idx_bits - CURVE_FIRST_BIT)) : 0ull);
-    const u64 h = hilbert_index(qx, qy, qz);
+    const u64 h = hilbert_index_table(curve_cell(x, g.lo[0], g.scale[0]), curve_cell(y, g.lo[1], g.scale[1]), curve_cell(z, g.lo[2], g.scale[2]), lds_tab);
     return (h < hmax ? h : hmax) << CURVE_FIRST_BIT;
 }
 // the sort word of element `index`: its key with the low idx_bits replaced by the index

@@ -23,7 +23,7 @@ constexpr int WAVES_PER_BLOCK = PCPX_WPB;  // 1: a finished wave frees its LDS a
 __device__ __forceinline__ u32 wave_in_block() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 // XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so give XCD x the
-// contiguous range of virtual blocks [x*per, (x+1)*per): Morton neighbours then share one L2.
+// contiguous range of virtual blocks [x*per, (x+1)*per): curve neighbours then share one L2.
 __device__ __forceinline__ u32 virtual_block()
 {
     u32 per = gridDim.x >> 3;  // grid is a multiple of 8
@@ -74,7 +74,7 @@ __device__ __forceinline__ u32 lds_address(const void* p)
 
 // ---- wave-uniform walk over the implicit 4-ary tree ------------------------------------------------
 
-// All members are wave-uniform (SGPRs).  next() yields, in Morton order, every leaf whose box is still
+// All members are wave-uniform (SGPRs).  next() yields, in curve (= sorted) order, every leaf whose box is still
 // needed by at least one lane at the time its parent is expanded.  State: bit 4*h + c of `pend` = child c
 // (a node of height h; leaves have height 0) of the current ancestor of height h+1 is still to visit.  A
 // depth-first walk always continues with the LOWEST set bit of pend, so popping is one find-first-set: no

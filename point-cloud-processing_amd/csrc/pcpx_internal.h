@@ -89,9 +89,11 @@ struct KnnOutputs {
     float* normals = nullptr;   // rows x 3: pcp::estimate_normal of the row
     float* centroids = nullptr; // rows x 3: pcp::common::center_of_geometry of the row (tangent plane point)
     float* meandist = nullptr;  // rows: mean Euclidean distance to the row's neighbours
+    u32 by_position = 0;        // self queries only: 1 = row index = the query's SORTED position instead of its input index (rows
+                                // of a slice of the curve order are then one contiguous piece of every output array)
 };
 
-// Queries of a batch, in Morton-sorted order.  For self queries qx == nullptr and the query of
+// Queries of a batch, in curve-sorted order.  For self queries qx == nullptr and the query of
 // sorted position p is point p of the leaves.
 struct QueryView {
     const float* qx;
@@ -154,7 +156,7 @@ struct Index {
     Leaf* d_leaves = nullptr;
     NodeBox* d_nodes = nullptr;
     u64 nodes_cap = 0;           // nodes
-    u32* d_scalars = nullptr;    // [0..6) encoded bbox, [6] valid count, [7] sort failure, 6 floats decoded bbox at [8..14), [16, 273) k_codes' counters
+    u32* d_scalars = nullptr;    // [0..6) encoded bbox, [6] points outside the grid, [7] sort failure, 6 floats decoded bbox at [8..14)
     u32 nleaves = 0;
     int depth = 0;
     u32 leaf0 = 0;
@@ -175,6 +177,7 @@ struct Index {
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
 
+    hipStream_t copy_stream = nullptr;  // second stream of the sliced host-pointer form (copies of finished slices beside the kernels)
     DevPool pool;        // staging buffers of the host-pointer entry points
     PinnedStage pinned;  // small-transfer staging
     u32 few_epoch = 0;   // launch counter of the latency path (its completion flag carries the epoch)
@@ -220,16 +223,20 @@ int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_
 // stable radix sort of 64-bit words by their bits [first_bit, 64) (first_bit a multiple of 8); words that agree on
 // those bits keep their input order.  sort_failure_flag: device word of the temporary storage that the sort sets if its
 // look-back ever gave up (it never should); read it after synchronising the stream.
+constexpr int SORT_TILE_WORDS = 4096;  // words per tile of the radix sort's passes
 // payload (optional): what the index build hangs on the sort's first pass.
 struct SortPayload {
     const float* xyz = nullptr;           // n x 3 in the words' input order: with `rec` and `idx_bits`, the first pass moves {x, y, z, index}
     float4* rec = nullptr;                //   of every element to its word's position after that pass and writes that position into the
     int idx_bits = 0;                     //   word's low idx_bits (which held the element's index)
-    const u32* top_hist_ready = nullptr;  // 256 counts of the words' top digit (bits [56, 64)), if the caller has them already
+    u32* tile_hist_ready = nullptr;       // counts of the words' top digit (bits [56, 64)) per tile of SORT_TILE_WORDS consecutive words,
+                                          //   [tile][256], if the caller has them already (scanned in place by the sort)
+    u32* failed_flag = nullptr;           // device word (zeroed by the caller) to set if the look-back ever gives up; default: inside tmp
 };
 int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit = 0,
                   const SortPayload* payload = nullptr);
 const u32* sort_failure_flag(void* tmp);
+u32* sort_tile_hist_buffer(void* tmp, u64 n);
 int ensure_scratch(Index& ix, size_t bytes);
 
 // orient.hip: propagate_normal_orientations on the device (rows, counts, coordinates, normals are device arrays)
@@ -263,6 +270,7 @@ int launch_wlop_density(Index& ix, float h, const void* d_records, float* d_out)
 int launch_wlop_median(Index& cloud, const QueryView& samples, float h, const void* d_records_vj, float* d_median);
 int launch_wlop_repulsion(Index& samples, float h, float mu, const void* d_records_wi, const float* d_median, float* d_out);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
+int launch_invert_perm(const u32* d_perm, u64 n, u32* d_position_of, hipStream_t s);
 int prepare_queue(Index& ix);  // zeroes the work-queue counters of the persistent kernels (stream-ordered)
 
 }  // namespace pcpx

@@ -25,7 +25,6 @@ namespace pcpx {
 namespace {
 
 constexpr u32 NO_LEVEL = 0xFFFFFFFFu;
-constexpr u64 NO_CLAIM = ~0ull;
 constexpr int OB = 256;           // threads per block
 constexpr int SCAN_ITEMS = 8;     // per thread in the block scan
 constexpr int SCAN_TILE = OB * SCAN_ITEMS;

@@ -1,4 +1,4 @@
-// pcpx_prep.hip -- arbitrary query batches: Morton-sort the queries on the index's grid and seed every group of 64.
+// pcpx_prep.hip -- arbitrary query batches: sort the queries along the index's curve and seed every group of 64.
 #include "pcpx_curve.h"
 #include "pcpx_device.h"
 
@@ -9,17 +9,21 @@ namespace pcpx {
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// arbitrary query batches: Morton-sort the queries on the index's grid, seed each group at the
+// arbitrary query batches: sort the queries along the index's curve (same grid, same key), seed each group at the
 // 64-point chunk where its first query would sit in the sorted cloud
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_query_codes(const float* __restrict__ q, u32 nq, const float* __restrict__ box6, int idx_bits,
-                                                     u64* __restrict__ codes)
+constexpr int QCODES_BLOCK = 1024;
+__global__ __launch_bounds__(QCODES_BLOCK) void k_query_codes(const float* __restrict__ q, u32 nq, const float* __restrict__ box6, int idx_bits,
+                                                               u64* __restrict__ codes)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    float x = q[3ull * i], y = q[3ull * i + 1], z = q[3ull * i + 2];
-    // (a query outside the box is clamped onto it: the key only decides where the query sits in the batch)
-    codes[i] = sort_word(curve_key(x, y, z, box6[0], box6[1], box6[2], box6[3], box6[4], box6[5]), i, idx_bits);
+    __shared__ u32 htab[HILBERT_TABLE_WORDS];
+    hilbert_table_to_lds(htab);
+    const CurveGrid grid = curve_grid(box6[0], box6[1], box6[2], box6[3], box6[4], box6[5]);
+    for (u32 i = blockIdx.x * QCODES_BLOCK + threadIdx.x; i < nq; i += gridDim.x * QCODES_BLOCK) {
+        const float x = q[3ull * i], y = q[3ull * i + 1], z = q[3ull * i + 2];
+        // (a query outside the box is clamped onto it: the key only decides where the query sits in the batch)
+        codes[i] = sort_word(curve_key(x, y, z, grid, htab), i, idx_bits);
+    }
 }
 
 // sorted words -> the queries in curve order (SoA) and their output rows
@@ -58,7 +62,21 @@ __global__ __launch_bounds__(256) void k_query_seeds(const u64* __restrict__ qco
     seed[g] = s0;
 }
 
+// position_of[perm[p]] = p: where every inserted point sits in the curve order
+__global__ __launch_bounds__(256) void k_invert_perm(const u32* __restrict__ perm, u32 n, u32* __restrict__ position_of)
+{
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) position_of[perm[p]] = p;
+}
+
 }  // namespace
+
+int launch_invert_perm(const u32* d_perm, u64 n, u32* d_position_of, hipStream_t s)
+{
+    if (n == 0) return PCPX_OK;
+    k_invert_perm<<<static_cast<u32>((n + 255) / 256), 256, 0, s>>>(d_perm, static_cast<u32>(n), d_position_of);
+    return check_hip(hipGetLastError(), "k_invert_perm launch", __FILE__, __LINE__);
+}
 
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
 {
@@ -90,7 +108,8 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
         const float* d_box = reinterpret_cast<const float*>(ix.d_scalars + 8);
         const int qbits = index_bits_for(nq);
         const int cmp_shift = std::max(SORT_FIRST_BIT, std::max(qbits, ix.idx_bits));
-        k_query_codes<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, n32, d_box, qbits, codes0);
+        const u32 cblocks = (n32 + QCODES_BLOCK - 1) / QCODES_BLOCK;
+        k_query_codes<<<cblocks < 512u ? cblocks : 512u, QCODES_BLOCK, 0, s>>>(d_q, n32, d_box, qbits, codes0);
         if ((st = sort_keys_u64(base + o_tmp, tb, codes0, codes1, nq, s, SORT_FIRST_BIT)) != PCPX_OK) return st;
         k_query_gather<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, codes1, qbits, n32, qx, qy, qz, row);
         k_query_seeds<<<static_cast<u32>((ngroups + 255) / 256), 256, 0, s>>>(

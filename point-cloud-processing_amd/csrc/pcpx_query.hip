@@ -1,28 +1,33 @@
-// pcpx_query.hip -- batched kNN / radius search / PCA-normal kernels for gfx950 (wave64).
+// pcpx_query.hip -- the throughput kNN kernel (k nearest neighbours of query batches, fused PCA normal / tangent-plane
+// centroid / mean neighbour distance) for gfx950 (wave64).  The latency form for a handful of queries is pcpx_few.hip.
 //
 // Execution model (DESIGN.md "Kernels"):
-//   * ONE WAVEFRONT = 64 Morton-consecutive queries, one query per lane.
-//   * Tree traversal is WAVE-UNIFORM: the pending-children bit stack (popped with one find-first-set) and
-//     all control flow live in SGPRs; the 4 child boxes of a node (one 128-B record) and whole leaf records
-//     (128 B) are fetched with scalar (SMEM) loads and broadcast to the 64 lanes as SGPR operands of the
-//     per-lane VALU distance code.  A subtree is entered when ANY lane still needs it (ballot), so the
-//     wave walks the union of its lanes' search regions -- small, because the lanes are neighbours on the
-//     Morton curve.
-//   * kNN selection: per lane a SORTED best-list of KCAP 64-bit keys (d2 bits << 32 | sorted position)
-//     in VGPRs plus an UNSORTED append buffer in LDS (one column per lane, conflict free).  Accepting a
-//     candidate is hand-written: two v_cmpx narrow EXEC to the lanes with d2 <= tau outside the eps-box,
-//     the LDS write and the address bump run under it.  When a column is nearly full the wave sorts the
-//     new keys in registers (bitonic network whose compare-exchange is v_min_f64 / v_max_f64: every key
-//     is the bit pattern of a finite non-negative double) and merges them with the best-list, which
-//     tightens tau = d2 of the k-th best.
-//   * Walk rounds: the first walk searches no farther than 1.375 x the wave's median seeded tau; a lane
-//     whose k-th distance ends up beyond that cap goes round again with a 4x larger one (shell accept).
-//   * Persistent waves pull query groups from 8 work queues (one per XCD-sized eighth of the Morton order).
-//   * The search is seeded with the 64 points of the query group itself (for arbitrary queries: the
-//     64-point chunk at the group's Morton position), so tau is tight before the traversal starts.
-//   * Keys carry the SORTED position, so neighbour ids and coordinates are gathered from the leaf
-//     records (spatially coherent, L1/L2 resident); the final rows are re-ordered by (d2, original index).
+//   * ONE WAVEFRONT = 64 queries that are consecutive on the index's Hilbert curve (pcpx_curve.h), one query per lane.
+//   * Tree traversal is WAVE-UNIFORM: the pending-children bit stack (popped with one find-first-set) and all control
+//     flow live in SGPRs; the 4 child boxes of a node (one 128-B record) and whole leaf records (128 B) are fetched with
+//     scalar (SMEM) loads and broadcast to the 64 lanes as SGPR operands of the per-lane VALU distance code.  A subtree is
+//     entered when ANY lane still needs it (ballot), so the wave walks the union of its lanes' search regions -- small,
+//     because the lanes are neighbours on the curve.
+//   * kNN selection: per lane a SORTED best-list of KCAP (8 / 16 / 32) 64-bit keys (d2 bits << 32 | sorted position) in
+//     VGPRs plus an UNSORTED append buffer in LDS (one column per lane, conflict free).  Accepting a candidate is
+//     hand-written: two v_cmpx narrow EXEC to the lanes with d2 <= tau outside the eps-box, the LDS write and the
+//     address bump run under it.  When a column is nearly full the wave sorts the new keys in registers, 8 at a time
+//     (bitonic network whose compare-exchange is v_min_f64 / v_max_f64: every key is the bit pattern of a finite
+//     non-negative double) and merges them with the best-list, which tightens tau = d2 of the k-th best.
+//   * Seeding: the 64 points at the group's own curve position (for arbitrary queries: the 64-point chunk where the
+//     group's middle query would sit) and a few leaves either side (per KCAP) are processed before the walk, so tau is
+//     tight when the traversal starts.
+//   * Walk rounds: the first walk searches no farther than cap_mult<KCAP>() (1.125 ... 1.375) x the wave's median
+//     seeded tau; a lane whose k-th distance ends up beyond that cap goes round again with a 4x larger one, accepting
+//     only the new shell.  The cap steers work, never results.
+//   * Persistent waves pull query groups from 8 work queues (one per XCD-sized eighth of the curve order).
+//   * Keys carry the SORTED position, so neighbour ids and coordinates are gathered from the leaf records (spatially
+//     coherent, L1/L2 resident); the final rows are re-ordered by (d2, original index).  After the search the row's
+//     positions wait in the (then idle) LDS column, not in registers: no kernel of the single-pass family uses scratch.
 //   * PCA normals are fused into the same kernel: no neighbour list round trip through HBM.
+//   * Rows go to the query's input index, or (KnnOutputs::by_position, self queries) to its curve position: slices of
+//     the curve order are then contiguous in every output array (pcpx_normals_knn_self_curve_order).
+// The measurements behind every tuning constant below are in profiles/experiments/README.md.
 //
 // Arithmetic follows the reference exactly: d = p - q, dx*dx + dy*dy + dz*dz in float32 without
 // FMA contraction (include/pcp/common/norm.hpp:102-112), eps-box exclusion
@@ -92,59 +97,34 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
     }
 }
 
-// key/payload variant for the (rare) final tie repair
-__device__ __forceinline__ void ce_payload(u64& ka, u64& kb, u32& pa, u32& pb)
-{
-    bool sw = ka > kb;
-    u64 t0 = sw ? kb : ka, t1 = sw ? ka : kb;
-    u32 q0 = sw ? pb : pa, q1 = sw ? pa : pb;
-    ka = t0; kb = t1; pa = q0; pb = q1;
-}
-template <int N>
-__device__ __forceinline__ void bitonic_sort_payload(u64 (&a)[N], u32 (&p)[N])
-{
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                int l = i ^ j;
-                if (l > i) {
-                    if ((i & k) == 0) ce_payload(a[i], a[l], p[i], p[l]);
-                    else ce_payload(a[l], a[i], p[l], p[i]);
-                }
-            }
-        }
-    }
-}
-
 // Rows of the per-lane append buffer.  A leaf may append LEAF keys, so a compaction runs whenever a
 // lane holds more than BUF - LEAF keys; fewer rows = less LDS per wave = more resident waves.
 #ifndef PCPX_BUF16
-#define PCPX_BUF16 10  // 10 rows x 512 B = 5 KB per wave = 7 waves/SIMD.  Measured on MI355X (10 M uniform / clustered, k=15, chunk-of-8 compaction, no trash row): 6 waves/SIMD 12 rows 1268 / 1135, 7 waves 11 rows 1263 / 1130, 7 waves 10 rows 1281 / 1150, 7 waves 9 rows 1236 / 1110
+#define PCPX_BUF16 10  // 10 rows x 512 B = 5 KB per wave = 7 waves/SIMD
 #endif
 #ifndef PCPX_BUF32
-#define PCPX_BUF32 14  // with the chunk-of-8 compaction (50 M points, k = 32, rebuild in the step, Mq/s): 16 rows 1036, 14 rows 1049, 12 rows 1037
+#define PCPX_BUF32 14  // (+ 2 rows of LDS that only the epilogue uses: lds_rows)
 #endif
 #ifndef PCPX_COMPACT_BY8
-#define PCPX_COMPACT_BY8 1     // k <= 16 kernel: compaction in chunks of 8 keys (80 VGPRs, 6 waves/SIMD): 1171 -> 1250 Mq/s
+#define PCPX_COMPACT_BY8 1     // compaction in chunks of 8 keys
 #endif
-// (the multi-pass kernels -- k > 32 -- keep the 16-key compaction and the C++ accept path with its trash row.  The single-pass
-//  k <= 32 kernel used to as well: the chunked form measured worse in round 1 (720 vs 735 Mq/s, 308 B of scratch); since the
-//  persistent loop's invariants no longer pin registers it is the better one: PCPX_BY8_K32.)
+// (the multi-pass kernels -- k > 32 -- keep the 16-key compaction and the C++ accept path with its trash row)
 #ifndef PCPX_BUF8
-#define PCPX_BUF8 10   // k <= 8: 10 rows x 512 B = 5 KB per wave, 8 waves/SIMD (10 M uniform, k = 8, Mq/s, chunk-of-8 compaction: 7 waves 9 rows 1506, 7/10 1530, 8/9 1553, 8/10 1581; the k <= 16 kernel of the time did 1337)
+#define PCPX_BUF8 10   // k <= 8: 10 rows x 512 B = 5 KB per wave, 8 waves/SIMD
 #endif
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
 #endif
 #ifndef PCPX_BY8_K32
-#define PCPX_BY8_K32 1  // the chunk-of-8 compaction (with its PAD invariant established) for the single-pass k <= 32 kernel too: 50 M points, k = 32: 994 -> 1041 Mq/s, scratch 40 -> 32 B/lane
+#define PCPX_BY8_K32 1  // the chunk-of-8 compaction (with its PAD invariant established) for the single-pass k <= 32 kernel too
 #endif
 // rows of LDS per wave: the C++ accept path (multi-pass kernels only) stores rejected keys to a trash row, row BUF;
 // the exec-masked path stores nothing for a rejected candidate
-__host__ __device__ constexpr int lds_rows(int buf, bool multi) { return buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0); }
+// (single-pass kernels: at least kcap / 2 rows -- after the search the column holds the row's kcap sorted positions, two per row)
+__host__ __device__ constexpr int lds_rows(int buf, bool multi, int kcap = 0)
+{
+    return (buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0)) > kcap / 2 ? (buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0)) : kcap / 2;
+}
 __host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 8 ? PCPX_BUF8 : kcap <= 16 ? PCPX_BUF16 : PCPX_BUF32; }
 
 // Fold this lane's buffered keys (cnt <= BUF <= 16) into its sorted best-list.  All LDS traffic is
@@ -299,16 +279,11 @@ __device__ __forceinline__ void append_if_shell(float d2, float tau, float lo, f
 #define PCPX_MINW32 4  // k <= 32 kernel: <= 128 VGPRs = 4 waves/SIMD
 #endif
 #ifndef PCPX_MINW
-#define PCPX_MINW 7  // k <= 16 kernel: <= 72 VGPRs = 7 waves/SIMD, possible since the compaction works in chunks of 8 keys (with the 16-key
-                     // compaction even 80 VGPRs meant 140 B/lane of scratch and -8 %)
+#define PCPX_MINW 7  // k <= 16 kernel: <= 72 VGPRs = 7 waves/SIMD
 #endif
 // PCPX_CAP_MULT x the median of the finite seeded taus of a sample of the wave's valid lanes (every fourth lane:
 // 16 readlanes; inf if no lane has a finite tau): rank every sampled value by counting, pick the middle one.
 // The cap only steers the work, never the result (a lane that fails the cap goes round again).
-// measured, 10 M points, Hilbert order, Mq/s uniform / clustered at k = 15 with 2 extra seed leaves: 1.25: 1873 / 1610, 1.375: 1865 / 1579,
-// 1.5: 1855 / 1578, 1.75: 1841 / 1588, 2: 1834 / 1587 (round 1, Z-order: 1: 1131 / 960, 1.25: 1175 / 1035, 1.375: 1168 / 1053, 1.5: 1164 / 1057);
-// per kernel with its own seed range (1.125 / 1.25 / 1.375 / 1.5): k = 8: 2340 / 2420 / 2454 / 2449, k = 15: 1935 / 1925 / 1924 / 1918,
-// k = 32: 1081 / 1073 / 1064 / 1062
 #ifdef PCPX_CAP_MULT
 template <int KCAP>
 constexpr float cap_mult() { return PCPX_CAP_MULT; }
@@ -358,7 +333,7 @@ struct MultiPass {
     u32 slot0 = 0;            // query slot of the first group of the launch
 };
 
-// One query group (64 Morton-consecutive queries, one per lane) from start to finish.
+// One query group (64 curve-consecutive queries, one per lane) from start to finish.
 template <int KCAP, bool SELF, bool STATS, bool MULTI>
 __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k_arg, const float eps,
                                           const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
@@ -427,16 +402,14 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
 
-    // ---- seed range: the 64-point chunk at the group's own Morton position ----
+    // ---- seed range: the 64-point chunk at the group's own curve position ----
     u32 s0, s1;
     if (SELF) s0 = g * LEAVES_PER_GROUP;
     else s0 = qv.seed[g];
     s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
     if (s0 > s1) s0 = s1;
     // leaves before and after the group's own chunk that are also processed before the walk: they are curve neighbours the walk
-    // would visit anyway, and seeing them first tightens tau sooner.  How many pays depends on k (10 M uniform points, Hilbert
-    // order, Mq/s with 0 / 1 / 2 / 3 / 4 extra leaves on either side): k = 8: 2414 / 2381 / 2349 / 2310 / 2274;
-    // k = 15: 1859 / 1900 / 1922 / 1921 / 1916; k = 32 (rebuild in the step): 1002 / 1033 / 1053 / 1063 / 1068
+    // would visit anyway, and seeing them first tightens tau sooner.  How many pays depends on k.
 #ifdef PCPX_SEED_EXTRA
     constexpr u32 seed_extra = PCPX_SEED_EXTRA;
 #else
@@ -454,7 +427,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     wk.ploc = 0;
     wk.l = 0;
     // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = cap_mult (1.125 ... 1.375) x the
-    // wave's median seeded tau: a lane whose 64-point seed chunk lies across a Morton-curve jump starts with a
+    // wave's median seeded tau: a lane whose 64-point seed chunk lies across a jump of the curve (rare on the Hilbert curve, the rule on a Z-order) starts with a
     // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
     // 7 ms groups against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all
     // its k nearest are within cap, and everything within cap has been visited).  Lanes that fail -- points in
@@ -639,29 +612,66 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         return;
     }
     // ---- sorted position -> original index; order rows by (d2, index) ----
-    u32 pos[KCAP];
+    // The append buffer is idle from here on: the row's sorted positions (which the fused normal gathers coordinates by) wait
+    // in the lane's LDS column, two per row, instead of in KCAP registers beside the KCAP keys -- that pair of arrays was what
+    // spilled (8 B/lane of scratch at k <= 16, 32 B at k <= 32).
+    u32* const pos_col = reinterpret_cast<u32*>(col);
+    auto pos_slot = [&](int s) -> u32& { return pos_col[(s >> 1) * 128 + (s & 1)]; };
 #pragma unroll
     for (int s = 0; s < KCAP; ++s) {
         u64 key = best[s];
         bool real = s >= first_slot && key != PAD_KEY;
         u32 ps = real ? static_cast<u32>(key) : 0u;
-        pos[s] = ps;
+        pos_slot(s) = ps;
         u32 id = t.leaves[ps / LEAF].id[ps % LEAF];
         asm volatile("" : "+v"(id));  // keep the load unconditional: sunk under `real` it becomes a branch per key, and the
                                       // values live across those branches were what spilled to scratch
         best[s] = real ? ((key & 0xFFFFFFFF00000000ull) | id) : key;
     }
+    // Keys were ascending in (d2, position); with the index in the low word only runs of EXACTLY equal d2 can be out of order.
+    // Rare: repaired by adjacent exchanges (odd-even transposition, at most KCAP rounds; a run of t ties needs t), the positions
+    // exchanged in LDS alongside.
     bool unordered = false;
 #pragma unroll
     for (int s = 0; s + 1 < KCAP; ++s) unordered |= best[s] > best[s + 1];
-    if (any_lane(unordered)) bitonic_sort_payload<KCAP>(best, pos);  // exact-tie repair, rare
+    for (int round = 0; round < KCAP && any_lane(unordered); ++round) {
+#pragma unroll
+        for (int parity = 0; parity < 2; ++parity) {
+#pragma unroll
+            for (int s = parity; s + 1 < KCAP; s += 2) {
+                const bool sw = best[s] > best[s + 1];
+                const u64 a = sw ? best[s + 1] : best[s], b = sw ? best[s] : best[s + 1];
+                best[s] = a;
+                best[s + 1] = b;
+                if (sw) {
+                    const u32 pa = pos_slot(s), pb = pos_slot(s + 1);
+                    pos_slot(s) = pb;
+                    pos_slot(s + 1) = pa;
+                }
+            }
+        }
+        unordered = false;
+#pragma unroll
+        for (int s = 0; s + 1 < KCAP; ++s) unordered |= best[s] > best[s + 1];
+    }
+    // (the column goes back to the chunked compaction's invariant -- empty slots hold PAD_KEY -- at the end of this function)
+    auto restore_column = [&]() {
+        if (PCPX_COMPACT_BY8 && (KCAP <= 16 || PCPX_BY8_K32)) {
+#pragma unroll
+            for (int r = 0; r < (KCAP + 1) / 2; ++r) col[r * 64] = PAD_KEY;
+        }
+    };
 
-    if (!valid) return;
+    if (!valid) {
+        restore_column();
+        return;
+    }
     // output row = original index of the query (read here, not at the start: one VGPR less through the search loop)
     // (the query's position is formed again rather than kept: as a 64-bit record offset it sat in a VGPR pair all through the search)
     u32 p_row = g * GROUP + lane;
     asm volatile("" : "+v"(p_row));
-    const u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : qv.row[p_row];
+    u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : qv.row[p_row];
+    if (SELF && o.by_position) row = p_row;
     u32 found = 0;
     u32 okmask = 0;
     const u64 ob = static_cast<u64>(row) * k;
@@ -699,8 +709,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) {
             bool ok = (okmask >> s) & 1u;
-            const Leaf& lf = t.leaves[pos[s] / LEAF];
-            float x = lf.x[pos[s] % LEAF], y = lf.y[pos[s] % LEAF], z = lf.z[pos[s] % LEAF];
+            const u32 ps = pos_slot(s);
+            const Leaf& lf = t.leaves[ps / LEAF];
+            float x = lf.x[ps % LEAF], y = lf.y[ps % LEAF], z = lf.z[ps % LEAF];
             sx += ok ? x : 0.f;
             sy += ok ? y : 0.f;
             sz += ok ? z : 0.f;
@@ -712,13 +723,17 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             o.centroids[3ull * row + 1] = my;
             o.centroids[3ull * row + 2] = mz;
         }
-        if (!o.normals) return;
+        if (!o.normals) {
+            restore_column();
+            return;
+        }
         float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) {
             bool ok = (okmask >> s) & 1u;
-            const Leaf& lf = t.leaves[pos[s] / LEAF];
-            float x = lf.x[pos[s] % LEAF], y = lf.y[pos[s] % LEAF], z = lf.z[pos[s] % LEAF];
+            const u32 ps = pos_slot(s);
+            const Leaf& lf = t.leaves[ps / LEAF];
+            float x = lf.x[ps % LEAF], y = lf.y[ps % LEAF], z = lf.z[ps % LEAF];
             float vx = ok ? x - mx : 0.f, vy = ok ? y - my : 0.f, vz = ok ? z - mz : 0.f;
             c00 += vx * vx;
             c10 += vy * vx;
@@ -733,12 +748,13 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         o.normals[3ull * row + 1] = nrm[1];
         o.normals[3ull * row + 2] = nrm[2];
     }
+    restore_column();
 }
 
 // Persistent launch: the grid is exactly the number of waves the GPU can hold, and every wave pulls query
 // groups from work queues until they are empty (group run times differ by 2-3x, so a static assignment
 // would leave a long tail, and 156 k single-wave workgroups per 10 M queries need not go through the
-// dispatcher).  There is one queue per XCD-sized eighth of the Morton order (blocks b and b+8 share an XCD,
+// dispatcher).  There is one queue per XCD-sized eighth of the curve order (blocks b and b+8 share an XCD,
 // so its L2 keeps serving one region); a wave drains its home queue first, then helps the others.  Counters
 // sit on separate 64-B lines and are zeroed before each launch.  Measured equal to one group per workgroup
 // on MI355X (19.0 vs 19.1 ms); note rocprofv3's MeanOccupancyPerCU reads 11.5 of 20 for both, i.e. it
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     extern __shared__ u64 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = wave_in_block();
-    u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI) * 64 + lane;
+    u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI, MULTI ? 0 : KCAP) * 64 + lane;
     if (PCPX_COMPACT_BY8 && !MULTI && (KCAP <= 16 || PCPX_BY8_K32)) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
 #pragma unroll
         for (int j = 0; j < BUF; ++j) col[j * 64] = PAD_KEY;
@@ -831,7 +847,7 @@ template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, const KnnOutputs& o)
 {
     constexpr int BUF = buf_rows(KCAP);
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false) * 64 * sizeof(u64);
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
     u32 grid = grid_for_groups(gcount);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     int st = prepare_queue(ix);
@@ -857,7 +873,7 @@ __global__ __launch_bounds__(256) void k_assemble(TreeView t, QueryView qv, u32 
     const u32 p = slot0 + i;
     const u32 nq = SELF ? t.n : qv.nq;
     if (p >= nq) return;
-    const u32 row = SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
+    const u32 row = (SELF && o.by_position) ? p : SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
     u64* r = keys + static_cast<u64>(i) * stride;
     u32 found = 0;
     for (u32 j = 0; j < k; ++j) {
@@ -945,7 +961,7 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
             return PCPX_ERR_INVALID;
         }
         // rows are complete in HBM: PCA normal per row (row order: sorted slots -> rows)
-        const u32* rowmap = self ? ix.perm() : qv.row;
+        const u32* rowmap = (self && o.by_position) ? nullptr : self ? ix.perm() : qv.row;
         return launch_normals(ix, o.idx, o.cnt, rowmap, static_cast<u64>(gf) * GROUP,
                               (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP < nslots ? (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP : nslots,
                               k, o.normals, nullptr, o.centroids, o.meandist);
@@ -970,7 +986,7 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     constexpr int KCAP = 16, BUF = buf_rows(KCAP);
     u64 groups = (ix.n + GROUP - 1) / GROUP;
     if (groups == 0) return PCPX_OK;
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false) * 64 * sizeof(u64);
+    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;

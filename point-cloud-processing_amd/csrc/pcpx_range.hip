@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, Quer
     range_group<SELF, FILL>(t, qv, g, radius, radii, out_cnt, offsets, out_idx, lane);
 }
 
-// AABB ranges: one wave per 64 boxes, no Morton coherence assumed (boxes are few in practice:
+// AABB ranges: one wave per 64 boxes, no spatial coherence assumed (boxes are few in practice:
 // test/octree/octree_range_search.cpp:80-118).  contains() is inclusive
 // (axis_aligned_bounding_box.hpp:111-125); prune = box/box overlap (intersections.hpp:25-32).
 template <bool FILL>

@@ -4,17 +4,22 @@
 // the high bits, point index in the low bits (pcpx_curve.h) -- and an arbitrary query batch does the same.
 //
 // Shape (round 3): MOST significant digit first, then least-significant-digit passes INSIDE the 256 buckets.
-//   k_sort_top_hist     counts the top digit (bits [56, 64)) of every word           (the build's k_codes does it itself),
-//   k_sort_seg_setup    turns the counts into the bucket table: first position and first tile of every bucket,
-//   k_sort_pass<false>  the top-digit pass: a stable partition of the whole array into the 256 buckets ("onesweep":
-//                       ticketed tiles of 4096 words, per-wave digit ranks, decoupled look-back over the predecessors'
-//                       published counts).  For the index build it also moves a 16-byte record {x, y, z, id} per point
-//                       to the word's new position and writes that position into the word's low bits, so that
-//                       everything after this pass -- and the leaf gather at the end -- stays inside one bucket,
-//   k_sort_seg_hist     per bucket: the digit counts of every remaining pass (one sweep over the partitioned words),
-//   k_sort_seg_bases    per bucket and pass: exclusive scan of the counts = the digits' first output positions,
-//   k_sort_pass<true>   one per remaining digit, least significant first: the same kernel, but a tile never straddles
-//                       a bucket and the look-back ends at the bucket's first tile.
+//   k_sort_top_hist     counts the top digit (bits [56, 64)) of every TILE of 4096 words (the build's k_codes does it itself),
+//   k_sort_tile_sums /  per digit: exclusive scan of the tiles' counts (= where a tile's words of that digit start inside
+//   k_sort_tile_scan    the digit's bucket) and the digit's total,
+//   k_sort_seg_setup    turns the totals into the bucket table: first position and first tile of every bucket,
+//   k_sort_pass<false>  the top-digit pass: a stable partition of the whole array into the 256 buckets.  Its input order is
+//                       known before it starts, so the tiles' offsets come from the scan above and a tile depends on no
+//                       other tile (as one more look-back pass its chain ran over all ~2 400 tiles of 10 M words and a tile
+//                       lived 57 us, 40 of them waiting: profiles/r03_pmc_rebuild.json).  For the index build it also moves
+//                       a 16-byte record {x, y, z, id} per point to the word's new position and writes that position into
+//                       the word's low bits, so that everything after this pass -- and the leaf gather at the end -- stays
+//                       inside one bucket,
+//   k_sort_seg_hist     per bucket: the digit counts of every remaining pass (one sweep over the partitioned words); a
+//                       tile scans its bucket's 256 counts itself to find where its digits start,
+//   k_sort_pass<true>   one per remaining digit, least significant first ("onesweep": ticketed tiles, per-wave digit ranks,
+//                       decoupled look-back over the predecessors' published counts): a tile never straddles a bucket and
+//                       the look-back ends at the bucket's first tile.
 // Round 2 ran five least-significant-digit passes over the whole array; its profile (profiles/r02_pmc_rebuild.json)
 // showed 63 % of a wave's time waiting in a look-back chain over all ~1 000 resident tiles.  With the buckets a chain
 // is n / (256 x 4096) tiles long on average (10 at 10 M words), whatever is resident, and the bucket of a leaf is an
@@ -39,8 +44,12 @@ namespace {
 
 constexpr int SORT_BLOCK = 256;
 constexpr int SORT_WAVES = SORT_BLOCK / 64;
-constexpr int SORT_ITEMS = 16;                      // 64-word chunks per wave
+#ifndef PCPX_SORT_ITEMS
+#define PCPX_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = PCPX_SORT_ITEMS;         // 64-word chunks per wave
 constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // words per tile
+static_assert(SORT_TILE == SORT_TILE_WORDS, "pcpx_internal.h names the tile size for the callers that count the top digit themselves");
 constexpr int RADIX = 256;
 constexpr int MAX_PASSES = 8;
 constexpr int TOP_SHIFT = 56;
@@ -95,18 +104,110 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* wtot, u32& total
     return before + incl - v;
 }
 
-// counts of the top digit: hist[256] (zeroed by the caller), one LDS atomic per word, one global atomic per non-empty
-// digit and block
-__global__ __launch_bounds__(SORT_BLOCK) void k_sort_top_hist(const u64* __restrict__ keys, u64 n, u32* __restrict__ hist)
+// two scans at once (one pair of barriers)
+__device__ __forceinline__ void block_exclusive_scan2(u32 va, u32 vb, u32* wtot2, u32& ea, u32& eb)
+{
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 ia = va, ib = vb;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 ua = __shfl_up(ia, off), ub = __shfl_up(ib, off);
+        if (lane >= static_cast<u32>(off)) {
+            ia += ua;
+            ib += ub;
+        }
+    }
+    __syncthreads();
+    if (lane == 63) {
+        wtot2[w] = ia;
+        wtot2[SORT_WAVES + w] = ib;
+    }
+    __syncthreads();
+    u32 ba = 0, bb = 0;
+#pragma unroll
+    for (u32 i = 0; i < SORT_WAVES; ++i) {
+        ba += i < w ? wtot2[i] : 0u;
+        bb += i < w ? wtot2[SORT_WAVES + i] : 0u;
+    }
+    ea = ba + ia - va;
+    eb = bb + ib - vb;
+}
+
+// counts of the top digit per tile of SORT_TILE words: tile_hist[tile][256]
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_top_hist(const u64* __restrict__ keys, u64 n, u32 ntiles, u32* __restrict__ tile_hist)
 {
     __shared__ u32 h[RADIX];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const u64 stride = static_cast<u64>(gridDim.x) * SORT_BLOCK;
-    for (u64 i = blockIdx.x * static_cast<u64>(SORT_BLOCK) + threadIdx.x; i < n; i += stride) atomicAdd(&h[digit_of(keys[i], TOP_SHIFT)], 1u);
-    __syncthreads();
-    const u32 c = h[threadIdx.x];
-    if (c) atomicAdd(&hist[threadIdx.x], c);
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 lo = static_cast<u64>(tile) * SORT_TILE, hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+        u64 key[SORT_ITEMS];
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const u64 i = lo + static_cast<u64>(it) * SORT_BLOCK + threadIdx.x;
+            key[it] = keys[i < hi ? i : hi - 1u];
+        }
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it)
+            if (lo + static_cast<u64>(it) * SORT_BLOCK + threadIdx.x < hi) atomicAdd(&h[digit_of(key[it], TOP_SHIFT)], 1u);
+        __syncthreads();
+        tile_hist[static_cast<size_t>(tile) * RADIX + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// Exclusive scan of the tiles' counts per digit, in place, and the digits' totals -- two launches over chunks of consecutive
+// tiles, every access a 1-KB row (thread = digit): (1) the chunks' sums, (2) a chunk's base = the sums of the chunks before
+// it, then the running prefix through the chunk.  (One block per digit walking its column was 17 us at 10 M words and 84 us
+// at 50 M: 4-byte reads a kilobyte apart.)
+constexpr u32 SCAN_CHUNKS_MAX = 256;
+__global__ __launch_bounds__(RADIX) void k_sort_tile_sums(const u32* __restrict__ tile_hist, u32 ntiles, u32 per_chunk, u32* __restrict__ chunk_sum)
+{
+    const u32 d = threadIdx.x;
+    const u32 t0 = blockIdx.x * per_chunk, t1 = t0 + per_chunk < ntiles ? t0 + per_chunk : ntiles;
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    u32 t = t0;
+    for (; t + 4 <= t1; t += 4) {  // (independent accumulators: four rows in flight)
+        s0 += tile_hist[static_cast<size_t>(t) * RADIX + d];
+        s1 += tile_hist[static_cast<size_t>(t + 1) * RADIX + d];
+        s2 += tile_hist[static_cast<size_t>(t + 2) * RADIX + d];
+        s3 += tile_hist[static_cast<size_t>(t + 3) * RADIX + d];
+    }
+    for (; t < t1; ++t) s0 += tile_hist[static_cast<size_t>(t) * RADIX + d];
+    chunk_sum[blockIdx.x * RADIX + d] = s0 + s1 + s2 + s3;
+}
+__global__ __launch_bounds__(RADIX) void k_sort_tile_scan(u32* __restrict__ tile_hist, u32 ntiles, u32 per_chunk, const u32* __restrict__ chunk_sum,
+                                                          u32* __restrict__ hist)
+{
+    const u32 d = threadIdx.x;
+    u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    u32 c = 0;
+    for (; c + 4 <= blockIdx.x; c += 4) {
+        b0 += chunk_sum[c * RADIX + d];
+        b1 += chunk_sum[(c + 1) * RADIX + d];
+        b2 += chunk_sum[(c + 2) * RADIX + d];
+        b3 += chunk_sum[(c + 3) * RADIX + d];
+    }
+    for (; c < blockIdx.x; ++c) b0 += chunk_sum[c * RADIX + d];
+    u32 acc = b0 + b1 + b2 + b3;
+    const u32 t0 = blockIdx.x * per_chunk, t1 = t0 + per_chunk < ntiles ? t0 + per_chunk : ntiles;
+    u32 t = t0;
+    for (; t + 4 <= t1; t += 4) {
+        u32* row = tile_hist + static_cast<size_t>(t) * RADIX + d;
+        const u32 v0 = row[0], v1 = row[RADIX], v2 = row[2 * RADIX], v3 = row[3 * RADIX];
+        row[0] = acc;
+        row[RADIX] = acc + v0;
+        row[2 * RADIX] = acc + v0 + v1;
+        row[3 * RADIX] = acc + v0 + v1 + v2;
+        acc += v0 + v1 + v2 + v3;
+    }
+    for (; t < t1; ++t) {
+        u32* row = tile_hist + static_cast<size_t>(t) * RADIX + d;
+        const u32 v = row[0];
+        row[0] = acc;
+        acc += v;
+    }
+    if (blockIdx.x == gridDim.x - 1) hist[d] = acc;
 }
 
 // one block: counts -> bucket table
@@ -144,8 +245,8 @@ struct TilePlace {
 };
 
 template <bool SEG, bool PAYLOAD>
-__global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restrict__ kin, u64* __restrict__ kout, u32 n, int shift, int tag_pass,
-                                                          const u32* __restrict__ digit_base, int base_stride,
+__global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 ? 4 : 3) void k_sort_pass(const u64* __restrict__ kin, u64* __restrict__ kout, u32 n, u32 tiles_arg, int shift, int tag_pass,
+                                                          const u32* __restrict__ seg_hist, const u32* __restrict__ tile_prefix,
                                                           const SegTable* __restrict__ seg, u64* __restrict__ status,
                                                           u32* __restrict__ ticket, u32* __restrict__ failed, SortPayloadArgs pl)
 {
@@ -154,27 +255,37 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
     __shared__ u32 whist[SORT_WAVES][RADIX];  // ranking: words of each digit seen so far by the wave; then: position of the wave's
                                               // first word of the digit in the tile's digit-sorted order
     __shared__ u32 gdelta[RADIX];             // output position of the tile's digit-sorted word j of digit d = gdelta[d] + j
-    __shared__ u32 wtot[SORT_WAVES];
+    __shared__ u32 wtot[2 * SORT_WAVES];
     __shared__ u32 place_s[4];
     u64(*wmask)[RADIX] = reinterpret_cast<u64(*)[RADIX]>(stage);  // [SORT_WAVES][RADIX]: lanes of the wave that hold digit d
 
-    const u32 lane = threadIdx.x & 63u;
-    const u32 w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) place_s[0] = atomicAdd(&ticket[tag_pass], 1u);
+    // Persistent blocks: a block takes tiles by ticket until none are left; the ticket of its next tile is requested while
+    // it scatters the current one (the atomic's round trip, 2-3 us under load, was a sixth of a tile's life when the block
+    // waited for it with nothing else to do, profiles/r03_pmc_rebuild.json).
+    // (The top-digit pass, SEG = false, has no chain: one tile per block, taken by block index.)
+    const u32 ntiles = SEG ? seg->tile_first[RADIX] : tiles_arg;
+    if (threadIdx.x == 0) place_s[0] = SEG ? atomicAdd(&ticket[tag_pass], 1u) : blockIdx.x;
+    for (;;) {
+    // (the thread's index is made opaque per tile: otherwise every address formed from it is a loop invariant of the
+    //  persistent block, kept in registers across the ranking loop -- which then spills)
+    u32 tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const u32 lane = tid & 63u;
+    const u32 w = tid >> 6;
 #pragma unroll
     for (int i = 0; i < SORT_WAVES; ++i) {
-        whist[i][threadIdx.x] = 0;
-        wmask[i][threadIdx.x] = 0ull;
+        whist[i][tid] = 0;
+        wmask[i][tid] = 0ull;
     }
     __syncthreads();
     const u32 tile = place_s[0];
+    if (tile >= ntiles) break;
     TilePlace tp;
     if (SEG) {
-        if (tile >= seg->tile_first[RADIX]) return;  // (the grid is an upper bound of the tile count)
         // the bucket of the tile: the one non-empty bucket with tile_first[b] <= tile < tile_first[b + 1]
-        const u32 f0 = seg->tile_first[threadIdx.x], f1 = seg->tile_first[threadIdx.x + 1];
+        const u32 f0 = seg->tile_first[tid], f1 = seg->tile_first[tid + 1];
         if (f0 <= tile && tile < f1) {
-            place_s[1] = threadIdx.x;
+            place_s[1] = tid;
             place_s[2] = f0;
         }
         __syncthreads();
@@ -189,7 +300,6 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
         tp.lo = tile * SORT_TILE;  // (n < 2^32 - TILE: checked on the host)
         tp.hi = n - tp.lo < static_cast<u32>(SORT_TILE) ? n : tp.lo + SORT_TILE;
     }
-    const u32* dbase = digit_base + static_cast<size_t>(tp.bucket) * base_stride;
 
     // ---- load, rank ----
     const u32 base = tp.lo + w * (SORT_ITEMS * 64) + lane;
@@ -224,7 +334,7 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
     // ---- thread d: the tile's count of digit d, published; its position in the tile's digit order; the count in all
     //      earlier tiles of the chain by look-back ----
     {
-        const u32 d = threadIdx.x;
+        const u32 d = tid;
         u32 cw[SORT_WAVES];
         u32 local = 0;
 #pragma unroll
@@ -234,10 +344,20 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
         }
         const u64 tag = static_cast<u64>(tag_pass + 1) << 44;
         u64* mine = status + static_cast<u64>(tile) * RADIX + d;
-        const bool first = tile == tp.floor;
-        __hip_atomic_store(mine, tag | (first ? ST_PREFIX : ST_LOCAL) | local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u32 tile_total = 0;
-        const u32 tb = block_exclusive_scan(local, wtot, tile_total);  // first word of digit d in the tile's digit-sorted order
+        const bool first = !SEG || tile == tp.floor;  // (top-digit pass: the offset comes from the tile scan, nothing is published)
+        if (SEG) __hip_atomic_store(mine, tag | (first ? ST_PREFIX : ST_LOCAL) | local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // tb: first word of digit d in the tile's digit-sorted order; dbase: first output position of digit d in this pass --
+        // the bucket's first position plus the exclusive scan of the bucket's digit counts (scanned here, by every tile: 256
+        // L2-resident words, instead of a launch of its own between the count and the first pass)
+        u32 tb, dbase;
+        if (SEG) {
+            block_exclusive_scan2(local, seg_hist[static_cast<size_t>(tp.bucket) * ((MAX_PASSES - 1) * RADIX) + d], wtot, tb, dbase);
+            dbase += seg->start[tp.bucket];
+        } else {
+            u32 unused = 0;
+            tb = block_exclusive_scan(local, wtot, unused);
+            dbase = seg->start[d] + tile_prefix[static_cast<size_t>(tile) * RADIX + d];
+        }
         {
             u32 acc = tb;
 #pragma unroll
@@ -252,7 +372,7 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
             // together).  4 at first: in the steady state a predecessor with a running total is that close; a round that
             // used up all it had fetched goes LOOK wide, so a chain of tiles that published their own counts together
             // (the start of a pass) is walked at LOOK tiles per round trip.
-            constexpr int LOOK = PCPX_SORT_LOOK;
+            constexpr int LOOK = SEG ? 4 : PCPX_SORT_LOOK;  // (bucketed chains are short; the wide form costs 16 registers)
             u32 t = tile;  // next to inspect: t - 1
             bool done = false;
             u32 spins = 0;
@@ -288,9 +408,15 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
             }
             __hip_atomic_store(mine, tag | ST_PREFIX | (static_cast<u64>(before) + local), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        gdelta[d] = dbase[d] + before - tb;
+        gdelta[d] = dbase + before - tb;
     }
     __syncthreads();  // (also: every wave is past its ranking, the lane masks are dead: `stage` may be written)
+    // The next ticket is taken HERE: this tile has published everything its successors wait for, so the tile behind the
+    // ticket starts at most one scatter later -- taken any earlier (at the top, to have it ready) the ticket would be a
+    // promise that is kept only after this whole tile, and every tile behind it spins in its look-back until then (measured:
+    // the top-digit pass 173 -> 209 us).  Its round trip (2-3 us under load) still hides behind the scatter below.
+    u32 next_ticket = ~0u;
+    if (SEG && tid == 0) next_ticket = atomicAdd(&ticket[tag_pass], 1u);
 
     // ---- the tile goes out through LDS in digit order: consecutive lanes write consecutive addresses ----
 #pragma unroll
@@ -299,20 +425,44 @@ __global__ __launch_bounds__(SORT_BLOCK, 4) void k_sort_pass(const u64* __restri
     }
     __syncthreads();
     const u32 in_tile = tp.hi - tp.lo;
-    for (u32 j = threadIdx.x; j < in_tile; j += SORT_BLOCK) {
-        const u64 k = stage[j];
-        const u32 dst = gdelta[digit_of(k, shift)] + j;
-        if (PAYLOAD) {
-            // the element's index is in the word's low bits; its record moves with the word, and the word now names
-            // the record's position
-            const u64 e = k & pl.low_mask;
-            const float x = pl.xyz[3 * e], y = pl.xyz[3 * e + 1], z = pl.xyz[3 * e + 2];
-            pl.rec[dst] = make_float4(x, y, z, __uint_as_float(static_cast<u32>(e)));
-            kout[dst] = (k & ~pl.low_mask) | dst;
-        } else {
-            kout[dst] = k;
+    if (PAYLOAD) {
+        // the element's index is in the word's low bits; its record moves with the word, and the word now names the
+        // record's position.  Four words per trip, so that their coordinate gathers are in flight together.
+        constexpr int U = 4;
+        for (u32 j0 = tid; j0 < in_tile; j0 += U * SORT_BLOCK) {
+            u64 k[U], e[U];
+            u32 dst[U];
+            float x[U], y[U], z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32 j = j0 + u * SORT_BLOCK;
+                k[u] = stage[j < in_tile ? j : j0];
+                e[u] = k[u] & pl.low_mask;
+                dst[u] = gdelta[digit_of(k[u], shift)] + (j < in_tile ? j : j0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[u] = pl.xyz[3 * e[u]];
+                y[u] = pl.xyz[3 * e[u] + 1];
+                z[u] = pl.xyz[3 * e[u] + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u * SORT_BLOCK < in_tile) {
+                    pl.rec[dst[u]] = make_float4(x[u], y[u], z[u], __uint_as_float(static_cast<u32>(e[u])));
+                    kout[dst[u]] = (k[u] & ~pl.low_mask) | dst[u];
+                }
+            }
+        }
+    } else {
+        for (u32 j = tid; j < in_tile; j += SORT_BLOCK) {
+            const u64 k = stage[j];
+            kout[gdelta[digit_of(k, shift)] + j] = k;
         }
     }
+    __syncthreads();  // (everyone is done with `stage`, `whist`, `gdelta` and place_s of this tile)
+    if (tid == 0) place_s[0] = next_ticket;
+    }  // next tile
 }
 
 // Per bucket: digit counts of the bucketed passes, hist[bucket][pass][256] (zeroed by the caller).  A block takes
@@ -353,31 +503,23 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restr
         const u32 s1 = seg->start[bucket + 1];
         const u32 lo = seg->start[bucket] + (tile - bfirst) * SORT_TILE;
         const u32 hi = s1 - lo < static_cast<u32>(SORT_TILE) ? s1 : lo + SORT_TILE;
-        for (u32 i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) {
-            const u64 key = keys[i];
-            for (int p = 0; p < passes; ++p) atomicAdd(&h[p][digit_of(key, first_bit + 8 * p)], 1u);
+        u64 key[SORT_ITEMS];  // (all loads of the tile in flight before the first count)
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const u32 i = lo + it * SORT_BLOCK + threadIdx.x;
+            key[it] = keys[i < hi ? i : hi - 1u];
+        }
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            if (lo + it * SORT_BLOCK + threadIdx.x < hi)
+                for (int p = 0; p < passes; ++p) atomicAdd(&h[p][digit_of(key[it], first_bit + 8 * p)], 1u);
         }
     }
     flush();
 }
 
-// block = bucket: exclusive scan of every pass's counts, offset by the bucket's first position
-__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_bases(const u32* __restrict__ hist, const SegTable* __restrict__ seg, int passes,
-                                                               u32* __restrict__ bases)
-{
-    __shared__ u32 wtot[SORT_WAVES];
-    const u32 b = blockIdx.x;
-    const u32 s0 = seg->start[b];
-    if (seg->start[b + 1] == s0) return;
-    for (int p = 0; p < passes; ++p) {
-        const size_t at = (static_cast<size_t>(b) * (MAX_PASSES - 1) + p) * RADIX + threadIdx.x;
-        u32 total = 0;
-        bases[at] = s0 + block_exclusive_scan(hist[at], wtot, total);
-    }
-}
-
 struct TmpLayout {
-    size_t o_top, o_ctl, o_seg, o_seghist, o_segbase, o_status, o_k, total;
+    size_t o_top, o_ctl, o_seg, o_seghist, o_status, o_tilehist, o_chunks, o_k, total;
     u64 ntiles_max;
 };
 TmpLayout tmp_layout(u64 n)
@@ -389,17 +531,18 @@ TmpLayout tmp_layout(u64 n)
     t.o_ctl = t.o_top + al(RADIX * sizeof(u32));
     t.o_seg = t.o_ctl + al(64 * sizeof(u32));
     t.o_seghist = t.o_seg + al(sizeof(SegTable));
-    t.o_segbase = t.o_seghist + al(static_cast<size_t>(RADIX) * (MAX_PASSES - 1) * RADIX * sizeof(u32));
-    t.o_status = t.o_segbase + al(static_cast<size_t>(RADIX) * (MAX_PASSES - 1) * RADIX * sizeof(u32));
-    t.o_k = t.o_status + al(t.ntiles_max * RADIX * sizeof(u64));
+    t.o_status = t.o_seghist + al(static_cast<size_t>(RADIX) * (MAX_PASSES - 1) * RADIX * sizeof(u32));
+    t.o_tilehist = t.o_status + al(t.ntiles_max * RADIX * sizeof(u64));
+    t.o_chunks = t.o_tilehist + al(t.ntiles_max * RADIX * sizeof(u32));
+    t.o_k = t.o_chunks + al(static_cast<size_t>(SCAN_CHUNKS_MAX) * RADIX * sizeof(u32));
     t.total = t.o_k + al(n * sizeof(u64));
     return t;
 }
 
 }  // namespace
 
-// Temporary storage: top-digit counts + tickets + failure flag + bucket table + per-bucket counts and bases + tile
-// status + one key buffer.  Result in kout.  Call with tmp == nullptr to get tmp_bytes.  kin is not modified.
+// Temporary storage: top-digit counts + tickets + failure flag + bucket table + per-bucket counts + tile status + one key
+// buffer.  Result in kout.  Call with tmp == nullptr to get tmp_bytes.  kin is not modified.
 // payload (the index build): see SortPayload in pcpx_internal.h.
 int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit, const SortPayload* payload)
 {
@@ -422,7 +565,6 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     u32* ctl = reinterpret_cast<u32*>(base + L.o_ctl);  // [0, 8) tickets, [8] failure flag
     SegTable* seg = reinterpret_cast<SegTable*>(base + L.o_seg);
     u32* seg_hist = reinterpret_cast<u32*>(base + L.o_seghist);
-    u32* seg_base = reinterpret_cast<u32*>(base + L.o_segbase);
     u64* status = reinterpret_cast<u64*>(base + L.o_status);
     u64* kt = reinterpret_cast<u64*>(base + L.o_k);
     const int passes = (64 - first_bit) / 8;  // the top-digit pass + (passes - 1) bucketed ones
@@ -430,46 +572,73 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     const u32 n32 = static_cast<u32>(n);
     const u64 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
 
-    // counts, tickets, flag, tables and the status array: cleared once per sort
-    const bool have_top = payload && payload->top_hist_ready;
-    if (have_top) {
-        PCPX_HIP(hipMemcpyAsync(top_hist, payload->top_hist_ready, RADIX * sizeof(u32), hipMemcpyDeviceToDevice, s));
-        PCPX_HIP(hipMemsetAsync(base + L.o_ctl, 0, L.o_k - L.o_ctl, s));
+    // tickets, flag, tables, the per-bucket counts and the status array: cleared once per sort
+    PCPX_HIP(hipMemsetAsync(base + L.o_ctl, 0, L.o_tilehist - L.o_ctl, s));
+    u32* tile_hist = reinterpret_cast<u32*>(base + L.o_tilehist);
+    if (payload && payload->tile_hist_ready) {
+        tile_hist = payload->tile_hist_ready;
     } else {
-        PCPX_HIP(hipMemsetAsync(base, 0, L.o_k, s));
         const u32 hblocks = static_cast<u32>(ntiles < 2048 ? ntiles : 2048);
-        k_sort_top_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kin, n, top_hist);
+        k_sort_top_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kin, n, static_cast<u32>(ntiles), tile_hist);
     }
-    k_sort_seg_setup<<<1, SORT_BLOCK, 0, s>>>(top_hist, seg);
+    {
+        const u32 nt = static_cast<u32>(ntiles);
+        const u32 per_chunk = (nt + SCAN_CHUNKS_MAX - 1) / SCAN_CHUNKS_MAX;
+        const u32 chunks = (nt + per_chunk - 1) / per_chunk;
+        u32* chunk_sum = reinterpret_cast<u32*>(base + L.o_chunks);
+        k_sort_tile_sums<<<chunks, RADIX, 0, s>>>(tile_hist, nt, per_chunk, chunk_sum);
+        k_sort_tile_scan<<<chunks, RADIX, 0, s>>>(tile_hist, nt, per_chunk, chunk_sum, top_hist);
+    }
+    const u32* top = top_hist;
+    u32* failed = payload && payload->failed_flag ? payload->failed_flag : ctl + 8;
+    k_sort_seg_setup<<<1, SORT_BLOCK, 0, s>>>(top, seg);
 
+    // persistent grids: as many blocks as are resident at once (4 per CU: LDS and registers), never more than tiles
+    static int cus_of_device[64] = {};
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64) cus = cus_of_device[dev];
+    if (cus <= 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        (void)hipGetLastError();
+        if (dev >= 0 && dev < 64) cus_of_device[dev] = cus;
+    }
+#ifndef PCPX_SORT_PERSISTENT
+#define PCPX_SORT_PERSISTENT 1  // 0: one block per tile (the dispatcher hands out blocks; every block still takes its tile by ticket)
+#endif
+    const u64 resident = PCPX_SORT_PERSISTENT ? static_cast<u64>(cus) * (SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 ? 4 : 3) : ~0ull;
+    const u32 grid_top = static_cast<u32>(ntiles);  // (one tile per block: no chain, nothing to keep resident)
+    const u32 grid_seg = static_cast<u32>(L.ntiles_max < resident ? L.ntiles_max : resident);
     // ping-pong between tmp and out so that the LAST pass writes out
     auto dst_of = [&](int j) { return ((passes - 1 - j) & 1) == 0 ? kout : kt; };
     SortPayloadArgs pl{nullptr, nullptr, 0};
     u64* kdst = dst_of(0);
     if (payload && payload->xyz) {
         pl.xyz = payload->xyz;
-        pl.rec = reinterpret_cast<float4*>(payload->rec);
+        pl.rec = payload->rec;
         pl.low_mask = (1ull << payload->idx_bits) - 1ull;
-        k_sort_pass<false, true><<<static_cast<u32>(ntiles), SORT_BLOCK, 0, s>>>(kin, kdst, n32, TOP_SHIFT, 0, seg->start, 0, seg, status, ctl, ctl + 8, pl);
+        k_sort_pass<false, true><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);
     } else {
-        k_sort_pass<false, false><<<static_cast<u32>(ntiles), SORT_BLOCK, 0, s>>>(kin, kdst, n32, TOP_SHIFT, 0, seg->start, 0, seg, status, ctl, ctl + 8, pl);
+        k_sort_pass<false, false><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);
     }
     if (low > 0) {
-        u32 tpb = static_cast<u32>(L.ntiles_max / 1024);
-        tpb = tpb < 4 ? 4 : tpb > 32 ? 32 : tpb;
+        u32 tpb = static_cast<u32>(L.ntiles_max / 2048);  // tiles per block: enough blocks to fill the chip, few flushes of the counts
+        tpb = tpb < 2 ? 2 : tpb > 32 ? 32 : tpb;
         const u32 hblocks = static_cast<u32>((L.ntiles_max + tpb - 1) / tpb);
         k_sort_seg_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kdst, seg, first_bit, low, tpb, seg_hist);
-        k_sort_seg_bases<<<RADIX, SORT_BLOCK, 0, s>>>(seg_hist, seg, low, seg_base);
         const u64* ksrc = kdst;
         for (int p = 0; p < low; ++p) {
             kdst = dst_of(p + 1);
-            k_sort_pass<true, false><<<static_cast<u32>(L.ntiles_max), SORT_BLOCK, 0, s>>>(ksrc, kdst, n32, first_bit + 8 * p, p + 1, seg_base + p * RADIX,
-                                                                                          (MAX_PASSES - 1) * RADIX, seg, status, ctl, ctl + 8, pl);
+            k_sort_pass<true, false><<<grid_seg, SORT_BLOCK, 0, s>>>(ksrc, kdst, n32, 0u, first_bit + 8 * p, p + 1, seg_hist + p * RADIX, nullptr, seg, status, ctl, failed, pl);
             ksrc = kdst;
         }
     }
     return check_hip(hipGetLastError(), "radix sort kernels", __FILE__, __LINE__);
 }
+
+// where a caller that counts the top digit per tile itself (SortPayload::tile_hist_ready) may put the counts: a region of the
+// sort's own temporary storage, [tile][256] for n words
+u32* sort_tile_hist_buffer(void* tmp, u64 n) { return reinterpret_cast<u32*>(static_cast<char*>(tmp) + tmp_layout(n).o_tilehist); }
 
 // the failure flag of the last sort that used this temporary storage (device word; read it after synchronising)
 const u32* sort_failure_flag(void* tmp)

@@ -57,7 +57,7 @@ def estimate_normal(points, device=0):
 
 
 class Index:
-    """Owns a pcpx_index handle: the device-resident Morton-sorted implicit AABB tree."""
+    """Owns a pcpx_index handle: the device-resident curve-sorted implicit AABB tree."""
 
     def __init__(self, xyz, voxel_grid=None, device=0):
         self._lib = _capi.load()
@@ -179,6 +179,18 @@ class Index:
         check(self._lib.pcpx_normals_knn_self(self._h, k, eps, _vp(nrm), _vp(idx), _vp(cnt)))
         return (nrm, idx, cnt) if want_knn else nrm
 
+    def normals_knn_self_curve_order(self, k, eps=1e-5, want_normals=True):
+        """(normals, idx, cnt, perm, position_of) with the rows in curve order: row p belongs to input point perm[p]; position_of is
+        the inverse table (0xFFFFFFFF for a point outside the voxel grid).  The copies overlap the kernels (include/pcpx.h)."""
+        n, n_in = self.size(), self.n_in
+        nrm = np.empty((n, 3), np.float32) if want_normals else None
+        idx = np.empty((n, k), np.uint32)
+        cnt = np.empty(n, np.uint32)
+        perm = np.empty(n, np.uint32)
+        pos = np.empty(n_in, np.uint32)
+        check(self._lib.pcpx_normals_knn_self_curve_order(self._h, k, eps, _vp(nrm), _vp(idx), _vp(cnt), _vp(perm), _vp(pos)))
+        return nrm, idx, cnt, perm, pos
+
     def oriented_normals_knn_self(self, k, eps=1e-5, want_knn=False):
         """estimate_normals followed by propagate_normal_orientations, both on the GPU (the rows stay there).
         Returns normals (and rows, counts if want_knn) plus the number of points reached from the root."""
@@ -243,7 +255,7 @@ class Index:
                                           C.c_void_p(d_d2) if d_d2 else None))
 
     def knn_batch_dev(self, d_queries, nq, k, eps, d_idx, d_cnt, d_d2=None):
-        """kNN of nq arbitrary device-resident query points (Morton-sorted internally, rows in query order)."""
+        """kNN of nq arbitrary device-resident query points (curve-sorted internally, rows in query order)."""
         check(self._lib.pcpx_knn_batch_dev(self._h, d_queries, nq, k, eps, d_idx, d_cnt, d_d2))
 
     def normals_knn_self_dev(self, k, eps, d_normals, d_idx=None, d_cnt=None, first=0, count=_capi.UINT64_MAX):

@@ -2,8 +2,8 @@
 over xGMI on the GPU box, "gloo" in the CPU tests).
 
 The path shards by query and needs exactly one collective: an all-gather of the per-rank bounding boxes
-(6 floats = 24 B per rank) so that every rank quantises Morton codes on the same grid.  Every rank then
-builds the same index and answers a contiguous, 64-aligned shard of the Morton-sorted queries
+(6 floats = 24 B per rank) so that every rank quantises curve keys on the same grid.  Every rank then
+builds the same index and answers a contiguous, 64-aligned shard of the curve-sorted queries
 (pcpx_shard_range); rows land in disjoint slices of the output, so no gather of results is needed.
 """
 import torch
@@ -32,5 +32,5 @@ def global_grid(local_box, dist=None, world=1, always=False):
 
 
 def query_shard(n_indexed, rank, world):
-    """(first, count) in Morton-sorted positions for this rank; first is a multiple of 64."""
+    """(first, count) in curve-sorted positions for this rank; first is a multiple of 64."""
     return shard_range(n_indexed, rank, world)

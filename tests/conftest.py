@@ -47,6 +47,32 @@ def bunny_golden():
     return np.load(os.path.join(GOLDEN, "bunny_k15.npz"))
 
 
+EXTRA_CLOUDS = ("detergent", "spray", "fandisk")  # the reference's other example clouds (examples/data/*.ply)
+
+
+@pytest.fixture(scope="session", params=EXTRA_CLOUDS)
+def extra_cloud(request, pkg):
+    """(name, points, golden) of one of the reference's example clouds beside the bunny: scanner noise (detergent), thin
+    walls (spray), a CAD shape with sharp edges and many exactly equal distances (fandisk)."""
+    pts, _ = pkg.ply.read_ply(os.path.join(GOLDEN, request.param + ".ply"))
+    return request.param, pts, np.load(os.path.join(GOLDEN, request.param + "_k15.npz"))
+
+
+def normals_vs_float64_eigh(pts, idx, cnt, nrm):
+    """float64 symmetric eigen-solve of every row's scatter matrix against the float32 normal: (max 1 - |cos| over the rows
+    whose smallest eigenvalue is separated by a relative gap >= 1e-3, fraction of rows that are not)."""
+    worst, ill = 0.0, 0
+    for r in range(len(idx)):
+        nb = pts[idx[r, : cnt[r]].astype(np.int64)].astype(np.float64)
+        c = nb - nb.mean(0)
+        w, v = np.linalg.eigh(c.T @ c)
+        if (w[1] - w[0]) / max(w[2], 1e-300) < 1e-3:
+            ill += 1
+            continue
+        worst = max(worst, 1.0 - abs(float(v[:, 0] @ nrm[r].astype(np.float64))))
+    return worst, ill / max(1, len(idx))
+
+
 def points_match(got, expected, eps=1e-5):
     """pcp::common::are_vectors_equal on each row (include/pcp/common/vector3d_queries.hpp:47-64)."""
     got = np.asarray(got, np.float32).reshape(-1, 3)

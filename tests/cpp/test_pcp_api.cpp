@@ -361,8 +361,13 @@ static void device_resident_scenarios()
     auto const idx = dev.idx.download();
     auto const cnt = dev.count.download(100, 50);
     auto const nrm = dev.normals.download(3 * 777, 3);
-    REQUIRE(idx == host_rows.idx);
-    for (std::size_t i = 0; i < cnt.size(); ++i) REQUIRE(cnt[i] == host_rows.count[100 + i]);
+    // (the host rows of a whole-index self query come back in curve order with the table of positions: row(i) / size_of_row(i))
+    REQUIRE(host_rows.position_of.size() == cloud.size());
+    bool same_rows = true;
+    for (std::size_t i = 0; i < cloud.size(); ++i)
+        same_rows = same_rows && std::equal(idx.begin() + static_cast<std::ptrdiff_t>(i * k), idx.begin() + static_cast<std::ptrdiff_t>((i + 1) * k), host_rows.row(i));
+    REQUIRE(same_rows);
+    for (std::size_t i = 0; i < cnt.size(); ++i) REQUIRE(cnt[i] == host_rows.size_of_row(100 + i));
     REQUIRE(nrm[0] == host_nrm[3 * 777] && nrm[1] == host_nrm[3 * 777 + 1] && nrm[2] == host_nrm[3 * 777 + 2]);
     pcp::gpu::device_array_t<float> up(6);
     float const six[6] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f};

@@ -10,8 +10,13 @@
    whole cloud (which normals the BFS flips, 1 bit per point), produced by oracle/pcp_oracle.cpp after
    it has been checked against (1) (tests/test_oracle.py does that check on every run).
 
+4. detergent.ply, spray.ply, fandisk.ply -- the reference's other three example clouds (examples/data/, data files: a
+   scanner-noise cloud, a thin-walled one, a CAD shape with sharp edges) and <name>_k15.npz: oracle outputs for 256 evenly
+   spaced query points each -- (d2,index)-sorted 15-NN rows, PCA normals with their eigenvalues, sphere-range counts at
+   2 % of the bounding-box diagonal -- from brute force, after the restated octree and kd-tree were checked to agree.
+
 Run from the repo root in the build container: python tests/golden/make_golden.py
-(step 2 needs /root/reference; steps 1 and 3 do not).
+(steps 2 and 4 copy from /root/reference when it is there; the other steps do not need it).
 """
 import json
 import os
@@ -112,6 +117,38 @@ def kats():
     }
 
 
+EXTRA_CLOUDS = ("detergent", "spray", "fandisk")
+EXTRA_ROWS = 256
+EXTRA_RADIUS_FRACTION = 0.02  # of the bounding-box diagonal
+
+
+def extra_cloud(pkg, O, name):
+    src = "/root/reference/examples/data/%s.ply" % name
+    dst = os.path.join(HERE, name + ".ply")
+    if os.path.exists(src):
+        shutil.copyfile(src, dst)
+    pts, _ = pkg.ply.read_ply(dst)
+    qsel = np.linspace(0, len(pts) - 1, EXTRA_ROWS).astype(np.int64)
+    idx, cnt, d2 = O.knn_bruteforce(pts, pts[qsel], 15, eps=1e-5, nthreads=8, want_d2=True)
+    nrm, ev = O.normals_from_knn(pts, idx, cnt, want_evals=True)
+    radius = np.float32(EXTRA_RADIUS_FRACTION * np.linalg.norm(pts.max(0).astype(np.float64) - pts.min(0).astype(np.float64)))
+    rc = O.range_count_bruteforce(pts, pts[qsel], float(radius), nthreads=8)
+    # the restated trees of the reference agree with brute force on this cloud (distances exactly; indices wherever the k-th
+    # distance is not tied)
+    for tree in (O.Octree(pts), O.KdTree(pts, compute_max_depth=True)):
+        ti, tc, td = tree.knn(pts[qsel], 15, want_d2=True)
+        assert (tc == cnt).all() and (td == d2).all(), name
+        differ = np.nonzero((ti != idx).any(1))[0]
+        for q in differ:  # same points at every distance below the k-th (their order among equal distances is the tree's own)
+            kth = d2[q, cnt[q] - 1]
+            for v in np.unique(d2[q, : cnt[q]]):
+                if v != kth:
+                    assert set(ti[q, : cnt[q]][d2[q, : cnt[q]] == v]) == set(idx[q, : cnt[q]][d2[q, : cnt[q]] == v]), name
+        assert all(len(tree.range_sphere(pts[q], float(radius))) == c for q, c in zip(qsel, rc)), name
+    np.savez_compressed(os.path.join(HERE, name + "_k15.npz"), query_index=qsel, knn_idx=idx, knn_cnt=cnt, knn_d2=d2, normals=nrm,
+                        evals=ev, range_radius=radius, range_count=rc)
+
+
 def main():
     with open(os.path.join(HERE, "reference_kats.json"), "w") as f:
         json.dump(kats(), f, indent=1)
@@ -142,6 +179,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "bunny_k15.npz"), query_index=qsel, knn_idx=idx, knn_cnt=cnt, knn_d2=d2,
                         normals=nrm, evals=ev, range_count_r001=rc, orientation_flipped=flipped,
                         orientation_root=np.int64(np.argmax(pts[:, 2])), orientation_reached=np.int64(reached))
+    for name in EXTRA_CLOUDS:
+        extra_cloud(pkg, O, name)
     print("wrote fixtures to", HERE)
 
 

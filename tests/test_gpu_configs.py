@@ -72,7 +72,7 @@ def test_config5_streaming_50m_k32(pkg, oracle):
         ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), d_d2.data_ptr())
         ix.synchronize()
         _device_row_properties(torch, d_pts, d_idx, d_cnt, d_d2, k)
-        sel = np.random.default_rng(50 + it).integers(0, n, 48)
+        sel = np.random.default_rng(50 + it).integers(0, n, 2048)
         t_sel = torch.from_numpy(sel).to(dev)
         _sampled_rows_exact(oracle, pts, sel, k, d_idx[t_sel].cpu().numpy().view(np.uint32), d_cnt[t_sel].cpu().numpy().view(np.uint32),
                             d_d2[t_sel].cpu().numpy())
@@ -134,7 +134,7 @@ def test_config4_clustered_10m_k15_sharded(pkg, oracle):
     idx = full_idx.cpu().numpy().view(np.uint32)
     cnt = full_cnt.cpu().numpy().view(np.uint32)
     nrm = full_nrm.cpu().numpy()
-    sel = np.random.default_rng(44).integers(0, n, 48)
+    sel = np.random.default_rng(44).integers(0, n, 2048)
     _sampled_rows_exact(oracle, pts, sel, k, idx[sel], cnt[sel], d_d2.cpu().numpy()[sel])
     big = np.random.default_rng(45).integers(0, n, 120_000)
     on = oracle.normals_from_knn(pts, idx[big], cnt[big], nthreads=16)

@@ -3,7 +3,7 @@ transcribed from the reference's Catch2 suite) and against the committed bunny g
 import numpy as np
 import pytest
 
-from conftest import knn_rows_equivalent, points_match, same_point_set
+from conftest import normals_vs_float64_eigh, knn_rows_equivalent, points_match, same_point_set
 
 
 def _octree_sweep(kats):
@@ -169,6 +169,56 @@ def test_trees_agree_with_bruteforce_on_bunny(oracle, bunny, bunny_golden):
     assert np.array_equal(oracle.range_count_bruteforce(bunny, q, 0.01, nthreads=8), g["range_count_r001"])
     nrm = oracle.normals_from_knn(bunny, idx, cnt)
     assert np.array_equal(nrm, g["normals"])
+
+
+def test_reference_range_prune_for_radius_above_one(oracle):
+    """include/pcp/common/intersections.hpp:101,129 compare a squared distance with `radius`: for radius > 1 the restated
+    trees under-report against brute force, and report exactly the brute-force set once that comparison uses radius^2 (the
+    test switch of the oracle).  For radius <= 1 the prune is merely loose and nothing is missed."""
+    rng = np.random.default_rng(32)
+    pts = rng.uniform(-6, 6, (20000, 3)).astype(np.float32)
+    q = rng.uniform(-6, 6, (16, 3)).astype(np.float32)
+    for r, expect_missing in ((0.8, False), (2.5, True)):
+        missed = 0
+        for tree in (oracle.Octree(pts), oracle.KdTree(pts)):
+            for c in q:
+                d = pts - c[None, :]
+                brute = set(np.nonzero((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2] <= np.float32(r) * np.float32(r))[0].tolist())
+                ref = set(tree.range_sphere(c, r).tolist())
+                oracle.set_geometric_prune(True)
+                try:
+                    fixed = set(tree.range_sphere(c, r).tolist())
+                finally:
+                    oracle.set_geometric_prune(False)
+                assert ref <= brute and fixed == brute
+                missed += len(brute - ref)
+        assert (missed > 0) == expect_missing
+
+
+def test_trees_agree_with_bruteforce_on_the_other_example_clouds(oracle, extra_cloud):
+    """detergent / spray / fandisk (examples/data/*.ply): brute force reproduces the committed rows bit for bit, the restated
+    octree and kd-tree agree with it (distances exactly, indices wherever distances are distinct), sphere counts agree, and
+    the restated solver's normals are within 1e-4 cosine of a float64 eigen-solve wherever that is well conditioned."""
+    name, pts, g = extra_cloud
+    qi = g["query_index"]
+    q = pts[qi]
+    idx, cnt, d2 = oracle.knn_bruteforce(pts, q, 15, nthreads=8, want_d2=True)
+    assert np.array_equal(idx, g["knn_idx"]) and np.array_equal(cnt, g["knn_cnt"]) and np.array_equal(d2, g["knn_d2"])
+    radius = float(g["range_radius"])
+    assert np.array_equal(oracle.range_count_bruteforce(pts, q, radius, nthreads=8), g["range_count"])
+    octree, kdtree = oracle.Octree(pts), oracle.KdTree(pts, compute_max_depth=True)
+    for tree in (octree, kdtree):
+        ti, tc, td = tree.knn(q, 15, nthreads=8, want_d2=True)
+        assert np.array_equal(td, d2), name
+        ok, why = knn_rows_equivalent(pts, q, ti, tc, idx, cnt)
+        assert ok, name + ": " + why
+    assert np.array_equal(octree.range_count(q, radius, nthreads=8), g["range_count"])
+    assert all(len(kdtree.range_sphere(c, radius)) == n for c, n in zip(q[::8], g["range_count"][::8]))
+    nrm = oracle.normals_from_knn(pts, idx, cnt)
+    assert np.array_equal(nrm, g["normals"])
+    worst, ill = normals_vs_float64_eigh(pts, idx, cnt, nrm)
+    print("%s: max 1-|cos| vs float64 eigh %.2e, ill-conditioned rows %.3f" % (name, worst, ill))
+    assert worst <= 1e-4
 
 
 def test_oracle_normals_close_to_float64_eigh(oracle, bunny, bunny_golden):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Single-query latency in the shape of the reference's own benchmark (benchmark/spatial_data_structures_benchmark.cpp:243-264):
+"""Single-query latency, range-search latency and construction time in the shapes of the reference's own benchmarks
+(benchmark/spatial_data_structures_benchmark.cpp:108-148, :169-213, :243-264):
 tools/latency_bench.cpp through the drop-in C++ header on the GPU, the oracle's octree restatement (reference algorithm and
 defaults, one thread, one query at a time) on the host beside it.  usage: python tools/latency_report.py [out.json]"""
 import importlib, json, os, subprocess, sys, time
@@ -23,6 +24,19 @@ for n in (1 << 20, 1 << 24):
     q = rng.uniform(-100, 100, (3000, 3)).astype(np.float32)
     tree.knn(q[:100], 10, nthreads=1)
     t0 = time.perf_counter(); tree.knn(q, 10, nthreads=1); cpu_us = (time.perf_counter() - t0) / len(q) * 1e6
+    # the reference's range-search shape on the host: one box of half-width <= 1 per call (benchmark :169-213)
+    c = rng.uniform(-99, 99, (3000, 3)).astype(np.float32)
+    blo = c + rng.uniform(-1, 0, (3000, 3)).astype(np.float32)
+    bhi = c + rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    t0 = time.perf_counter()
+    for i in range(3000):
+        tree.range_aabb(blo[i], bhi[i])
+    gpu["cpu_oracle_octree_range_us_per_query_1_thread"] = round((time.perf_counter() - t0) / 3000 * 1e6, 2)
+    t0 = time.perf_counter(); kd = O.KdTree(pts, compute_max_depth=True); gpu["cpu_oracle_kdtree_build_s"] = round(time.perf_counter() - t0, 2)
+    t0 = time.perf_counter()
+    for i in range(3000):
+        kd.range_aabb(blo[i], bhi[i])
+    gpu["cpu_oracle_kdtree_range_us_per_query_1_thread"] = round((time.perf_counter() - t0) / 3000 * 1e6, 2)
     gpu["cpu_oracle_octree_points"] = m
     gpu["cpu_oracle_octree_knn_us_per_query_1_thread"] = round(cpu_us, 2)
     gpu["cpu_oracle_octree_build_s"] = round(build_s, 2)

@@ -14,13 +14,17 @@ t0 = time.perf_counter(); ix = pkg.Index(pts); t_build = time.perf_counter() - t
 t0 = time.perf_counter(); ix.rebuild(pts); t_rebuild = time.perf_counter() - t0
 vp = lambda a: a.ctypes.data_as(C.c_void_p)
 nrm = np.zeros((n, 3), np.float32); idx = np.zeros((n, k), np.uint32); cnt = np.zeros(n, np.uint32); rc = np.zeros(n, np.uint32)
+perm = np.zeros(n, np.uint32); pos = np.zeros(n, np.uint32)
 calls = {
+    # rows in curve order + the position table: slices are copied while later slices are computed (include/pcpx.h)
+    "normals_and_knn_rows_curve_order": lambda: lib.pcpx_normals_knn_self_curve_order(ix._h, k, 1e-5, vp(nrm), vp(idx), vp(cnt), None, vp(pos)),
+    "knn_rows_curve_order": lambda: lib.pcpx_normals_knn_self_curve_order(ix._h, k, 1e-5, None, vp(idx), vp(cnt), vp(perm), None),
     "normals_only": lambda: lib.pcpx_normals_knn_self(ix._h, k, 1e-5, vp(nrm), None, None),
     "normals_and_knn_rows": lambda: lib.pcpx_normals_knn_self(ix._h, k, 1e-5, vp(nrm), vp(idx), vp(cnt)),
     "knn_rows": lambda: lib.pcpx_knn_self(ix._h, k, 1e-5, vp(idx), vp(cnt), None),
     "range_count_r001": lambda: lib.pcpx_range_count_self(ix._h, 0.01, vp(rc)),
 }
-bytes_out = {"normals_only": 12 * n, "normals_and_knn_rows": (12 + 4 * k + 4) * n, "knn_rows": (4 * k + 4) * n, "range_count_r001": 4 * n}
+bytes_out = {"normals_and_knn_rows_curve_order": (12 + 4 * k + 4 + 4) * n, "knn_rows_curve_order": (4 * k + 4 + 4) * n, "normals_only": 12 * n, "normals_and_knn_rows": (12 + 4 * k + 4) * n, "knn_rows": (4 * k + 4) * n, "range_count_r001": 4 * n}
 res = {}
 for name, fn in calls.items():
     capi.check(fn())

@@ -7,8 +7,8 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        m = re.search(r"(k_[a-z_0-9]+|radix_sort_onesweep_iteration|onesweep_histograms)", name)
-        key = m.group(1) if m else name[:40]
+        m = re.search(r"(k_[a-z_0-9]+(<[^>(]*>)?|radix_sort_onesweep_iteration|onesweep_histograms)", name)
+        key = m.group(1).replace(" ", "") if m else name[:40]
         acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, d in acc.items():

@@ -21,3 +21,10 @@ for t in trace10 trace50; do
   f=$(find "$out/$t" -name '*kernel_stats.csv' | head -1)
   echo "== $t"; python3 tools/rocprof_summary.py "$f" | tee "$out/${t}_kernel_stats.txt"
 done
+# variants built beforehand (libpcpx_<tag>.so): rebuild time with each
+for lib in point-cloud-processing_amd/libpcpx_*.so; do
+  [ -f "$lib" ] || continue
+  for sz in 1e7 5e7; do
+    echo "variant $lib $sz: $(PCPX_LIB=$PWD/$lib timeout -k 10 200 python3 tools/rebuild_loop.py $sz 10 2>&1 | tail -1)"
+  done
+done
