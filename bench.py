@@ -156,7 +156,8 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
 
         def step():
             it_no[0] += 1
-            ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, voxel_grid=grid)
+            # (PCPX_BUILD_COARSE_ORDER: this index answers one query pass before the next rebuild)
+            ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, voxel_grid=grid, coarse_order=True)
             ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
     else:
         def step():
@@ -191,7 +192,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         t0 = time.perf_counter()
         reb = 5
         for _ in range(reb):
-            ix.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid)
+            ix.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid, coarse_order=streaming)
         torch.cuda.synchronize()
         rebuild_ms = (time.perf_counter() - t0) * 1e3 / reb
 

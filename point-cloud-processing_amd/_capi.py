@@ -18,6 +18,7 @@ PCPX_ERR_ALLOC = -3
 PCPX_ERR_CAPACITY = -4
 PCPX_ERR_UNSUPPORTED = -5
 PCPX_BUILD_USE_GRID = 1
+PCPX_BUILD_COARSE_ORDER = 2
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 

@@ -16,6 +16,9 @@ namespace pcpx {
 
 namespace {
 
+#ifndef PCPX_BUILD_ADAPTIVE_MARGIN
+#define PCPX_BUILD_ADAPTIVE_MARGIN 6  // PCPX_BUILD_COARSE_ORDER: bits of curve resolution kept beyond log2 of a top-digit bucket's size
+#endif
 #ifndef PCPX_BUILD_RECORDS
 #define PCPX_BUILD_RECORDS 1  // 1: the sort's first pass moves a {x, y, z, id} record per point into its top-digit bucket and the leaf
                               // fill gathers from there; 0: the leaf fill gathers the coordinates from the input-order copy
@@ -593,6 +596,9 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         pl.idx_bits = ix.idx_bits;
         pl.tile_hist_ready = sort_tile_hist_buffer(ix.d_sort_tmp, n);
         pl.failed_flag = ix.d_scalars + 7;
+        const bool coarse = params && (params->flags & PCPX_BUILD_COARSE_ORDER);
+        pl.adaptive_margin_bits = coarse ? PCPX_BUILD_ADAPTIVE_MARGIN : 0;
+        ix.sorted_from_bit = coarse ? 40 : SORT_FIRST_BIT;
         int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
         if (st != PCPX_OK) return st;
     }

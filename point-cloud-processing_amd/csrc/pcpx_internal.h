@@ -151,6 +151,7 @@ struct Index {
     u32* d_perm = nullptr;                 // sorted position -> input index
     float4* d_rec = nullptr;               // {x, y, z, input index} per point, grouped by the sort word's top digit (the leaf fill's source)
     int idx_bits = 1;                      // low bits of a sort word that hold the input index
+    int sorted_from_bit = 24;              // the sorted words are ordered on their bits [sorted_from_bit, 64) everywhere
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     Leaf* d_leaves = nullptr;
@@ -231,6 +232,9 @@ struct SortPayload {
     int idx_bits = 0;                     //   word's low idx_bits (which held the element's index)
     u32* tile_hist_ready = nullptr;       // counts of the words' top digit (bits [56, 64)) per tile of SORT_TILE_WORDS consecutive words,
                                           //   [tile][256], if the caller has them already (scanned in place by the sort)
+    int adaptive_margin_bits = 0;         // > 0: a bucket (words sharing the top digit) of c words is sorted on ceil((ceil(log2 c) + margin) / 8)
+                                          //   of its lower digits only, at least two: every word is then ordered on bits [40, 64), and on as many
+                                          //   bits below as separate the words of its own bucket with `margin` bits to spare.  0: the full sort.
     u32* failed_flag = nullptr;           // device word (zeroed by the caller) to set if the look-back ever gives up; default: inside tmp
 };
 int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit = 0,

@@ -107,7 +107,7 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
     if (nq > 0) {
         const float* d_box = reinterpret_cast<const float*>(ix.d_scalars + 8);
         const int qbits = index_bits_for(nq);
-        const int cmp_shift = std::max(SORT_FIRST_BIT, std::max(qbits, ix.idx_bits));
+        const int cmp_shift = std::max(ix.sorted_from_bit, std::max(qbits, ix.idx_bits));  // (the binary search needs bits the index is ordered on)
         const u32 cblocks = (n32 + QCODES_BLOCK - 1) / QCODES_BLOCK;
         k_query_codes<<<cblocks < 512u ? cblocks : 512u, QCODES_BLOCK, 0, s>>>(d_q, n32, d_box, qbits, codes0);
         if ((st = sort_keys_u64(base + o_tmp, tb, codes0, codes1, nq, s, SORT_FIRST_BIT)) != PCPX_OK) return st;

@@ -60,7 +60,11 @@ constexpr int TOP_SHIFT = 56;
 // bucket table of one sort (device memory, written by k_sort_seg_setup)
 struct SegTable {
     u32 start[RADIX + 1];       // first position of bucket b; start[RADIX] = n
-    u32 tile_first[RADIX + 1];  // first tile of bucket b in the bucketed passes; tile_first[RADIX] = number of tiles
+    u32 tile_first[RADIX + 1];  // first tile of bucket b in the bucketed tile order; tile_first[RADIX] = number of tiles
+    u32 pass_tile_first[MAX_PASSES - 1][RADIX + 1];  // the same for bucketed pass q (1-based: row q - 1), over the buckets that take
+                                                     // part in it: a pass hands out tickets for its own tiles only
+    u32 first_pass[RADIX];      // the first bucketed pass (1-based) bucket b takes part in: 1 unless the caller lets a bucket's
+                                // depth follow its size (SortPayload::adaptive_margin_bits), then passes below it are skipped
 };
 
 __device__ __forceinline__ u32 digit_of(u64 key, int shift) { return static_cast<u32>(key >> shift) & (RADIX - 1); }
@@ -158,63 +162,76 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_top_hist(const u64* __restr
 
 // Exclusive scan of the tiles' counts per digit, in place, and the digits' totals -- two launches over chunks of consecutive
 // tiles, every access a 1-KB row (thread = digit): (1) the chunks' sums, (2) a chunk's base = the sums of the chunks before
-// it, then the running prefix through the chunk.  (One block per digit walking its column was 17 us at 10 M words and 84 us
-// at 50 M: 4-byte reads a kilobyte apart.)
+// it, then the running prefix through the chunk.  About sqrt(tiles) chunks, so that neither loop of (2) is long; eight rows
+// in flight per thread.  (One block per digit walking its column was 17 us at 10 M words and 84 us at 50 M: 4-byte reads a
+// kilobyte apart.)
 constexpr u32 SCAN_CHUNKS_MAX = 256;
+constexpr int SCAN_ROWS = 8;  // rows in flight per thread
 __global__ __launch_bounds__(RADIX) void k_sort_tile_sums(const u32* __restrict__ tile_hist, u32 ntiles, u32 per_chunk, u32* __restrict__ chunk_sum)
 {
     const u32 d = threadIdx.x;
     const u32 t0 = blockIdx.x * per_chunk, t1 = t0 + per_chunk < ntiles ? t0 + per_chunk : ntiles;
-    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    u32 t = t0;
-    for (; t + 4 <= t1; t += 4) {  // (independent accumulators: four rows in flight)
-        s0 += tile_hist[static_cast<size_t>(t) * RADIX + d];
-        s1 += tile_hist[static_cast<size_t>(t + 1) * RADIX + d];
-        s2 += tile_hist[static_cast<size_t>(t + 2) * RADIX + d];
-        s3 += tile_hist[static_cast<size_t>(t + 3) * RADIX + d];
+    u32 sum = 0;
+    for (u32 t = t0; t < t1; t += SCAN_ROWS) {
+        u32 v[SCAN_ROWS];
+#pragma unroll
+        for (int j = 0; j < SCAN_ROWS; ++j) v[j] = t + j < t1 ? tile_hist[static_cast<size_t>(t + j) * RADIX + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_ROWS; ++j) sum += v[j];
     }
-    for (; t < t1; ++t) s0 += tile_hist[static_cast<size_t>(t) * RADIX + d];
-    chunk_sum[blockIdx.x * RADIX + d] = s0 + s1 + s2 + s3;
+    chunk_sum[blockIdx.x * RADIX + d] = sum;
 }
 __global__ __launch_bounds__(RADIX) void k_sort_tile_scan(u32* __restrict__ tile_hist, u32 ntiles, u32 per_chunk, const u32* __restrict__ chunk_sum,
                                                           u32* __restrict__ hist)
 {
     const u32 d = threadIdx.x;
-    u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-    u32 c = 0;
-    for (; c + 4 <= blockIdx.x; c += 4) {
-        b0 += chunk_sum[c * RADIX + d];
-        b1 += chunk_sum[(c + 1) * RADIX + d];
-        b2 += chunk_sum[(c + 2) * RADIX + d];
-        b3 += chunk_sum[(c + 3) * RADIX + d];
+    u32 acc = 0;
+    for (u32 c = 0; c < blockIdx.x; c += SCAN_ROWS) {
+        u32 v[SCAN_ROWS];
+#pragma unroll
+        for (int j = 0; j < SCAN_ROWS; ++j) v[j] = c + j < blockIdx.x ? chunk_sum[(c + j) * RADIX + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_ROWS; ++j) acc += v[j];
     }
-    for (; c < blockIdx.x; ++c) b0 += chunk_sum[c * RADIX + d];
-    u32 acc = b0 + b1 + b2 + b3;
     const u32 t0 = blockIdx.x * per_chunk, t1 = t0 + per_chunk < ntiles ? t0 + per_chunk : ntiles;
-    u32 t = t0;
-    for (; t + 4 <= t1; t += 4) {
-        u32* row = tile_hist + static_cast<size_t>(t) * RADIX + d;
-        const u32 v0 = row[0], v1 = row[RADIX], v2 = row[2 * RADIX], v3 = row[3 * RADIX];
-        row[0] = acc;
-        row[RADIX] = acc + v0;
-        row[2 * RADIX] = acc + v0 + v1;
-        row[3 * RADIX] = acc + v0 + v1 + v2;
-        acc += v0 + v1 + v2 + v3;
-    }
-    for (; t < t1; ++t) {
-        u32* row = tile_hist + static_cast<size_t>(t) * RADIX + d;
-        const u32 v = row[0];
-        row[0] = acc;
-        acc += v;
+    for (u32 t = t0; t < t1; t += SCAN_ROWS) {
+        u32 v[SCAN_ROWS];
+#pragma unroll
+        for (int j = 0; j < SCAN_ROWS; ++j) v[j] = t + j < t1 ? tile_hist[static_cast<size_t>(t + j) * RADIX + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_ROWS; ++j) {
+            if (t + j < t1) tile_hist[static_cast<size_t>(t + j) * RADIX + d] = acc;
+            acc += v[j];
+        }
     }
     if (blockIdx.x == gridDim.x - 1) hist[d] = acc;
 }
 
 // one block: counts -> bucket table
-__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_setup(const u32* __restrict__ hist, SegTable* __restrict__ seg)
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_setup(const u32* __restrict__ hist, SegTable* __restrict__ seg, int low, int margin_bits)
 {
     __shared__ u32 wtot[SORT_WAVES];
     const u32 c = hist[threadIdx.x];
+    {
+        // Depth by size (index build only): a bucket of c words is sorted on as many of its lower digits as separate its words
+        // with `margin_bits` to spare -- ceil((ceil(log2 c) + margin) / 8) of them, at least two -- and takes no part in the
+        // passes below those.  The sort is then exact on the top digit and the top two lower digits everywhere, and as fine
+        // as its density asks for in every bucket.
+        u32 first = 1;
+        if (margin_bits > 0 && low >= 3) {
+            const int lg = c > 1 ? 32 - __builtin_clz(c - 1u) : 0;
+            int need = (lg + margin_bits + 7) / 8;
+            need = need < 2 ? 2 : need > low ? low : need;
+            first = static_cast<u32>(low + 1 - need);
+        }
+        seg->first_pass[threadIdx.x] = first;
+        for (int q = 1; q <= low; ++q) {
+            u32 tiles = 0;
+            const u32 f = block_exclusive_scan(static_cast<u32>(q) >= first ? (c + SORT_TILE - 1) / SORT_TILE : 0u, wtot, tiles);
+            seg->pass_tile_first[q - 1][threadIdx.x] = f;
+            if (threadIdx.x == 0) seg->pass_tile_first[q - 1][RADIX] = tiles;
+        }
+    }
     u32 total = 0;
     const u32 s = block_exclusive_scan(c, wtot, total);
     seg->start[threadIdx.x] = s;
@@ -245,7 +262,7 @@ struct TilePlace {
 };
 
 template <bool SEG, bool PAYLOAD>
-__global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 ? 4 : 3) void k_sort_pass(const u64* __restrict__ kin, u64* __restrict__ kout, u32 n, u32 tiles_arg, int shift, int tag_pass,
+__global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 ? 4 : 3) void k_sort_pass(const u64* __restrict__ kin, u64* __restrict__ kout, u64* __restrict__ kout_odd, u32 n, u32 tiles_arg, int shift, int tag_pass,
                                                           const u32* __restrict__ seg_hist, const u32* __restrict__ tile_prefix,
                                                           const SegTable* __restrict__ seg, u64* __restrict__ status,
                                                           u32* __restrict__ ticket, u32* __restrict__ failed, SortPayloadArgs pl)
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
     __shared__ u32 whist[SORT_WAVES][RADIX];  // ranking: words of each digit seen so far by the wave; then: position of the wave's
                                               // first word of the digit in the tile's digit-sorted order
     __shared__ u32 gdelta[RADIX];             // output position of the tile's digit-sorted word j of digit d = gdelta[d] + j
+    __shared__ u32 godd[SEG ? 1 : RADIX];     // top-digit pass: bucket d's words go to kout_odd, not kout (its first bucketed pass is an even one)
     __shared__ u32 wtot[2 * SORT_WAVES];
     __shared__ u32 place_s[4];
     u64(*wmask)[RADIX] = reinterpret_cast<u64(*)[RADIX]>(stage);  // [SORT_WAVES][RADIX]: lanes of the wave that hold digit d
@@ -263,7 +281,8 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
     // it scatters the current one (the atomic's round trip, 2-3 us under load, was a sixth of a tile's life when the block
     // waited for it with nothing else to do, profiles/r03_pmc_rebuild.json).
     // (The top-digit pass, SEG = false, has no chain: one tile per block, taken by block index.)
-    const u32 ntiles = SEG ? seg->tile_first[RADIX] : tiles_arg;
+    const u32* my_tile_first = SEG ? seg->pass_tile_first[tag_pass - 1] : seg->tile_first;  // (tag_pass = the bucketed pass's number, 1-based)
+    const u32 ntiles = SEG ? my_tile_first[RADIX] : tiles_arg;
     if (threadIdx.x == 0) place_s[0] = SEG ? atomicAdd(&ticket[tag_pass], 1u) : blockIdx.x;
     for (;;) {
     // (the thread's index is made opaque per tile: otherwise every address formed from it is a loop invariant of the
@@ -282,8 +301,8 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
     if (tile >= ntiles) break;
     TilePlace tp;
     if (SEG) {
-        // the bucket of the tile: the one non-empty bucket with tile_first[b] <= tile < tile_first[b + 1]
-        const u32 f0 = seg->tile_first[tid], f1 = seg->tile_first[tid + 1];
+        // the bucket of the tile: the one bucket of this pass with tile_first[b] <= tile < tile_first[b + 1]
+        const u32 f0 = my_tile_first[tid], f1 = my_tile_first[tid + 1];
         if (f0 <= tile && tile < f1) {
             place_s[1] = tid;
             place_s[2] = f0;
@@ -409,6 +428,7 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
             __hip_atomic_store(mine, tag | ST_PREFIX | (static_cast<u64>(before) + local), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         gdelta[d] = dbase + before - tb;
+        if (!SEG) godd[d] = (seg->first_pass[d] - 1u) & 1u;
     }
     __syncthreads();  // (also: every wave is past its ranking, the lane masks are dead: `stage` may be written)
     // The next ticket is taken HERE: this tile has published everything its successors wait for, so the tile behind the
@@ -450,14 +470,15 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
             for (int u = 0; u < U; ++u) {
                 if (j0 + u * SORT_BLOCK < in_tile) {
                     pl.rec[dst[u]] = make_float4(x[u], y[u], z[u], __uint_as_float(static_cast<u32>(e[u])));
-                    kout[dst[u]] = (k[u] & ~pl.low_mask) | dst[u];
+                    (godd[digit_of(k[u], shift)] ? kout_odd : kout)[dst[u]] = (k[u] & ~pl.low_mask) | dst[u];
                 }
             }
         }
     } else {
         for (u32 j = tid; j < in_tile; j += SORT_BLOCK) {
             const u64 k = stage[j];
-            kout[gdelta[digit_of(k, shift)] + j] = k;
+            const u32 d = digit_of(k, shift);
+            ((!SEG && godd[d]) ? kout_odd : kout)[gdelta[d] + j] = k;
         }
     }
     __syncthreads();  // (everyone is done with `stage`, `whist`, `gdelta` and place_s of this tile)
@@ -467,8 +488,9 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
 
 // Per bucket: digit counts of the bucketed passes, hist[bucket][pass][256] (zeroed by the caller).  A block takes
 // `tiles_per_block` consecutive tiles of the bucketed tile order and flushes its LDS counts whenever the bucket changes.
-__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restrict__ keys, const SegTable* __restrict__ seg, int first_bit,
-                                                              int passes, u32 tiles_per_block, u32* __restrict__ hist)
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restrict__ keys_even, const u64* __restrict__ keys_odd,
+                                                              const SegTable* __restrict__ seg, int first_bit, int passes, u32 tiles_per_block,
+                                                              u32* __restrict__ hist)
 {
     __shared__ u32 h[MAX_PASSES - 1][RADIX];
     __shared__ u32 place_s[2];
@@ -503,6 +525,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restr
         const u32 s1 = seg->start[bucket + 1];
         const u32 lo = seg->start[bucket] + (tile - bfirst) * SORT_TILE;
         const u32 hi = s1 - lo < static_cast<u32>(SORT_TILE) ? s1 : lo + SORT_TILE;
+        const u64* keys = ((seg->first_pass[bucket] - 1u) & 1u) ? keys_odd : keys_even;  // where the top-digit pass put this bucket
         u64 key[SORT_ITEMS];  // (all loads of the tile in flight before the first count)
 #pragma unroll
         for (int it = 0; it < SORT_ITEMS; ++it) {
@@ -583,7 +606,9 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     }
     {
         const u32 nt = static_cast<u32>(ntiles);
-        const u32 per_chunk = (nt + SCAN_CHUNKS_MAX - 1) / SCAN_CHUNKS_MAX;
+        u32 want = 16;  // about sqrt(tiles) chunks
+        while (want < SCAN_CHUNKS_MAX && want * want < nt) want += 8;
+        const u32 per_chunk = (nt + want - 1) / want;
         const u32 chunks = (nt + per_chunk - 1) / per_chunk;
         u32* chunk_sum = reinterpret_cast<u32*>(base + L.o_chunks);
         k_sort_tile_sums<<<chunks, RADIX, 0, s>>>(tile_hist, nt, per_chunk, chunk_sum);
@@ -591,7 +616,8 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     }
     const u32* top = top_hist;
     u32* failed = payload && payload->failed_flag ? payload->failed_flag : ctl + 8;
-    k_sort_seg_setup<<<1, SORT_BLOCK, 0, s>>>(top, seg);
+    const int margin = (payload && low >= 3) ? payload->adaptive_margin_bits : 0;
+    k_sort_seg_setup<<<1, SORT_BLOCK, 0, s>>>(top, seg, low, margin);
 
     // persistent grids: as many blocks as are resident at once (4 per CU: LDS and registers), never more than tiles
     static int cus_of_device[64] = {};
@@ -613,23 +639,24 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     auto dst_of = [&](int j) { return ((passes - 1 - j) & 1) == 0 ? kout : kt; };
     SortPayloadArgs pl{nullptr, nullptr, 0};
     u64* kdst = dst_of(0);
+    u64* kodd = dst_of(1);  // (a bucket whose first bucketed pass is pass q is read there from dst_of(q - 1))
     if (payload && payload->xyz) {
         pl.xyz = payload->xyz;
         pl.rec = payload->rec;
         pl.low_mask = (1ull << payload->idx_bits) - 1ull;
-        k_sort_pass<false, true><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);
+        k_sort_pass<false, true><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, kodd, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);
     } else {
-        k_sort_pass<false, false><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);
+        k_sort_pass<false, false><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, kodd, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);
     }
     if (low > 0) {
         u32 tpb = static_cast<u32>(L.ntiles_max / 2048);  // tiles per block: enough blocks to fill the chip, few flushes of the counts
         tpb = tpb < 2 ? 2 : tpb > 32 ? 32 : tpb;
         const u32 hblocks = static_cast<u32>((L.ntiles_max + tpb - 1) / tpb);
-        k_sort_seg_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kdst, seg, first_bit, low, tpb, seg_hist);
+        k_sort_seg_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kdst, kodd, seg, first_bit, low, tpb, seg_hist);
         const u64* ksrc = kdst;
         for (int p = 0; p < low; ++p) {
             kdst = dst_of(p + 1);
-            k_sort_pass<true, false><<<grid_seg, SORT_BLOCK, 0, s>>>(ksrc, kdst, n32, 0u, first_bit + 8 * p, p + 1, seg_hist + p * RADIX, nullptr, seg, status, ctl, failed, pl);
+            k_sort_pass<true, false><<<grid_seg, SORT_BLOCK, 0, s>>>(ksrc, kdst, nullptr, n32, 0u, first_bit + 8 * p, p + 1, seg_hist + p * RADIX, nullptr, seg, status, ctl, failed, pl);
             ksrc = kdst;
         }
     }

@@ -59,31 +59,35 @@ def estimate_normal(points, device=0):
 class Index:
     """Owns a pcpx_index handle: the device-resident curve-sorted implicit AABB tree."""
 
-    def __init__(self, xyz, voxel_grid=None, device=0):
+    def __init__(self, xyz, voxel_grid=None, device=0, coarse_order=False):
         self._lib = _capi.load()
         self._h = C.c_void_p(None)
         self.device = device
         xyz = _f32(xyz, 3)
         self.n_in = len(xyz)
-        p = self._params(voxel_grid)
+        p = self._params(voxel_grid, coarse_order)
         check(self._lib.pcpx_index_create(_vp(xyz), len(xyz), p, device, C.byref(self._h)))
 
     @staticmethod
-    def _params(voxel_grid):
-        if voxel_grid is None:
+    def _params(voxel_grid, coarse_order=False):
+        """pcpx_build_params: voxel_grid = the explicit grid (PCPX_BUILD_USE_GRID); coarse_order = PCPX_BUILD_COARSE_ORDER (an index that
+        is rebuilt after a query pass or two: one radix pass fewer on a uniform cloud, same results)."""
+        if voxel_grid is None and not coarse_order:
             return None
-        g = np.asarray(voxel_grid, np.float32).reshape(6)
         p = BuildParams()
         p.struct_size = C.sizeof(BuildParams)
-        p.flags = _capi.PCPX_BUILD_USE_GRID
+        p.flags = (_capi.PCPX_BUILD_USE_GRID if voxel_grid is not None else 0) | (_capi.PCPX_BUILD_COARSE_ORDER if coarse_order else 0)
+        if voxel_grid is None:
+            return C.pointer(p)
+        g = np.asarray(voxel_grid, np.float32).reshape(6)
         for a in range(3):
             p.grid_min[a] = float(g[a])
             p.grid_max[a] = float(g[3 + a])
         return C.pointer(p)
 
-    def rebuild(self, xyz, voxel_grid=None):
+    def rebuild(self, xyz, voxel_grid=None, coarse_order=False):
         xyz = _f32(xyz, 3)
-        check(self._lib.pcpx_index_rebuild(self._h, _vp(xyz), len(xyz), self._params(voxel_grid)))
+        check(self._lib.pcpx_index_rebuild(self._h, _vp(xyz), len(xyz), self._params(voxel_grid, coarse_order)))
         self.n_in = len(xyz)
 
     def close(self):
@@ -236,18 +240,18 @@ class Index:
 
     # ---- device-pointer forms (torch tensors / raw pointers), used by bench.py ----
     @classmethod
-    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None):
+    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None, coarse_order=False):
         self = cls.__new__(cls)
         self._lib = _capi.load()
         self._h = C.c_void_p(None)
         self.device = device
         self.n_in = n
-        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid), device,
+        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid, coarse_order), device,
                                               C.c_void_p(stream) if stream else None, C.byref(self._h)))
         return self
 
-    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None):
-        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid)))
+    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None, coarse_order=False):
+        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid, coarse_order)))
         self.n_in = n
 
     def knn_self_dev(self, k, eps, d_idx, d_cnt, d_d2=None, first=0, count=_capi.UINT64_MAX):

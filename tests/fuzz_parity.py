@@ -47,9 +47,10 @@ while time.time() < t_end:
     n = len(pts)
     k = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 31, 32, 33, 40, 70]))
     eps = float(rng.choice([1e-5, 0.0, 1e-3, 1e-7]))
-    ix = pkg.Index(pts)
+    coarse = bool(rng.integers(0, 2))  # PCPX_BUILD_COARSE_ORDER: same results by contract
+    ix = pkg.Index(pts, coarse_order=coarse)
     sel = rng.choice(n, size=min(n, 300), replace=False)
-    what = {"n": n, "kind": kind, "k": k, "eps": eps, "seed": seed, "case": cases}
+    what = {"n": n, "kind": kind, "k": k, "eps": eps, "coarse_order": coarse, "seed": seed, "case": cases}
     print("case", json.dumps(what), flush=True)  # so that a hang names its case
     try:
         idx, cnt = ix.knn_self(k, eps)[:2]

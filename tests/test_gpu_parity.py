@@ -437,6 +437,33 @@ def test_rows_in_curve_order_equal_rows_in_input_order(pkg, n, k):
     ix.close()
 
 
+def test_coarse_order_build_gives_the_same_results(pkg):
+    """PCPX_BUILD_COARSE_ORDER (top-level buckets sorted only as deep as their size asks for) changes the order of points inside small
+    cells, never a query result: rows, distances, counts and normals equal the default build's bit for bit, on a uniform and on a
+    clustered cloud, through creation and through an in-place rebuild; arbitrary query batches too (their seeds are looked up in the
+    coarser order)."""
+    for pts in (pkg.synthetic.uniform_cloud(300_000, 5), pkg.synthetic.clustered_cloud(300_000, seed=6)):
+        a = pkg.Index(pts)
+        b = pkg.Index(pts, coarse_order=True)
+        na, ia, ca = a.normals_knn_self(15, want_knn=True)
+        nb, ib, cb = b.normals_knn_self(15, want_knn=True)
+        _, _, da = a.knn_self(15, want_d2=True)
+        _, _, db = b.knn_self(15, want_d2=True)
+        assert np.array_equal(ca, cb) and np.array_equal(da, db)
+        same = np.all(ia == ib, axis=1)
+        assert same.mean() > 0.999  # (rows may differ only where points tie exactly with the k-th distance)
+        assert np.array_equal(na[same].view(np.uint32), nb[same].view(np.uint32))
+        assert np.array_equal(a.range_count_self(0.02), b.range_count_self(0.02))
+        q = np.random.default_rng(9).random((5000, 3), dtype=np.float32)
+        qa, qb = a.knn(q, 9, want_d2=True), b.knn(q, 9, want_d2=True)
+        assert np.array_equal(qa[1], qb[1]) and np.array_equal(qa[2], qb[2])
+        b.rebuild(pts[::-1].copy(), coarse_order=True)
+        nb2, ib2, cb2 = b.normals_knn_self(15, want_knn=True)
+        assert np.array_equal(cb2[::-1], ca)
+        a.close()
+        b.close()
+
+
 def test_sorted_shards_cover_the_cloud(pkg):
     """The per-rank query shards of the multi-GPU path (pcpx_shard_range + *_dev sorted slices): the union
     of the shards' rows equals the single-call result."""
@@ -654,6 +681,18 @@ def test_short_randomised_parity_run():
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "8", "99"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+
+
+def test_randomised_parity_run_on_large_clouds():
+    """tests/fuzz_parity.py in its `big` mode for 60 s with a fixed seed: 1 - 5 M points per case (deep trees, several rounds of
+    query groups per resident wave), six cloud shapes, every entry point against brute force on sampled queries."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "60", "314", "big"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    summary = out.stdout.strip().splitlines()[-1]
+    print(summary)
+    assert '"failures": 0' in summary
 
 
 def test_error_behaviour_of_the_abi(pkg):

@@ -15,6 +15,9 @@ fi
 timeout -k 10 200 python3 tools/rebuild_loop.py 1e7 20 > "$out/rebuild_10m.json" 2> "$out/err.log" && cat "$out/rebuild_10m.json" &&
 timeout -k 10 200 python3 tools/rebuild_loop.py 1e7 20 clustered > "$out/rebuild_10m_clustered.json" 2>> "$out/err.log" && cat "$out/rebuild_10m_clustered.json" &&
 timeout -k 10 300 python3 tools/rebuild_loop.py 5e7 10 > "$out/rebuild_50m.json" 2>> "$out/err.log" && cat "$out/rebuild_50m.json" &&
+timeout -k 10 200 python3 tools/rebuild_loop.py 1e7 20 uniform coarse > "$out/rebuild_10m_coarse.json" 2>> "$out/err.log" && cat "$out/rebuild_10m_coarse.json" &&
+timeout -k 10 200 python3 tools/rebuild_loop.py 1e7 20 clustered coarse > "$out/rebuild_10m_clustered_coarse.json" 2>> "$out/err.log" && cat "$out/rebuild_10m_clustered_coarse.json" &&
+timeout -k 10 300 python3 tools/rebuild_loop.py 5e7 10 uniform coarse > "$out/rebuild_50m_coarse.json" 2>> "$out/err.log" && cat "$out/rebuild_50m_coarse.json" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace10" -- python3 tools/rebuild_loop.py 1e7 10 > "$out/prof10.json" 2>> "$out/err.log" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace50" -- python3 tools/rebuild_loop.py 5e7 5 > "$out/prof50.json" 2>> "$out/err.log" || { echo "failed"; tail -5 "$out/err.log"; exit 1; }
 for t in trace10 trace50; do
