@@ -228,8 +228,11 @@ def host_api_rates(pkg, pts, k):
     idx = np.zeros((n, k), np.uint32)
     cnt = np.zeros(n, np.uint32)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    pos = np.zeros(n, np.uint32)
     out = {}
     for name, fn in (("host_api_normals", lambda: lib.pcpx_normals_knn_self(ix._h, k, 1e-5, vp(nrm), None, None)),
+                     # rows in curve order + the table of positions: finished slices are copied while later ones are computed
+                     ("host_api_rows_curve_order", lambda: lib.pcpx_normals_knn_self_curve_order(ix._h, k, 1e-5, vp(nrm), vp(idx), vp(cnt), None, vp(pos))),
                      ("host_api_rows", lambda: lib.pcpx_normals_knn_self(ix._h, k, 1e-5, vp(nrm), vp(idx), vp(cnt)))):
         for _ in range(3):  # the GPU has idled while the host arrays were made: let its clocks come back up
             capi.check(fn())
@@ -241,6 +244,9 @@ def host_api_rates(pkg, pts, k):
         out[name + "_ms"] = round(best * 1e3, 3)
         out[name + "_mqps"] = round(n / best / 1e6, 1)
     out["host_api_rows_bytes_to_host"] = (12 + 4 * k + 4) * n
+    out["host_api_rows_curve_order_bytes_to_host"] = (12 + 4 * k + 4 + 4) * n
+    for name in ("host_api_rows", "host_api_rows_curve_order"):
+        out[name + "_GBps"] = round(out[name + "_bytes_to_host"] / out[name + "_ms"] / 1e6, 2)
     ix.close()
     return out, nrm, idx
 
@@ -358,14 +364,14 @@ def main():
                     "note": "fused kNN+normals kernel: a tree search, bounded by vector-instruction issue, not by HBM (DESIGN.md "
                             "'Roofline'); achieved = algorithmic bytes / HIP-event time of the launch on its stream, measured in this "
                             "run; traffic = PMC HBM bytes per launch from the committed rocprofv3 --pmc passes of this command "
-                            "(profiles/r02_hbm_traffic.json), null when that file is not for this workload"}
-        traffic_file = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+                            "(profiles/r03_hbm_traffic.json), null when that file is not for this workload"}
+        traffic_file = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
                 if tr.get("workload") == args.workload and world == 1:
                     roofline["traffic"] = tr.get("k_knn_hbm_bytes_per_launch")
-                    roofline["traffic_source"] = "profiles/r02_hbm_traffic.json (separate --pmc passes, not this run)"
+                    roofline["traffic_source"] = "profiles/r03_hbm_traffic.json (separate --pmc passes, not this run)"
                     roofline["hbm_measured_GBps"] = round(roofline["traffic"] / avg_s / 1e9, 1)
                     roofline["hbm_measured_frac"] = round(roofline["traffic"] / avg_s / HBM_PEAK, 5)
             except Exception:

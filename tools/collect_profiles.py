@@ -4,7 +4,7 @@ usage: tools/collect_profiles.py r01"""
 import glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -19,8 +19,12 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("bench_uniform_10m_k8.json", "bench_uniform_10m_k8.json"),
                   ("bench_c5_50m_k32_stream.json", "bench_c5_50m_k32_stream.json"), ("pcie_inclusive.json", "pcie_inclusive.json"),
                   ("batch_query_rate.json", "batch_query_rate.json"), ("latency.json", "latency.json"),
-                  ("shard_rate.json", "shard_rate.json"), ("pcie_rate.json", "pcie_rate.json"),
+                  ("shard_rate.json", "shard_rate.json"), ("shard_rate_clustered.json", "shard_rate_clustered_10m_k15.json"),
+                  ("shard_rate_c5.json", "shard_rate_c5_50m_k32_stream.json"), ("pcie_rate.json", "pcie_rate.json"),
                   ("rebuild_10m.json", "rebuild_10m.json"), ("rebuild_50m.json", "rebuild_50m.json"),
+                  ("rebuild_10m_clustered.json", "rebuild_10m_clustered.json"), ("rebuild_10m_coarse.json", "rebuild_10m_coarse_order.json"),
+                  ("rebuild_50m_coarse.json", "rebuild_50m_coarse_order.json"),
+                  ("pmc_range/range_kernel_stats.txt", "range_kernel_stats.txt"), ("pmc_range/range_under_prof.json", "range_count_10m.json"),
                   ("valu_issue_rates.txt", "valu_issue_rates.txt"), ("filter_bench.json", "filter_bench.json"),
                   ("fuzz_filters.json", "fuzz_filters.json")):
     if os.path.exists(os.path.join(src, name)):
@@ -38,6 +42,20 @@ if rstats:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), rstats[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rebuild_kernel_stats.txt"), "w").write(
         "rocprofv3 --kernel-trace --stats -- python3 tools/rebuild_loop.py 1e7 10   (12 rebuilds of 10 M points, auto bounding box)\n" + txt)
+r50 = sorted(glob.glob(os.path.join(src, "trace_rebuild50", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+if r50:
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), r50[0]], capture_output=True, text=True).stdout
+    open(os.path.join(dst, tag + "_rebuild_50m_kernel_stats.txt"), "w").write(
+        "rocprofv3 --kernel-trace --stats -- python3 tools/rebuild_loop.py 5e7 5   (7 rebuilds of 50 M points, auto bounding box)\n" + txt)
+for sub, name in (("pmc_rebuild", "pmc_rebuild"), ("pmc_range", "pmc_range")):
+    f = os.path.join(src, sub, "pmc_summary.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        keep = {k: {c: round(v["avg_per_dispatch"], 1) for c, v in cs.items()} for k, cs in d.items() if k.startswith("k_")}
+        json.dump({"command": "tools/%s.sh: rocprofv3 --kernel-trace --pmc <one counter group per pass> (averages per dispatch; FETCH_SIZE / WRITE_SIZE in KB)" % sub,
+                   "fetch_size_rule": "bytes read = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM: gfx950 tallies 128-B requests at 64 B); calibrated here on "
+                                      "k_bbox, which reads exactly 12 B per point: 120 MB at 10 M points against FETCH_SIZE = 58.8 MB",
+                   "counters": keep}, open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w"), indent=1)
 fstats = sorted(glob.glob(os.path.join(src, "trace_filter", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
 if fstats:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), fstats[0]], capture_output=True, text=True).stdout
@@ -47,7 +65,8 @@ if fstats:
 pmc = os.path.join(src, "pmc", "pmc_summary.json")
 if os.path.exists(pmc):
     shutil.copyfile(pmc, os.path.join(dst, tag + "_pmc_summary.json"))
-    d = json.load(open(pmc)).get("k_knn", {})
+    allk = json.load(open(pmc))
+    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,false,false") or k == "k_knn"), {})
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"]["avg_per_dispatch"], d["WRITE_SIZE"]["avg_per_dispatch"]
         json.dump({
@@ -56,10 +75,10 @@ if os.path.exists(pmc):
             "command": "tools/pmc_passes.sh: rocprofv3 --kernel-trace --pmc <one counter group per pass> --output-format csv -- "
                        "python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 (FETCH_SIZE in pass 3, WRITE_SIZE in pass 4)",
             "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
-            "correction": "MI355X_MICROARCH.md section HBM: bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, and on gfx950 FETCH_SIZE reports "
-                          "1/2 of the bytes of a wide coalesced read, so the read side is doubled; this kernel's reads are 32-128 B "
-                          "scalar loads and 4-B gathers, an access shape the guide marks uncalibrated, so the doubled figure is an "
-                          "upper estimate",
+            "correction": "one rule for every kernel of this repository: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM: "
+                          "gfx950 tallies 128-B read requests at 64 B), calibrated on k_bbox, which reads exactly 120 MB at 10 M points and "
+                          "reports FETCH_SIZE = 58.8 MB (profiles/%s_pmc_rebuild.json); this kernel's reads are 32-128 B scalar loads and "
+                          "4-B gathers, for which the factor is not separately calibrated: an upper estimate" % tag,
             "k_knn_hbm_bytes_per_launch": int((2 * f + w) * 1024),
             "k_knn_hbm_bytes_per_launch_uncorrected": int((f + w) * 1024),
             "algorithmic_bytes_per_launch": 84 * 10_000_000}, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
