@@ -188,6 +188,7 @@ class device_index_t
     // returned is unspecified (the cached rows come from the throughput kernel, an uncached call from the latency
     // kernel).  The same is done for sphere ranges of one radius.  If the one-off batch fill fails (out of memory, a device
     // error) the cache is marked failed and every later call takes the single-query path: the failure is not retried.
+    static constexpr std::size_t single_range_room = 256;  // indices a single-range call offers up front
     static constexpr unsigned batch_after         = 16;
     static constexpr std::uint64_t max_cache_ints = 1ull << 28;  // 1 GiB of indices at most
 
@@ -330,8 +331,9 @@ class device_index_t
                        std::vector<std::uint32_t>& idx) const
     {
         off.assign(static_cast<std::size_t>(n) + 1, 0);
-        idx.clear();
-        int st = pcpx_range_sphere_batch(h_, centers, radii, 0.f, n, off.data(), nullptr, 0);
+        idx.assign(n == 1 ? single_range_room : 0, 0u);  // (one range: room for a typical result, so that one call -- one launch -- does it)
+        int st = pcpx_range_sphere_batch(h_, centers, radii, 0.f, n, off.data(), idx.empty() ? nullptr : idx.data(), idx.size());
+        if (st == PCPX_OK) idx.resize(static_cast<std::size_t>(off[n]));
         if (st == PCPX_ERR_CAPACITY)
         {
             idx.resize(static_cast<std::size_t>(off[n]));
@@ -342,8 +344,9 @@ class device_index_t
     void range_boxes(float const* boxes6, std::uint64_t n, std::vector<std::uint64_t>& off, std::vector<std::uint32_t>& idx) const
     {
         off.assign(static_cast<std::size_t>(n) + 1, 0);
-        idx.clear();
-        int st = pcpx_range_aabb_batch(h_, boxes6, n, off.data(), nullptr, 0);
+        idx.assign(n == 1 ? single_range_room : 0, 0u);
+        int st = pcpx_range_aabb_batch(h_, boxes6, n, off.data(), idx.empty() ? nullptr : idx.data(), idx.size());
+        if (st == PCPX_OK) idx.resize(static_cast<std::size_t>(off[n]));
         if (st == PCPX_ERR_CAPACITY)
         {
             idx.resize(static_cast<std::size_t>(off[n]));

@@ -730,6 +730,41 @@ int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float
     return PCPX_OK;
 }
 
+// One sphere / one box per call: the latency form (pcpx_range.hip: k_range_one) through the handle's pinned stage.  Returns
+// PCPX_OK / PCPX_ERR_CAPACITY like the batch form, or +1 when the range holds more than the stage does (caller: batch form).
+constexpr u32 RANGE_ONE_CAP = 4096;
+static int range_one_to_host(Index* ix, bool aabb, const float* range6, uint64_t* out_offsets, uint32_t* out_idx, uint64_t idx_capacity)
+{
+    int st;
+    const size_t o_done = 0, o_range = 64, o_cnt = 128, o_idx = 192, total = o_idx + RANGE_ONE_CAP * sizeof(u32);
+    const bool fresh = ix->pinned.bytes < total;
+    if ((st = ix->pinned.ensure(total)) != PCPX_OK) return st;
+    char* stage = static_cast<char*>(ix->pinned.p);
+    volatile u32* done = reinterpret_cast<volatile u32*>(stage + o_done);
+    if (fresh) *done = 0u;
+    std::memcpy(stage + o_range, range6, (aabb ? 6 : 4) * sizeof(float));
+    const u32 epoch = ++ix->few_epoch ? ix->few_epoch : ++ix->few_epoch;  // never 0 (shared with the k-NN latency path: same word)
+    if ((st = launch_range_one(*ix, aabb, reinterpret_cast<const float*>(stage + o_range), RANGE_ONE_CAP, reinterpret_cast<u32*>(stage + o_idx),
+                               reinterpret_cast<u32*>(stage + o_cnt), const_cast<u32*>(done), epoch)) != PCPX_OK)
+        return st;
+    bool seen = false;
+    if (!g_few_no_poll)
+        for (u32 spin = 0; spin < 400000u && !seen; ++spin) seen = *done == epoch;
+    if (!seen) PCPX_HIP(hipStreamSynchronize(ix->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const u32 cnt = *reinterpret_cast<const volatile u32*>(stage + o_cnt);
+    if (cnt > RANGE_ONE_CAP) return 1;
+    out_offsets[0] = 0;
+    out_offsets[1] = cnt;
+    if (cnt == 0) return PCPX_OK;
+    if (!out_idx || idx_capacity < cnt) {
+        set_error("pcpx range search: need room for %u indices", cnt);
+        return PCPX_ERR_CAPACITY;
+    }
+    std::memcpy(out_idx, stage + o_idx, cnt * sizeof(u32));
+    return PCPX_OK;
+}
+
 int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radii, float radius, uint64_t nq,
                             uint64_t* out_offsets, uint32_t* out_idx, uint64_t idx_capacity)
 {
@@ -743,6 +778,11 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
     if (nq == 0) {
         out_offsets[0] = 0;
         return PCPX_OK;
+    }
+    if (nq == 1) {  // the per-call shape of the reference's API: one launch through the pinned stage
+        const float sphere[4] = {q_xyz[0], q_xyz[1], q_xyz[2], radii ? radii[0] : radius};
+        st = range_one_to_host(ix, false, sphere, out_offsets, out_idx, idx_capacity);
+        if (st != 1) return st;
     }
     DevBuf dq(ix->pool), dr(ix->pool), dc(ix->pool), doff(ix->pool), dout(ix->pool);
     if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
@@ -789,6 +829,10 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
     if (nb == 0) {
         out_offsets[0] = 0;
         return PCPX_OK;
+    }
+    if (nb == 1) {
+        st = range_one_to_host(ix, true, boxes6, out_offsets, out_idx, idx_capacity);
+        if (st != 1) return st;
     }
     DevBuf db(ix->pool), dc(ix->pool), doff(ix->pool), dout(ix->pool);
     if ((st = db.alloc(nb * 6 * sizeof(float))) != PCPX_OK) return st;

@@ -258,6 +258,7 @@ int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_firs
                        const float* d_radii, u32* d_out_cnt);
 int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,
                       u32* d_out_idx);
+int launch_range_one(Index& ix, bool aabb, const float* range, u32 cap, u32* out_idx, u32* out_cnt, u32* done_flag, u32 epoch);
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt);
 int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx);
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,

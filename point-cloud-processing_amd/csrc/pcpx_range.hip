@@ -122,7 +122,62 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
     if (valid && !FILL) out_cnt[p] = cnt;
 }
 
+// ONE range, latency form (the reference's per-call shape: benchmark/spatial_data_structures_benchmark.cpp:169-213): a single
+// wavefront walks the tree for the one range (every lane holds the same range, so the wave-uniform walk is the range's own), lane
+// j < 8 tests point j of a leaf, matches are appended in walk order through a ballot.  The range, the count and up to `cap` indices
+// live in the handle's pinned stage (host memory the device reads and writes in place), and the host polls the completion word:
+// one launch, no copy, no stream synchronisation -- the count / scan / fill sequence of the batch form is two launches and two
+// synchronisations (41 us per call for a range that holds a handful of points).
+template <bool AABB>
+__global__ __launch_bounds__(64) void k_range_one(TreeView t, const float* __restrict__ range, u32 cap, u32* __restrict__ out_idx,
+                                                  u32* __restrict__ out_cnt, u32* __restrict__ done_flag, u32 epoch)
+{
+    const u32 lane = threadIdx.x;
+    const float a0 = range[0], a1 = range[1], a2 = range[2], a3 = range[3], a4 = AABB ? range[4] : 0.f, a5 = AABB ? range[5] : 0.f;
+    const float r2 = a3 * a3;  // sphere.hpp:34 radius * radius in float
+    auto need = [&](const NodeBox& b) -> bool {
+        if (AABB) return (b.hi[0] >= a0) & (b.hi[1] >= a1) & (b.hi[2] >= a2) & (b.lo[0] <= a3) & (b.lo[1] <= a4) & (b.lo[2] <= a5) & (b.poison == 0.f);
+        return box_d2(b, a0, a1, a2) <= r2;
+    };
+    u32 cnt = 0;
+    Walker wk;
+    u32 leaf = 0, nexp = 0;
+    bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
+    if (!more) more = wk.next(t, need, leaf, nexp);
+    while (more) {
+        bool in = false;
+        u32 id = 0;
+        if (lane < static_cast<u32>(LEAF)) {
+            const Leaf& lf = t.leaves[leaf];
+            const float x = lf.x[lane], y = lf.y[lane], z = lf.z[lane];  // (NaN padding fails every comparison below)
+            id = lf.id[lane];
+            if (AABB) {
+                in = (x >= a0) & (y >= a1) & (z >= a2) & (x <= a3) & (y <= a4) & (z <= a5);
+            } else {
+                const float dx = x - a0, dy = y - a1, dz = z - a2;
+                in = sq3(dx, dy, dz) <= r2;
+            }
+        }
+        const u64 m = __builtin_amdgcn_ballot_w64(in);
+        const u32 at = cnt + __builtin_amdgcn_mbcnt_lo(static_cast<u32>(m), 0u);  // (only lanes 0..7 can be set)
+        if (in && at < cap) out_idx[at] = id;
+        cnt += static_cast<u32>(__builtin_popcountll(m));
+        more = wk.next(t, need, leaf, nexp);
+    }
+    if (lane == 0) *out_cnt = cnt;
+    __threadfence_system();  // the row and the count are visible to the host before the completion word
+    if (lane == 0) __hip_atomic_store(done_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+int launch_range_one(Index& ix, bool aabb, const float* range, u32 cap, u32* out_idx, u32* out_cnt, u32* done_flag, u32 epoch)
+{
+    ProfileScope prof(ix, PCPX_K_RANGE);
+    if (aabb) k_range_one<true><<<1, 64, 0, ix.stream>>>(ix.view(), range, cap, out_idx, out_cnt, done_flag, epoch);
+    else k_range_one<false><<<1, 64, 0, ix.stream>>>(ix.view(), range, cap, out_idx, out_cnt, done_flag, epoch);
+    return check_hip(hipGetLastError(), "k_range_one launch", __FILE__, __LINE__);
+}
 
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
                        const float* d_radii, u32* d_out_cnt)

@@ -288,6 +288,34 @@ def test_range_count_and_lists(pkg, oracle, n, r):
         assert sorted(idx[off[i]:off[i + 1]].tolist()) == sorted(tree.range_sphere(q[i], r).tolist())
 
 
+def test_single_range_calls_take_the_latency_path_and_agree(pkg, oracle):
+    """One sphere or one box per call (the shape of the reference's range_search and of its benchmark) goes through a one-wavefront
+    kernel and the pinned stage; the lists equal the batch form's, in the same order, for empty results, ordinary ones, and ones
+    larger than the stage (4 096 indices: the call falls back to the batch form)."""
+    rng = np.random.default_rng(17)
+    pts = rng.random((60000, 3), dtype=np.float32)
+    ix = pkg.Index(pts)
+    centers = rng.random((24, 3), dtype=np.float32)
+    centers[0] = [5, 5, 5]  # nothing there
+    for r in (0.0, 0.02, 0.3):  # 0.3: ~6 800 points per sphere, more than the stage holds
+        off, idx = ix.range_sphere(centers, r)
+        for i in range(len(centers)):
+            o1, i1 = ix.range_sphere(centers[i:i + 1], r)
+            assert int(o1[1]) == int(off[i + 1] - off[i])
+            assert np.array_equal(i1, idx[int(off[i]):int(off[i + 1])])
+    half = np.array([0.01, 0.05, 0.4], np.float32)
+    for h in half:
+        boxes = np.concatenate([centers - h, centers + h], axis=1).astype(np.float32)
+        off, idx = ix.range_aabb(boxes)
+        for i in range(len(boxes)):
+            o1, i1 = ix.range_aabb(boxes[i:i + 1])
+            assert int(o1[1]) == int(off[i + 1] - off[i])
+            assert np.array_equal(i1, idx[int(off[i]):int(off[i + 1])])
+    one = pkg.Index(pts[:1])  # a one-point index: the root is the only leaf
+    o1, i1 = one.range_sphere(pts[:1], 0.1)
+    assert list(i1) == [0] and int(o1[1]) == 1
+
+
 def test_ranges_wider_than_one(pkg, oracle):
     """radius > 1, the one place where results knowingly differ from the reference: its box-sphere test compares the SQUARED
     distance with `radius` (include/pcp/common/intersections.hpp:87-102, :113-130), so its trees prune boxes between
