@@ -85,7 +85,6 @@ __device__ __forceinline__ P lds_ptr(T* generic)
 }
 
 // exclusive scan of v over the 256 threads of the block (thread order); `wtot` is 4 words of LDS
-template <bool LEAD = true>
 __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* wtot, u32& total)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -95,7 +94,7 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* wtot, u32& total
         const u32 up = __shfl_up(incl, off);
         if (lane >= static_cast<u32>(off)) incl += up;
     }
-    if (LEAD) __syncthreads();  // (wtot may still be in use by an earlier scan)
+    __syncthreads();  // (wtot may still be in use by an earlier scan)
     if (lane == 63) wtot[w] = incl;
     __syncthreads();
     u32 before = 0, all = 0;
@@ -109,8 +108,7 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* wtot, u32& total
     return before + incl - v;
 }
 
-// two scans at once; LEAD = false: the caller guarantees that nobody still reads wtot2 from an earlier scan (one barrier less)
-template <bool LEAD = true>
+// two scans at once (one pair of barriers)
 __device__ __forceinline__ void block_exclusive_scan2(u32 va, u32 vb, u32* wtot2, u32& ea, u32& eb)
 {
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -123,7 +121,7 @@ __device__ __forceinline__ void block_exclusive_scan2(u32 va, u32 vb, u32* wtot2
             ib += ub;
         }
     }
-    if (LEAD) __syncthreads();
+    __syncthreads();
     if (lane == 63) {
         wtot2[w] = ia;
         wtot2[SORT_WAVES + w] = ib;
@@ -303,22 +301,15 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
     if (tile >= ntiles) break;
     TilePlace tp;
     if (SEG) {
-        // the bucket of the tile: the one bucket of this pass with tile_first[b] <= tile < tile_first[b + 1].  Every wave finds
-        // it for itself (a lane looks at four buckets, a ballot names the lane that holds it): no LDS, no barrier.
-        u32 mine = RADIX, mine_first = 0;
-#pragma unroll
-        for (int j = 0; j < RADIX / 64; ++j) {
-            const u32 bkt = lane * (RADIX / 64) + j;
-            const u32 f0 = my_tile_first[bkt], f1 = my_tile_first[bkt + 1];
-            if (f0 <= tile && tile < f1) {
-                mine = bkt;
-                mine_first = f0;
-            }
+        // the bucket of the tile: the one bucket of this pass with tile_first[b] <= tile < tile_first[b + 1]
+        const u32 f0 = my_tile_first[tid], f1 = my_tile_first[tid + 1];
+        if (f0 <= tile && tile < f1) {
+            place_s[1] = tid;
+            place_s[2] = f0;
         }
-        const u64 who = __builtin_amdgcn_ballot_w64(mine != static_cast<u32>(RADIX));
-        const int src = static_cast<int>(__builtin_ctzll(who | (1ull << 63)));  // (exactly one lane; the guard keeps ctz defined)
-        tp.bucket = __builtin_amdgcn_readlane(mine, src);
-        tp.floor = __builtin_amdgcn_readlane(mine_first, src);
+        __syncthreads();
+        tp.bucket = place_s[1];
+        tp.floor = place_s[2];
         const u32 s0 = seg->start[tp.bucket], s1 = seg->start[tp.bucket + 1];
         tp.lo = s0 + (tile - tp.floor) * SORT_TILE;
         tp.hi = s1 - tp.lo < static_cast<u32>(SORT_TILE) ? s1 : tp.lo + SORT_TILE;
@@ -379,12 +370,11 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
         // L2-resident words, instead of a launch of its own between the count and the first pass)
         u32 tb, dbase;
         if (SEG) {
-            // (wtot's last readers are two barriers back, in the previous tile)
-            block_exclusive_scan2<false>(local, seg_hist[static_cast<size_t>(tp.bucket) * ((MAX_PASSES - 1) * RADIX) + d], wtot, tb, dbase);
+            block_exclusive_scan2(local, seg_hist[static_cast<size_t>(tp.bucket) * ((MAX_PASSES - 1) * RADIX) + d], wtot, tb, dbase);
             dbase += seg->start[tp.bucket];
         } else {
             u32 unused = 0;
-            tb = block_exclusive_scan<false>(local, wtot, unused);
+            tb = block_exclusive_scan(local, wtot, unused);
             dbase = seg->start[d] + tile_prefix[static_cast<size_t>(tile) * RADIX + d];
         }
         {
