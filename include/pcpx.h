@@ -305,6 +305,11 @@ typedef struct pcpx_profile {
  * followed (capacity permitting) by {start, end (100 MHz ticks), groups done, slowest group ticks, its id}
  * of every persistent wave. */
 int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t* out_stats, uint64_t capacity);
+/* Where the throughput kNN kernel (k <= 32) applies the reference's eps-box exclusion
+ * (include/pcp/common/vector3d_queries.hpp:47-64): 0 = chosen per launch from eps and the cloud's point spacing (the
+ * default), 1 = on buffered keys when they are folded into the best-list, 2 = on every candidate.  Results are the same;
+ * the tests run all three. */
+int pcpx_debug_eps_test_mode(pcpx_index* idx, int mode);
 /* Diagnostic access to the build's radix sort: stable sort of 64-bit words by their bits [first_bit, 64)
  * (first_bit a multiple of 8): words that agree on those bits keep their input order. */
 int pcpx_debug_sort_keys(const uint64_t* keys, uint64_t n, int first_bit, int device, uint64_t* out_keys);

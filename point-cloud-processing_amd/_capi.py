@@ -109,6 +109,7 @@ SIGNATURES = {
     "pcpx_comm_global_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, f32p]),
     "pcpx_index_synchronize": (C.c_int, [C.c_void_p]),
     "pcpx_debug_knn_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, u64p, C.c_uint64]),
+    "pcpx_debug_eps_test_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pcpx_debug_sort_keys": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),
     "pcpx_profile_begin": (C.c_int, [C.c_void_p]),
     "pcpx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),

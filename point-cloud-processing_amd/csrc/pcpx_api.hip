@@ -1130,6 +1130,18 @@ int pcpx_estimate_normals_batch(const float* xyz, const uint64_t* offsets, uint6
     return PCPX_OK;
 }
 
+int pcpx_debug_eps_test_mode(pcpx_index* h, int mode)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    if (!ix || mode < 0 || mode > 2) {
+        set_error("pcpx_debug_eps_test_mode: mode is 0 (automatic), 1 (in the compaction) or 2 (per candidate)");
+        return PCPX_ERR_INVALID;
+    }
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    ix->eps_test_mode = mode;
+    return PCPX_OK;
+}
+
 int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_stats, uint64_t capacity)
 {
     Index* ix = reinterpret_cast<Index*>(h);

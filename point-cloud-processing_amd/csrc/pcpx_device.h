@@ -48,6 +48,26 @@ struct NodeBox4 {
     NodeBox c[W];
 };
 
+// The four child boxes of a node as two 64-byte scalar loads.  (From load_const hipcc fetches only the seven used words of
+// each box -- x4 + x2 + x1: twelve SMEM instructions per expansion, and the scalar side of the query kernels is as loaded
+// as their vector side.)  The wait is part of the statement: the compiler does not count loads it cannot see.
+__device__ __forceinline__ NodeBox4 load_node4(const NodeBox* first_child)
+{
+    typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 a, b;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b)
+                 : "s"(first_child));
+    NodeBox4 out;
+    u32* o = reinterpret_cast<u32*>(&out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        o[i] = a[i];
+        o[16 + i] = b[i];
+    }
+    return out;
+}
+
 __device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
 // Index records (leaves, node boxes) are immutable while a query kernel runs.  Reading them through
@@ -80,7 +100,10 @@ __device__ __forceinline__ u32 lds_address(const void* p)
 // depth-first walk always continues with the LOWEST set bit of pend, so popping is one find-first-set: no
 // per-level loop.  `ploc` is the level-local index of the ancestor of height l+1 (node ids are never
 // stored: heap id = (4^d - 1)/3 + local index at tree level d, and a leaf's local index is its number).
-struct Walker {
+// X16: the child boxes come as two 64-byte loads (load_node4) -- fewer scalar instructions, four more SGPRs at once; the
+// kernel picks (k_knn for k <= 8, at 8 waves per SIMD, is faster without).
+template <bool X16>
+struct WalkerT {
     u64 pend;
     u32 ploc;
     int l;
@@ -93,16 +116,15 @@ struct Walker {
     __device__ __forceinline__ u32 child_mask(const TreeView& t, int d, u32 loc, Need&& need)
     {
         const u32 first_child = level_base(d + 1) + (loc << LOGW);  // heap id of child 0
-        const NodeBox4 cb = load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
-        // the mask is built on the scalar unit (left to itself hipcc makes it a vector value: v_cndmask, three v_or and a
-        // v_readfirstlane per expansion; the vector ALU is the saturated unit, the scalar one is not)
+        const NodeBox4 cb = X16 ? load_node4(t.nodes + first_child) : load_const(reinterpret_cast<const NodeBox4*>(t.nodes + first_child));
+        // the mask is built on the scalar unit, two instructions per child: "some lane needs it" goes to SCC and is shifted
+        // into the mask with an add-with-carry (children in reverse order, so child 0 ends up in bit 0).  (Left to itself hipcc
+        // makes the mask a vector value: v_cndmask, three v_or and a v_readfirstlane per expansion.)
         u32 m = 0;
 #pragma unroll
-        for (int c = 0; c < W; ++c) {
+        for (int c = W - 1; c >= 0; --c) {
             const u64 lanes = __builtin_amdgcn_ballot_w64(need(cb.c[c]));
-            u32 bit;
-            asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(bit) : "s"(lanes), "n"(1 << c) : "scc");
-            m |= bit;
+            asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(m) : "s"(lanes) : "scc");
         }
         return m;
     }
@@ -146,6 +168,7 @@ struct Walker {
         return false;
     }
 };
+using Walker = WalkerT<true>;
 
 inline u32 grid_for_groups(u64 groups)
 {

@@ -182,6 +182,7 @@ struct Index {
     DevPool pool;        // staging buffers of the host-pointer entry points
     PinnedStage pinned;  // small-transfer staging
     u32 few_epoch = 0;   // launch counter of the latency path (its completion flag carries the epoch)
+    int eps_test_mode = 0;  // k_knn's eps-box test: 0 = where it is cheaper (query.hip: eps_box_threshold), 1 = in the compaction, 2 = per candidate
 
     u64* sorted_codes() const { return d_codes[1]; }
     u32* perm() const { return d_perm; }

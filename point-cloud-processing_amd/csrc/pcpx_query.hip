@@ -44,6 +44,15 @@ namespace {
 
 constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID): larger than every real key, a finite double
 
+// PAD_KEY in a fresh register pair: for the stores that refill buffer rows.  (As a plain constant hipcc hoists the pair out of
+// the persistent loop and, short of registers, parks it in scratch: two v_mov where they are needed are cheaper.)
+__device__ __forceinline__ u64 pad_key_here()
+{
+    u32 lo = static_cast<u32>(PAD_KEY), hi = static_cast<u32>(PAD_KEY >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (static_cast<u64>(hi) << 32) | lo;
+}
+
 // ---- selection network on 64-bit keys -------------------------------------------------------------
 // Keys are (float32 d2 >= 0 bits) << 32 | u32: as IEEE doubles they are finite, non-negative and
 // ordered like the integers, so min/max of the doubles is the integer compare-exchange in 2 VALU ops
@@ -163,8 +172,66 @@ __device__ __forceinline__ void static_for(F&& f)
 // Invariant of the chunked path: every buffer slot that holds no key holds PAD_KEY (k_knn fills the rows once per
 // wave, a compaction writes PAD_KEY back into the rows it has read) -- so rows are read unconditionally and need no
 // masking by cnt: 8 LDS writes per chunk instead of 32 VALU instructions, and the vector ALU is the saturated unit.
+// The eps-box test (a candidate inside the box |d.| < eps on all three axes is not a neighbour:
+// include/pcp/common/vector3d_queries.hpp:47-64) can wait for the compaction: a point inside the box has d2 < thr
+// = 3 eps^2 (1 + 1e-6), so only buffered keys below thr need the exact test, and after the chunk is sorted they are its
+// first ones.  Self queries meet exactly one such key per lane (the query point itself), so two or three of a group's
+// ~44 compactions take the slow path below, against a v_max3 + v_cmpx for each of its ~780 candidates.  A key that fails
+// never reaches best[]: tau only ever comes from neighbours.  `on` is wave-uniform (launch-uniform, in fact).
+#ifndef PCPX_DEFER_EPS
+#define PCPX_DEFER_EPS 1
+#endif
+#ifndef PCPX_APPEND4
+#define PCPX_APPEND4 1
+#endif
+#ifndef PCPX_TOUCH_AHEAD
+#define PCPX_TOUCH_AHEAD 0
+#endif
+#ifndef PCPX_TWO_PHASE_HALF
+#define PCPX_TWO_PHASE_HALF 4
+#endif
+#ifndef PCPX_TWO_PHASE
+#define PCPX_TWO_PHASE 0  // leaf loop of the deferred form: 1 = masks first, LDS writes only for candidates some lane accepts; 2 = skip per leaf only; 0 = v_cmpx per candidate
+#endif
+struct EpsFilter {
+    bool on;
+    float thr, eps, qx, qy, qz;
+    const Leaf* leaves;
+};
+__device__ __forceinline__ float key_d2(u64 key) { return __uint_as_float(static_cast<u32>(key >> 32)); }
+
+// nw[0 .. 8) ascending, read from rows r0 .. r0 + R of the column (which hold PAD_KEY again): drop the keys inside the eps-box
+template <int R>
+__device__ __forceinline__ void drop_eps_box(u64 (&nw)[8], u64* __restrict__ col_r0, const EpsFilter& f)
+{
+    if (!any_lane(key_d2(nw[0]) < f.thr)) return;  // (PAD_KEY: d2 = +inf)
+    // back into the rows in ascending order (the real keys of the chunk are at most R and come first): the loop below is
+    // rare and runs on LDS so that it costs the compaction no registers
+#pragma unroll
+    for (int j = 0; j < R; ++j) col_r0[j * 64] = nw[j];
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+        const u64 key = col_r0[j * 64];
+        const bool near = key_d2(key) < f.thr;
+        if (!any_lane(near)) break;  // ascending: none of the later keys either
+        if (near) {
+            const u32 ps = static_cast<u32>(key);
+            const Leaf& lf = f.leaves[ps / LEAF];
+            const float dx = lf.x[ps % LEAF] - f.qx, dy = lf.y[ps % LEAF] - f.qy, dz = lf.z[ps % LEAF] - f.qz;
+            const float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+            if (!(m >= f.eps)) col_r0[j * 64] = pad_key_here();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nw[j] = j < R ? col_r0[j * 64] : PAD_KEY;
+    const u64 pad = pad_key_here();
+#pragma unroll
+    for (int j = 0; j < R; ++j) col_r0[j * 64] = pad;
+    bitonic_sort<8>(nw);
+}
+
 template <int KCAP, int BUF>
-__device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt)
+__device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt, const EpsFilter& f)
 {
     static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 8, "rows");
     {   // (tried: a third tier that reads and sorts only 4 keys when no lane holds more -- 47 % of the compactions: the
@@ -172,9 +239,11 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         u64 nw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
+        const u64 pad = pad_key_here();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) col[j * 64] = PAD_KEY;
+        for (int j = 0; j < 8; ++j) col[j * 64] = pad;
         bitonic_sort<8>(nw);
+        if (f.on) drop_eps_box<8>(nw, col, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
         bitonic_merge<KCAP>(best);
@@ -183,9 +252,11 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         u64 nw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) nw[j] = 8 + j < BUF ? col[(8 + j) * 64] : PAD_KEY;
+        const u64 pad = pad_key_here();
 #pragma unroll
-        for (int j = 8; j < BUF; ++j) col[j * 64] = PAD_KEY;
+        for (int j = 8; j < BUF; ++j) col[j * 64] = pad;
         bitonic_sort<8>(nw);
+        if (f.on) drop_eps_box<(BUF > 8 ? BUF - 8 : 1)>(nw, col + 8 * 64, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
         bitonic_merge<KCAP>(best);
@@ -250,6 +321,76 @@ __device__ __forceinline__ void append_if(float d2, float tau, float dx, float d
                  : [wa] "+v"(wa), [pos] "+v"(pos)
                  : [d2] "v"(d2), [tau] "v"(tau), [m] "v"(m), [eps] "s"(eps), [sv] "s"(saved)
                  : "vcc", "memory");
+}
+
+// The same without the eps-box test (EpsFilter: it waits for the compaction).
+__device__ __forceinline__ void append_if_within(float d2, float tau, u32& pos, u32& wa, u64 saved)
+{
+    asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                 "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                 "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_u32_e32 %[pos], 1, %[pos]"
+                 : [wa] "+v"(wa), [pos] "+v"(pos)
+                 : [d2] "v"(d2), [tau] "v"(tau), [sv] "s"(saved)
+                 : "vcc", "memory");
+}
+// Four candidates of a leaf in one statement: distances (dx*dx + dy*dy + dz*dz, three roundings as in norm.hpp) and the
+// exec-masked append of each.  One statement, because between two asm statements of which the second reads a register the
+// first writes hipcc puts an s_nop (seven per leaf with one statement per candidate), and because it would otherwise compute
+// all eight distances first: the scalar side of this kernel is as loaded as its vector side, and the registers are the
+// best-list's.  `pos` steps by one per candidate for every lane; NaN padding points fail d2 <= tau.
+__device__ __forceinline__ void append4_if_within(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                  float qx, float qy, float qz, float tau, u32& pos, u32& wa, u64 saved)
+{
+    float a, b, c;
+#define PCPX_CAND(J)                                                  \
+    "v_sub_f32_e32 %[a], %[x" #J "], %[qx]\n\t"                       \
+    "v_sub_f32_e32 %[b], %[y" #J "], %[qy]\n\t"                       \
+    "v_sub_f32_e32 %[c], %[z" #J "], %[qz]\n\t"                       \
+    "v_mul_f32_e32 %[a], %[a], %[a]\n\t"                              \
+    "v_mul_f32_e32 %[b], %[b], %[b]\n\t"                              \
+    "v_add_f32_e32 %[a], %[a], %[b]\n\t"                              \
+    "v_mul_f32_e32 %[c], %[c], %[c]\n\t"                              \
+    "v_add_f32_e32 %[a], %[a], %[c]\n\t"                              \
+    "v_cmpx_le_f32_e32 %[a], %[tau]\n\t"                              \
+    "ds_write2_b32 %[wa], %[pos], %[a] offset1:1\n\t"                 \
+    "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"                           \
+    "s_mov_b64 exec, %[sv]\n\t"                                       \
+    "v_add_u32_e32 %[pos], 1, %[pos]\n\t"
+    asm volatile(PCPX_CAND(0) PCPX_CAND(1) PCPX_CAND(2) PCPX_CAND(3)
+                 : [wa] "+v"(wa), [pos] "+v"(pos), [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c)
+                 : [x0] "s"(x[0]), [x1] "s"(x[1]), [x2] "s"(x[2]), [x3] "s"(x[3]), [y0] "s"(y[0]), [y1] "s"(y[1]), [y2] "s"(y[2]),
+                   [y3] "s"(y[3]), [z0] "s"(z[0]), [z1] "s"(z[1]), [z2] "s"(z[2]), [z3] "s"(z[3]), [qx] "v"(qx), [qy] "v"(qy),
+                   [qz] "v"(qz), [tau] "v"(tau), [sv] "s"(saved)
+                 : "vcc", "memory");
+#undef PCPX_CAND
+}
+__device__ __forceinline__ void append_if_within_shell(float d2, float tau, float lo, u32& pos, u32& wa, u64 saved)
+{
+    asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                 "v_cmpx_lt_f32_e32 %[lo], %[d2]\n\t"
+                 "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                 "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_u32_e32 %[pos], 1, %[pos]"
+                 : [wa] "+v"(wa), [pos] "+v"(pos)
+                 : [d2] "v"(d2), [tau] "v"(tau), [lo] "s"(lo), [sv] "s"(saved)
+                 : "vcc", "memory");
+}
+
+// Append under a lane mask that is already known (the two-phase leaf loop: all eight distances and their `d2 <= tau` masks
+// first, then one LDS write per candidate that some lane accepts -- in the walk most candidates are accepted by no lane,
+// and an LDS instruction costs the CU's one LDS pipe the same whatever its EXEC).
+__device__ __forceinline__ void append_under(u64 mask, float d2, u32 pos, u32& wa, u64 saved)
+{
+    asm volatile("s_mov_b64 exec, %[mask]\n\t"
+                 "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
+                 "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [wa] "+v"(wa)
+                 : [mask] "s"(mask), [d2] "v"(d2), [pos] "v"(pos), [sv] "s"(saved)
+                 : "memory");
 }
 
 // The same for the later walk rounds: additionally lo < d2 (only the new shell (lo, tau] is accepted).
@@ -334,9 +475,9 @@ struct MultiPass {
 };
 
 // One query group (64 curve-consecutive queries, one per lane) from start to finish.
-template <int KCAP, bool SELF, bool STATS, bool MULTI>
+template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH>
 __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k_arg, const float eps,
-                                          const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
+                                          const float eps_thr, const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
                                           u64* __restrict__ col, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
@@ -401,6 +542,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     const u32 wa_full = lds_row0 + (static_cast<u32>(BUF - LEAF + 1) << 9);  // wa >= this: a leaf might not fit any more
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
+    // single-pass kernels: the eps-box test waits for the compaction, unless the launcher picked the EPS_EACH form (launch_knn_t)
+    const EpsFilter eps_filter{PCPX_ASM_ACCEPT && !MULTI && !EPS_EACH, eps_thr, eps, qx, qy, qz, t.leaves};
 
     // ---- seed range: the 64-point chunk at the group's own curve position ----
     u32 s0, s1;
@@ -422,7 +565,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 
     // Single loop, single back-edge: each iteration fetches the next leaf (seed chunk first, then the
     // tree walk), runs the one compaction site if needed, then the one candidate site.
-    Walker wk;
+    WalkerT<(KCAP > 8)> wk;
     wk.pend = 0;
     wk.ploc = 0;
     wk.l = 0;
@@ -440,6 +583,14 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     u32 seedcur = s0;
     bool walking = false;
     bool running = true;
+    // PCPX_TOUCH_AHEAD: the leaf found by this trip of the loop is processed by the NEXT trip; meanwhile one dword of each of
+    // its record's two cache lines is fetched (after the current leaf's record has arrived: SMEM has one counter, waiting for
+    // the current record would otherwise wait for those too), so that its 96-byte scalar load hits the scalar cache.  More
+    // than half of the scalar loads of this kernel miss that cache (SQC_DCACHE_MISSES) and a wave sits ~1/3 of its time in
+    // s_waitcnt.  The walk runs one leaf ahead of tau: a larger tau only visits more.
+    bool ahead_have = false;
+    u32 ahead_leaf = 0;
+    u32 touch0 = 0, touch1 = 0;
     while (running) {
         u32 leaf = 0;
         bool have = false;
@@ -454,6 +605,15 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             } while (have && leaf >= s0 && leaf < s1);
             if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
         }
+        if (PCPX_TOUCH_AHEAD) {
+            asm volatile("" ::"s"(touch0), "s"(touch1));  // (the touched dwords have a register each until here)
+            const bool found = have;
+            const u32 found_leaf = leaf;
+            have = ahead_have;
+            leaf = ahead_leaf;
+            ahead_have = found;
+            ahead_leaf = found_leaf;
+        }
         // compaction: buffer nearly full (a leaf may add LEAF keys), or draining at a phase end.  The fast accept
         // path keeps only the write address `wa`, the other paths only `cnt`.
         constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;
@@ -466,7 +626,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 st_c3 += any_lane(cnt > 3) ? 0u : 1u;
                 st_c4 += any_lane(cnt > 4) ? 0u : 1u;
             }
-            if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF>(best, col, cnt);
+            if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF>(best, col, cnt, eps_filter);
             else compact<KCAP, BUF>(best, col, cnt);
             float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
             tau = active ? fminf(nt, cap) : -1.f;
@@ -488,8 +648,64 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             }
             const Leaf lf = load_const(t.leaves + leaf);  // (a vector-memory fetch of the record measured the same)
             const u32 posbase = leaf * LEAF;
+            if (PCPX_TOUCH_AHEAD) {
+                u32 ln = __builtin_amdgcn_readfirstlane(ahead_have ? ahead_leaf : leaf);  // (nothing ahead: this record again -- no branch, the values stay scalar)
+                asm volatile("" : "+s"(ln) : "s"(__float_as_uint(lf.x[0])));  // not before this record is here
+                const u32* rec = reinterpret_cast<const u32*>(t.leaves + ln);
+                touch0 = load_const(rec);
+                touch1 = load_const(rec + 16);
+            }
             // copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
-            if (fast && !second_round) {
+            if (fast && eps_filter.on && !second_round && PCPX_TWO_PHASE) {
+                // (PCPX_TWO_PHASE_HALF candidates at a time: eight distances kept side by side cost the k <= 16 kernel scratch)
+                const u64 saved = save_exec();
+#pragma unroll
+                for (int h = 0; h < LEAF; h += PCPX_TWO_PHASE_HALF) {
+                    float d2v[PCPX_TWO_PHASE_HALF];
+                    u64 acc[PCPX_TWO_PHASE_HALF];
+                    u64 some = 0;
+#pragma unroll
+                    for (int j = 0; j < PCPX_TWO_PHASE_HALF; ++j) {
+                        float dx = lf.x[h + j] - qx, dy = lf.y[h + j] - qy, dz = lf.z[h + j] - qz;
+                        d2v[j] = sq3(dx, dy, dz);
+                        acc[j] = __builtin_amdgcn_ballot_w64(d2v[j] <= tau);  // NaN padding points fail
+                        some |= acc[j];
+                        if (STATS) st_app += (d2v[j] <= tau) ? 1u : 0u;
+                    }
+                    if (some != 0) {
+#pragma unroll
+                        for (int j = 0; j < PCPX_TWO_PHASE_HALF; ++j) {
+                            if (PCPX_TWO_PHASE == 2 || acc[j] != 0) append_under(acc[j], d2v[j], posbase + h + j, wa, saved);
+                        }
+                    }
+                }
+            } else if (fast && eps_filter.on && !second_round && !STATS && PCPX_APPEND4) {
+                u32 posv = posbase;
+                const u64 saved = save_exec();
+                static_assert(LEAF == 8, "two statements of four candidates");
+                append4_if_within(lf.x, lf.y, lf.z, qx, qy, qz, tau, posv, wa, saved);
+                append4_if_within(lf.x + 4, lf.y + 4, lf.z + 4, qx, qy, qz, tau, posv, wa, saved);
+            } else if (fast && eps_filter.on && !second_round) {
+                u32 posv = posbase;
+                const u64 saved = save_exec();
+#pragma unroll
+                for (int j = 0; j < LEAF; ++j) {
+                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                    float d2 = sq3(dx, dy, dz);
+                    if (STATS) st_app += (d2 <= tau) ? 1u : 0u;
+                    append_if_within(d2, tau, posv, wa, saved);  // NaN padding points fail d2 <= tau
+                }
+            } else if (fast && eps_filter.on) {
+                u32 posv = posbase;
+                const u64 saved = save_exec();
+#pragma unroll
+                for (int j = 0; j < LEAF; ++j) {
+                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                    float d2 = sq3(dx, dy, dz);
+                    if (STATS) st_app += (d2 <= tau && d2 > lo_d2) ? 1u : 0u;
+                    append_if_within_shell(d2, tau, lo_d2, posv, wa, saved);
+                }
+            } else if (fast && !second_round) {
                 u32 posv = posbase;
                 const u64 saved = save_exec();
 #pragma unroll
@@ -529,7 +745,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 asm volatile("" ::"v"(wa), "v"(cnt));
                 tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
             }
-        } else if (!trig) {
+        } else if (!trig && !(PCPX_TOUCH_AHEAD && ahead_have)) {
             // drained: seed chunk -> capped tree walk -> (rarely) uncapped walk of the failed lanes -> finished
             if (!walking) {
                 walking = true;
@@ -657,8 +873,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // (the column goes back to the chunked compaction's invariant -- empty slots hold PAD_KEY -- at the end of this function)
     auto restore_column = [&]() {
         if (PCPX_COMPACT_BY8 && (KCAP <= 16 || PCPX_BY8_K32)) {
+            const u64 pad = pad_key_here();
 #pragma unroll
-            for (int r = 0; r < (KCAP + 1) / 2; ++r) col[r * 64] = PAD_KEY;
+            for (int r = 0; r < (KCAP + 1) / 2; ++r) col[r * 64] = pad;
         }
     };
 
@@ -668,7 +885,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     }
     // output row = original index of the query (read here, not at the start: one VGPR less through the search loop)
     // (the query's position is formed again rather than kept: as a 64-bit record offset it sat in a VGPR pair all through the search)
-    u32 p_row = g * GROUP + lane;
+    u32 g_again = g;
+    asm volatile("" : "+s"(g_again));  // (or hipcc keeps the search's `p` for this: in scratch, in the k <= 16 kernel)
+    u32 p_row = g_again * GROUP + lane;
     asm volatile("" : "+v"(p_row));
     u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : qv.row[p_row];
     if (SELF && o.by_position) row = p_row;
@@ -761,9 +980,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 // under-reports on gfx950 (this grid is fully resident by construction).
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
-template <int KCAP, bool SELF, bool STATS, bool MULTI = false>
+template <int KCAP, bool SELF, bool STATS, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
-    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, KnnOutputs o, MultiPass mp,
+    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, float eps_thr, KnnOutputs o, MultiPass mp,
     u32* __restrict__ queue, unsigned long long* __restrict__ stats)
 {
     constexpr int BUF = buf_rows(KCAP);
@@ -795,7 +1014,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
                 tg = __builtin_amdgcn_s_memrealtime();
                 tcg = __builtin_amdgcn_s_memtime();
             }
-            knn_group<KCAP, SELF, STATS, MULTI>(t, qv, group_first + qbeg + gi, k, eps, o, mp, stats, col, lane);
+            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH>(t, qv, group_first + qbeg + gi, k, eps, eps_thr, o, mp, stats, col, lane);
             if (STATS) {
                 if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
                 ++n_done;
@@ -843,22 +1062,54 @@ int prepare_queue(Index& ix)
     return PCPX_OK;
 }
 
+// Squared distance below which a buffered key still needs the exact eps-box test (EpsFilter), or -1: test every candidate.
+// A point inside the box has |d.| < eps on every axis, so its float d2 is at most 3 eps^2 (1 + 2^-24)^3.  Waiting pays
+// while such keys are rare: eps small against the spacing of the points (estimated from the cloud's box: only a
+// performance decision, both forms give the same rows).  Index::eps_test_mode (pcpx_debug_eps_test_mode) forces either.
+static float eps_box_threshold(const Index& ix, float eps)
+{
+    if (!PCPX_DEFER_EPS || ix.eps_test_mode == 2) return -1.f;
+    if (!(eps > 0.f)) return 0.f;  // nothing is inside an empty box
+    const double t = 3.0 * static_cast<double>(eps) * static_cast<double>(eps) * (1.0 + 1e-6);
+    if (!(t < 1e37)) return ix.eps_test_mode == 1 ? std::numeric_limits<float>::infinity() : -1.f;
+    float thr = static_cast<float>(t);
+    if (static_cast<double>(thr) < t) thr = std::nextafterf(thr, std::numeric_limits<float>::infinity());
+    const float floor_thr = 2.f * std::numeric_limits<float>::min();  // products of differences below 2^-63 underflow
+    if (thr < floor_thr) thr = floor_thr;
+    if (ix.eps_test_mode == 1) return thr;
+    const double ex = static_cast<double>(ix.bbox[3]) - ix.bbox[0], ey = static_cast<double>(ix.bbox[4]) - ix.bbox[1],
+                 ez = static_cast<double>(ix.bbox[5]) - ix.bbox[2];
+    const double vol = ex * ey * ez;
+    if (!(vol > 0.0) || ix.n == 0) return -1.f;
+    const double spacing = std::cbrt(vol / static_cast<double>(ix.n));
+    return t <= 0.01 * spacing * spacing ? thr : -1.f;
+}
+
+template <int KCAP, bool SELF, bool EPS_EACH>
+static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcount, u32 k, float eps, float thr, const KnnOutputs& o)
+{
+    constexpr int BUF = buf_rows(KCAP);
+    const size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
+    const u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
+    int st = prepare_queue(ix);
+    if (st != PCPX_OK) return st;
+    auto* fn = k_knn<KCAP, SELF, false, false, EPS_EACH>;
+    const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WAVES_PER_BLOCK, lds, gcount);
+    ProfileScope prof(ix, PCPX_K_KNN);
+    fn<<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr);
+    return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
+}
+
 template <int KCAP>
 static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps, const KnnOutputs& o)
 {
-    constexpr int BUF = buf_rows(KCAP);
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
-    u32 grid = grid_for_groups(gcount);
-    u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
-    int st = prepare_queue(ix);
-    if (st != PCPX_OK) return st;
-    (void)grid;
-    const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false>) : reinterpret_cast<const void*>(k_knn<KCAP, false, false>);
-    u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount);
-    ProfileScope prof(ix, PCPX_K_KNN);
-    if (self) k_knn<KCAP, true, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, MultiPass{}, ix.d_queue, nullptr);
-    else k_knn<KCAP, false, false><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, o, MultiPass{}, ix.d_queue, nullptr);
-    return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
+    const float thr = eps_box_threshold(ix, eps);
+    if (PCPX_DEFER_EPS && thr >= 0.f) {
+        return self ? launch_knn_form<KCAP, true, false>(ix, qv, gfirst, gcount, k, eps, thr, o)
+                    : launch_knn_form<KCAP, false, false>(ix, qv, gfirst, gcount, k, eps, thr, o);
+    }
+    return self ? launch_knn_form<KCAP, true, true>(ix, qv, gfirst, gcount, k, eps, thr, o)
+                : launch_knn_form<KCAP, false, true>(ix, qv, gfirst, gcount, k, eps, thr, o);
 }
 
 // ---- k > 32: stitch the per-pass keys of every query into its output row -----------------------------
@@ -948,8 +1199,8 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
         const u32 kp = (pass + 1 < npass) ? KCAP : k - pass * KCAP;
         int st = prepare_queue(ix);
         if (st != PCPX_OK) return st;
-        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, KnnOutputs{}, mp, ix.d_queue, nullptr);
-        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, KnnOutputs{}, mp, ix.d_queue, nullptr);
+        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, KnnOutputs{}, mp, ix.d_queue, nullptr);
+        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, KnnOutputs{}, mp, ix.d_queue, nullptr);
     }
     const u32 n32 = static_cast<u32>(nslots);
     if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
@@ -992,7 +1243,7 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     if (st != PCPX_OK) return st;
     u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WAVES_PER_BLOCK, lds, groups);
     k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps),
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), eps_box_threshold(ix, sanitize_eps(eps)),
         KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }

@@ -273,6 +273,10 @@ class Index:
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 
+    def debug_eps_test_mode(self, mode):
+        """0: automatic; 1: eps-box test on buffered keys (compaction); 2: on every candidate.  Same results, different cost."""
+        check(self._lib.pcpx_debug_eps_test_mode(self._h, int(mode)))
+
     def debug_knn_stats(self, k, eps=1e-5, want_waves=False, floor=False):
         """floor=True: every lane starts from its true k-th distance (what a perfect visiting order could reach)."""
         cap = 16 + 5 * 65536

@@ -229,6 +229,26 @@ def test_knn_coincident_points_and_eps(pkg, oracle):
     _check_knn_exact(pkg, oracle, pts, base[:64] + np.float32(1e-3), 8, eps=2e-3)
 
 
+@pytest.mark.parametrize("k", [5, 15, 32])
+def test_eps_box_test_in_either_place_gives_the_same_rows(pkg, oracle, k):
+    """The throughput kernel applies the eps-box exclusion either to every candidate or to the buffered keys when they are
+    folded into the best-list (pcpx_debug_eps_test_mode; the launcher picks by eps against the point spacing).  Both forms,
+    forced, against brute force: tiny, ordinary and absurdly large boxes, twins inside the box, self and foreign queries."""
+    rng = np.random.default_rng(17)
+    base = rng.random((6000, 3), dtype=np.float32)
+    twins = base[:1500] + rng.uniform(-4e-6, 4e-6, (1500, 3)).astype(np.float32)
+    pts = np.concatenate([base, twins, base[:300]])
+    foreign = np.concatenate([rng.random((700, 3), dtype=np.float32), base[:300] + np.float32(2e-6)])
+    ix = pkg.Index(pts)
+    for mode in (1, 2, 0):
+        ix.debug_eps_test_mode(mode)
+        for eps in (0.0, 1e-7, 1e-5, 1e-3, 0.04, 0.3):
+            _check_knn_exact(pkg, oracle, pts, None, k, eps=eps, self_query=True, ix=ix)
+            _check_knn_exact(pkg, oracle, pts, foreign, k, eps=eps, ix=ix)
+    with pytest.raises(Exception):
+        ix.debug_eps_test_mode(3)
+
+
 def test_knn_lattice_ties(pkg, oracle):
     """A lattice makes exact distance ties the norm; (d2, index) ordering must still match exactly, and
     the reference trees must agree up to ties."""
