@@ -55,9 +55,14 @@ __device__ __forceinline__ NodeBox4 load_node4(const NodeBox* first_child)
 {
     typedef u32 u32x16 __attribute__((ext_vector_type(16)));
     u32x16 a, b;
+    // (the address is wave-uniform by construction; where hipcc cannot see that, this pins it to scalar registers)
+    const u64 address = reinterpret_cast<uintptr_t>(first_child);
+    const u32 address_lo = __builtin_amdgcn_readfirstlane(static_cast<u32>(address));  // (the builtin returns int: no sign extension)
+    const u32 address_hi = __builtin_amdgcn_readfirstlane(static_cast<u32>(address >> 32));
+    const u64 uniform = (static_cast<u64>(address_hi) << 32) | address_lo;
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(a), "=&s"(b)
-                 : "s"(first_child));
+                 : "s"(uniform));
     NodeBox4 out;
     u32* o = reinterpret_cast<u32*>(&out);
 #pragma unroll
@@ -144,6 +149,32 @@ struct WalkerT {
         l = t.depth - 1;
         pend = static_cast<u64>(child_mask(t, 0, 0u, need)) << (W * l);
         return false;
+    }
+
+    // The same walk as next(), in pieces, for a caller that keeps "is there another leaf" in its control flow instead of in
+    // a value (hipcc turns a wave-uniform bool that lives across blocks into a 64-bit lane mask: s_cselect_b64, s_and_b64
+    // with EXEC and a VCC branch where one SCC branch would do; k_knn's scalar side is as loaded as its vector side).
+    //   while (!wk.done()) { u32 loc; int h = wk.pop(loc); if (h == 0) { wk.at_leaf(loc); ...leaf loc... } else wk.expand(t, h, loc, need); }
+    __device__ __forceinline__ bool done() const { return pend == 0; }
+    __device__ __forceinline__ int pop(u32& loc)
+    {
+        const int bit = __builtin_ctzll(pend);
+        pend &= ~(1ull << bit);
+        const int h = bit >> LOGW;
+        loc = ((ploc >> (LOGW * (h - l))) << LOGW) + (static_cast<u32>(bit) & (W - 1u));  // climb h - l levels, step down
+        return h;
+    }
+    __device__ __forceinline__ void at_leaf(u32 loc)
+    {
+        ploc = loc >> LOGW;
+        l = 0;
+    }
+    template <class Need>
+    __device__ __forceinline__ void expand(const TreeView& t, int h, u32 loc, Need&& need)
+    {
+        l = h - 1;
+        ploc = loc;
+        pend |= static_cast<u64>(child_mask(t, t.depth - h, loc, need)) << (W * l);
     }
 
     template <class Need>

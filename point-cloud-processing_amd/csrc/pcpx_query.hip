@@ -181,18 +181,6 @@ __device__ __forceinline__ void static_for(F&& f)
 #ifndef PCPX_DEFER_EPS
 #define PCPX_DEFER_EPS 1
 #endif
-#ifndef PCPX_APPEND4
-#define PCPX_APPEND4 1
-#endif
-#ifndef PCPX_TOUCH_AHEAD
-#define PCPX_TOUCH_AHEAD 0
-#endif
-#ifndef PCPX_TWO_PHASE_HALF
-#define PCPX_TWO_PHASE_HALF 4
-#endif
-#ifndef PCPX_TWO_PHASE
-#define PCPX_TWO_PHASE 0  // leaf loop of the deferred form: 1 = masks first, LDS writes only for candidates some lane accepts; 2 = skip per leaf only; 0 = v_cmpx per candidate
-#endif
 struct EpsFilter {
     bool on;
     float thr, eps, qx, qy, qz;
@@ -200,10 +188,11 @@ struct EpsFilter {
 };
 __device__ __forceinline__ float key_d2(u64 key) { return __uint_as_float(static_cast<u32>(key >> 32)); }
 
-// nw[0 .. 8) ascending, read from rows r0 .. r0 + R of the column (which hold PAD_KEY again): drop the keys inside the eps-box
-template <int R>
-__device__ __forceinline__ void drop_eps_box(u64 (&nw)[8], u64* __restrict__ col_r0, const EpsFilter& f)
+// nw[0 .. N) ascending, read from rows r0 .. r0 + R of the column (which hold PAD_KEY again): drop the keys inside the eps-box
+template <int R, int N>
+__device__ __forceinline__ void drop_eps_box(u64 (&nw)[N], u64* __restrict__ col_r0, const EpsFilter& f)
 {
+    static_assert(R <= N, "rows");
     if (!any_lane(key_d2(nw[0]) < f.thr)) return;  // (PAD_KEY: d2 = +inf)
     // back into the rows in ascending order (the real keys of the chunk are at most R and come first): the loop below is
     // rare and runs on LDS so that it costs the compaction no registers
@@ -222,12 +211,12 @@ __device__ __forceinline__ void drop_eps_box(u64 (&nw)[8], u64* __restrict__ col
             if (!(m >= f.eps)) col_r0[j * 64] = pad_key_here();
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nw[j] = j < R ? col_r0[j * 64] : PAD_KEY;
     const u64 pad = pad_key_here();
 #pragma unroll
+    for (int j = 0; j < N; ++j) nw[j] = j < R ? col_r0[j * 64] : pad;
+#pragma unroll
     for (int j = 0; j < R; ++j) col_r0[j * 64] = pad;
-    bitonic_sort<8>(nw);
+    bitonic_sort<N>(nw);
 }
 
 template <int KCAP, int BUF>
@@ -243,22 +232,24 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) col[j * 64] = pad;
         bitonic_sort<8>(nw);
-        if (f.on) drop_eps_box<8>(nw, col, f);
+        if (f.on) drop_eps_box<8, 8>(nw, col, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
         bitonic_merge<KCAP>(best);
     }
     if (BUF > 8 && any_lane(cnt > 8)) {
-        u64 nw[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) nw[j] = 8 + j < BUF ? col[(8 + j) * 64] : PAD_KEY;
+        constexpr int R = BUF > 8 ? BUF - 8 : 1;               // rows of the second chunk
+        constexpr int N = R <= 2 ? 2 : R <= 4 ? 4 : 8;         // its sorting network (10 rows: one compare-exchange)
+        u64 nw[N];
         const u64 pad = pad_key_here();
 #pragma unroll
-        for (int j = 8; j < BUF; ++j) col[j * 64] = pad;
-        bitonic_sort<8>(nw);
-        if (f.on) drop_eps_box<(BUF > 8 ? BUF - 8 : 1)>(nw, col + 8 * 64, f);
+        for (int j = 0; j < N; ++j) nw[j] = j < R ? col[(8 + j) * 64] : pad;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+        for (int j = 8; j < BUF; ++j) col[j * 64] = pad;
+        bitonic_sort<N>(nw);
+        if (f.on) drop_eps_box<R, N>(nw, col + 8 * 64, f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
         bitonic_merge<KCAP>(best);
     }
     cnt = 0;
@@ -377,20 +368,6 @@ __device__ __forceinline__ void append_if_within_shell(float d2, float tau, floa
                  : [wa] "+v"(wa), [pos] "+v"(pos)
                  : [d2] "v"(d2), [tau] "v"(tau), [lo] "s"(lo), [sv] "s"(saved)
                  : "vcc", "memory");
-}
-
-// Append under a lane mask that is already known (the two-phase leaf loop: all eight distances and their `d2 <= tau` masks
-// first, then one LDS write per candidate that some lane accepts -- in the walk most candidates are accepted by no lane,
-// and an LDS instruction costs the CU's one LDS pipe the same whatever its EXEC).
-__device__ __forceinline__ void append_under(u64 mask, float d2, u32 pos, u32& wa, u64 saved)
-{
-    asm volatile("s_mov_b64 exec, %[mask]\n\t"
-                 "ds_write2_b32 %[wa], %[pos], %[d2] offset1:1\n\t"
-                 "v_add_u32_e32 %[wa], 0x200, %[wa]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [wa] "+v"(wa)
-                 : [mask] "s"(mask), [d2] "v"(d2), [pos] "v"(pos), [sv] "s"(saved)
-                 : "memory");
 }
 
 // The same for the later walk rounds: additionally lo < d2 (only the new shell (lo, tau] is accepted).
@@ -563,232 +540,196 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         s1 = s1 + seed_extra < t.nleaves ? s1 + seed_extra : t.nleaves;
     }
 
-    // Single loop, single back-edge: each iteration fetches the next leaf (seed chunk first, then the
-    // tree walk), runs the one compaction site if needed, then the one candidate site.
-    WalkerT<(KCAP > 8)> wk;
-    wk.pend = 0;
-    wk.ploc = 0;
-    wk.l = 0;
-    // Walk rounds with a growing radius.  In the first round no lane searches farther than `cap` = cap_mult (1.125 ... 1.375) x the
-    // wave's median seeded tau: a lane whose 64-point seed chunk lies across a jump of the curve (rare on the Hilbert curve, the rule on a Z-order) starts with a
-    // tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured:
-    // 7 ms groups against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all
-    // its k nearest are within cap, and everything within cap has been visited).  Lanes that fail -- points in
-    // genuinely sparse places -- go round again with cap x 4, accepting only the new shell lo_d2 < d2 <= cap so
-    // that nothing is seen twice, until they verify or the cap covers the whole cloud.
+    // Phases: the seed leaves, then walk rounds with a growing radius.  Each phase has its own loop (the one loop with mode
+    // flags that served them all until round 3 spent more scalar instructions steering itself than the walk needs: the scalar
+    // side of this kernel is as loaded as its vector side, profiles/experiments/README.md); a trip of a loop fetches the next
+    // leaf, folds the append buffer into the best-list if the leaf might not fit (or, at the end of the phase, if any key is
+    // buffered), then runs the leaf's candidates.
+    // In the first walk round no lane searches farther than `cap` = cap_mult (1.125 ... 1.375) x the wave's median seeded tau: a
+    // lane whose 64-point seed chunk lies across a jump of the curve (rare on the Hilbert curve, the rule on a Z-order) starts
+    // with a tau hundreds of times too large and would drag the whole wave through thousands of leaves (measured: 7 ms groups
+    // against a 0.37 ms mean).  After a round a lane is exact iff its k-th distance <= cap (then all its k nearest are within
+    // cap, and everything within cap has been visited).  Lanes that fail -- points in genuinely sparse places -- go round again
+    // with cap x 4, accepting only the new shell lo_d2 < d2 <= cap so that nothing is seen twice, until they verify or the cap
+    // covers the whole cloud.
     float cap = inf;       // wave-uniform; inf = no cap
-    float lo_d2 = -1.f;    // wave-uniform; second round accepts only d2 > lo_d2
-    bool second_round = false;
-    u32 rounds = 0;
-    u32 seedcur = s0;
-    bool walking = false;
-    bool running = true;
-    // PCPX_TOUCH_AHEAD: the leaf found by this trip of the loop is processed by the NEXT trip; meanwhile one dword of each of
-    // its record's two cache lines is fetched (after the current leaf's record has arrived: SMEM has one counter, waiting for
-    // the current record would otherwise wait for those too), so that its 96-byte scalar load hits the scalar cache.  More
-    // than half of the scalar loads of this kernel miss that cache (SQC_DCACHE_MISSES) and a wave sits ~1/3 of its time in
-    // s_waitcnt.  The walk runs one leaf ahead of tau: a larger tau only visits more.
-    bool ahead_have = false;
-    u32 ahead_leaf = 0;
-    u32 touch0 = 0, touch1 = 0;
-    while (running) {
-        u32 leaf = 0;
-        bool have = false;
-        if (!walking) {
-            have = seedcur < s1;
-            leaf = seedcur;
-            seedcur += have ? 1u : 0u;
-        } else {
-            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-            do {
-                have = wk.next(t, need, leaf, st_expand);
-            } while (have && leaf >= s0 && leaf < s1);
-            if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
+    float lo_d2 = -1.f;    // wave-uniform; later rounds accept only d2 > lo_d2
+    constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;  // keeps only the write address `wa`; the other accept paths only `cnt`
+
+    // fold the buffered keys into the best-list (one copy of the selection network per call site)
+    auto fold = [&](bool in_seed_phase) {
+        if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
+        if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
+        if (STATS) {  // how full is the fullest lane when a compaction runs?
+            st_c3 += any_lane(cnt > 3) ? 0u : 1u;
+            st_c4 += any_lane(cnt > 4) ? 0u : 1u;
         }
-        if (PCPX_TOUCH_AHEAD) {
-            asm volatile("" ::"s"(touch0), "s"(touch1));  // (the touched dwords have a register each until here)
-            const bool found = have;
-            const u32 found_leaf = leaf;
-            have = ahead_have;
-            leaf = ahead_leaf;
-            ahead_have = found;
-            ahead_leaf = found_leaf;
+        if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF>(best, col, cnt, eps_filter);
+        else compact<KCAP, BUF>(best, col, cnt);
+        float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+        tau = active ? fminf(nt, cap) : -1.f;
+        if (STATS) tau = fminf(tau, tau_known);
+        wa = col_addr + (static_cast<u32>(cnt) << 9);
+        if (STATS) {
+            ++st_compact;
+            if (in_seed_phase) ++st_seed_compact;
+            // the clock read must not be scheduled ahead of the merge network: make it depend on tau
+            asm volatile("" ::"v"(tau));
+            tc_compact += __builtin_amdgcn_s_memtime() - tc_mark;
         }
-        // compaction: buffer nearly full (a leaf may add LEAF keys), or draining at a phase end.  The fast accept
-        // path keeps only the write address `wa`, the other paths only `cnt`.
-        constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;
+    };
+    // before a leaf: fold if some lane could not take LEAF more keys; at the end of a phase: if any lane holds a key
+    auto fold_if_needed = [&](bool before_leaf, bool in_seed_phase) {
         if (!fast) wa = col_addr + (static_cast<u32>(cnt) << 9);
-        bool trig = have ? any_lane(wa >= wa_full) : any_lane(wa >= lds_row0 + 512u);
-        if (trig) {
+        if (any_lane(wa >= (before_leaf ? wa_full : lds_row0 + 512u))) fold(in_seed_phase);
+    };
+
+    // candidates of one leaf: SMEM broadcast, branch-free accept; `shell`: a later walk round
+    auto candidates = [&](const u32 leaf, const bool shell) {
+        if (STATS) {
+            ++st_leaves;
+            tc_mark = __builtin_amdgcn_s_memtime();
+        }
+        const Leaf lf = load_const(t.leaves + leaf);  // (a vector-memory fetch of the record measured the same)
+        const u32 posbase = leaf * LEAF;
+        // copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
+        if (fast && eps_filter.on && !shell && !STATS) {
+            u32 posv = posbase;
+            const u64 saved = save_exec();
+            static_assert(LEAF == 8, "two statements of four candidates");
+            append4_if_within(lf.x, lf.y, lf.z, qx, qy, qz, tau, posv, wa, saved);
+            append4_if_within(lf.x + 4, lf.y + 4, lf.z + 4, qx, qy, qz, tau, posv, wa, saved);
+        } else if (fast && eps_filter.on && !shell) {
+            u32 posv = posbase;
+            const u64 saved = save_exec();
+#pragma unroll
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                float d2 = sq3(dx, dy, dz);
+                if (STATS) st_app += (d2 <= tau) ? 1u : 0u;
+                append_if_within(d2, tau, posv, wa, saved);  // NaN padding points fail d2 <= tau
+            }
+        } else if (fast && eps_filter.on) {
+            u32 posv = posbase;
+            const u64 saved = save_exec();
+#pragma unroll
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                float d2 = sq3(dx, dy, dz);
+                if (STATS) st_app += (d2 <= tau && d2 > lo_d2) ? 1u : 0u;
+                append_if_within_shell(d2, tau, lo_d2, posv, wa, saved);
+            }
+        } else if (fast && !shell) {
+            u32 posv = posbase;
+            const u64 saved = save_exec();
+#pragma unroll
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                float d2 = sq3(dx, dy, dz);
+                if (STATS) st_app += (d2 <= tau && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
+                append_if(d2, tau, dx, dy, dz, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
+            }
+        } else if (fast) {  // later rounds: only the shell (lo_d2, tau]
+            u32 posv = posbase;
+            const u64 saved = save_exec();
+#pragma unroll
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                float d2 = sq3(dx, dy, dz);
+                if (STATS) st_app += (d2 <= tau && d2 > lo_d2 && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
+                append_if_shell(d2, tau, lo_d2, dx, dy, dz, eps, posv, wa, saved);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                float d2 = sq3(dx, dy, dz);
+                float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                const u64 key = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
+                float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
+                bool acc = m2 >= eps && d2 > lo_d2;  // outside the eps-box (eps >= 0); not seen in round one
+                if (MULTI) acc = acc && (!has_lo || key > lo_key);
+                int slot = acc ? cnt : BUF;
+                col[slot * 64] = key;
+                cnt += acc ? 1 : 0;
+                if (STATS) st_app += acc ? 1u : 0u;
+            }
+        }
+        if (STATS) {
+            asm volatile("" ::"v"(wa), "v"(cnt));
+            tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
+        }
+    };
+
+    // ---- the seed leaves ----
+    for (u32 leaf = s0;; ++leaf) {
+        const bool more = leaf < s1;
+        fold_if_needed(more, true);
+        if (!more) break;
+        candidates(leaf, false);
+    }
+    if (STATS) st_seed_app = st_app;
+    cap = wave_radius_cap<KCAP>(tau, valid, lane);
+    tau = active ? fminf(tau, cap) : -1.f;
+
+    // ---- walk rounds ----
+    WalkerT<(KCAP > 8)> wk;
+    const u32 seed_count = s1 - s0;
+    bool shell = false;
+    for (u32 rounds = 0;;) {
+        bool root_leaf = wk.start(t, need, st_expand);
+        (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
+        for (;;) {
+            // pop until the next leaf outside the seed range (a seed leaf was seen under a larger tau than any later one) --
+            // "is there one" stays in the control flow: see WalkerT::pop
+            u32 leaf = 0;
             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-            if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
-            if (STATS) {  // how full is the fullest lane when a compaction runs?
-                st_c3 += any_lane(cnt > 3) ? 0u : 1u;
-                st_c4 += any_lane(cnt > 4) ? 0u : 1u;
+            for (;;) {
+                if (wk.done()) goto round_done;
+                u32 loc;
+                const int h = wk.pop(loc);
+                if (h != 0) {
+                    ++st_expand;
+                    wk.expand(t, h, loc, need);
+                    continue;
+                }
+                wk.at_leaf(loc);
+                if (loc - s0 >= seed_count) {
+                    leaf = loc;
+                    break;
+                }
             }
-            if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF>(best, col, cnt, eps_filter);
-            else compact<KCAP, BUF>(best, col, cnt);
-            float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
-            tau = active ? fminf(nt, cap) : -1.f;
-            if (STATS) tau = fminf(tau, tau_known);
-            wa = col_addr + (static_cast<u32>(cnt) << 9);
-            if (STATS) {
-                ++st_compact;
-                if (!walking) ++st_seed_compact;
-                // the clock read must not be scheduled ahead of the merge network: make it depend on tau
-                asm volatile("" ::"v"(tau));
-                tc_compact += __builtin_amdgcn_s_memtime() - tc_mark;
-            }
+            if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
+            fold_if_needed(true, false);
+            candidates(leaf, shell);
         }
-        if (have) {
-            // ---- candidates of one leaf: SMEM broadcast, branch-free accept ----
-            if (STATS) {
-                ++st_leaves;
-                tc_mark = __builtin_amdgcn_s_memtime();
-            }
-            const Leaf lf = load_const(t.leaves + leaf);  // (a vector-memory fetch of the record measured the same)
-            const u32 posbase = leaf * LEAF;
-            if (PCPX_TOUCH_AHEAD) {
-                u32 ln = __builtin_amdgcn_readfirstlane(ahead_have ? ahead_leaf : leaf);  // (nothing ahead: this record again -- no branch, the values stay scalar)
-                asm volatile("" : "+s"(ln) : "s"(__float_as_uint(lf.x[0])));  // not before this record is here
-                const u32* rec = reinterpret_cast<const u32*>(t.leaves + ln);
-                touch0 = load_const(rec);
-                touch1 = load_const(rec + 16);
-            }
-            // copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
-            if (fast && eps_filter.on && !second_round && PCPX_TWO_PHASE) {
-                // (PCPX_TWO_PHASE_HALF candidates at a time: eight distances kept side by side cost the k <= 16 kernel scratch)
-                const u64 saved = save_exec();
-#pragma unroll
-                for (int h = 0; h < LEAF; h += PCPX_TWO_PHASE_HALF) {
-                    float d2v[PCPX_TWO_PHASE_HALF];
-                    u64 acc[PCPX_TWO_PHASE_HALF];
-                    u64 some = 0;
-#pragma unroll
-                    for (int j = 0; j < PCPX_TWO_PHASE_HALF; ++j) {
-                        float dx = lf.x[h + j] - qx, dy = lf.y[h + j] - qy, dz = lf.z[h + j] - qz;
-                        d2v[j] = sq3(dx, dy, dz);
-                        acc[j] = __builtin_amdgcn_ballot_w64(d2v[j] <= tau);  // NaN padding points fail
-                        some |= acc[j];
-                        if (STATS) st_app += (d2v[j] <= tau) ? 1u : 0u;
-                    }
-                    if (some != 0) {
-#pragma unroll
-                        for (int j = 0; j < PCPX_TWO_PHASE_HALF; ++j) {
-                            if (PCPX_TWO_PHASE == 2 || acc[j] != 0) append_under(acc[j], d2v[j], posbase + h + j, wa, saved);
-                        }
-                    }
-                }
-            } else if (fast && eps_filter.on && !second_round && !STATS && PCPX_APPEND4) {
-                u32 posv = posbase;
-                const u64 saved = save_exec();
-                static_assert(LEAF == 8, "two statements of four candidates");
-                append4_if_within(lf.x, lf.y, lf.z, qx, qy, qz, tau, posv, wa, saved);
-                append4_if_within(lf.x + 4, lf.y + 4, lf.z + 4, qx, qy, qz, tau, posv, wa, saved);
-            } else if (fast && eps_filter.on && !second_round) {
-                u32 posv = posbase;
-                const u64 saved = save_exec();
-#pragma unroll
-                for (int j = 0; j < LEAF; ++j) {
-                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-                    float d2 = sq3(dx, dy, dz);
-                    if (STATS) st_app += (d2 <= tau) ? 1u : 0u;
-                    append_if_within(d2, tau, posv, wa, saved);  // NaN padding points fail d2 <= tau
-                }
-            } else if (fast && eps_filter.on) {
-                u32 posv = posbase;
-                const u64 saved = save_exec();
-#pragma unroll
-                for (int j = 0; j < LEAF; ++j) {
-                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-                    float d2 = sq3(dx, dy, dz);
-                    if (STATS) st_app += (d2 <= tau && d2 > lo_d2) ? 1u : 0u;
-                    append_if_within_shell(d2, tau, lo_d2, posv, wa, saved);
-                }
-            } else if (fast && !second_round) {
-                u32 posv = posbase;
-                const u64 saved = save_exec();
-#pragma unroll
-                for (int j = 0; j < LEAF; ++j) {
-                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-                    float d2 = sq3(dx, dy, dz);
-                    if (STATS) st_app += (d2 <= tau && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
-                    append_if(d2, tau, dx, dy, dz, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
-                }
-            } else if (fast) {  // later rounds: only the shell (lo_d2, tau]
-                u32 posv = posbase;
-                const u64 saved = save_exec();
-#pragma unroll
-                for (int j = 0; j < LEAF; ++j) {
-                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-                    float d2 = sq3(dx, dy, dz);
-                    if (STATS) st_app += (d2 <= tau && d2 > lo_d2 && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
-                    append_if_shell(d2, tau, lo_d2, dx, dy, dz, eps, posv, wa, saved);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < LEAF; ++j) {
-                    float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
-                    float d2 = sq3(dx, dy, dz);
-                    float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-                    const u64 key = (static_cast<u64>(__float_as_uint(d2)) << 32) | (posbase + j);
-                    float m2 = d2 <= tau ? m : -1.f;  // NaN padding points fail here
-                    bool acc = m2 >= eps && d2 > lo_d2;  // outside the eps-box (eps >= 0); not seen in round one
-                    if (MULTI) acc = acc && (!has_lo || key > lo_key);
-                    int slot = acc ? cnt : BUF;
-                    col[slot * 64] = key;
-                    cnt += acc ? 1 : 0;
-                    if (STATS) st_app += acc ? 1u : 0u;
-                }
-            }
-            if (STATS) {
-                asm volatile("" ::"v"(wa), "v"(cnt));
-                tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
-            }
-        } else if (!trig && !(PCPX_TOUCH_AHEAD && ahead_have)) {
-            // drained: seed chunk -> capped tree walk -> (rarely) uncapped walk of the failed lanes -> finished
-            if (!walking) {
-                walking = true;
-                if (STATS) st_seed_app = st_app;
-                cap = wave_radius_cap<KCAP>(tau, valid, lane);
-                tau = active ? fminf(tau, cap) : -1.f;
-                bool root_leaf = wk.start(t, need, st_expand);
-                (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
-            } else if (cap < inf) {
-                // a capped round ended: lanes whose k-th distance is within the cap are exact; the others go
-                // round again with 4x the radius^2, accepting only the new shell (lo_d2, cap]
-                const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
-                const bool failed = active && !(kth <= cap);
-                if (any_lane(failed)) {
-                    second_round = true;
-                    if (STATS) ++st_round2;
-                    lo_d2 = cap;
-                    const NodeBox root = load_const(t.nodes);
-                    const float ex = root.hi[0] - root.lo[0], ey = root.hi[1] - root.lo[1], ez = root.hi[2] - root.lo[2];
-                    const float diag2 = sq3(ex, ey, ez);
-                    // next radius^2; the last round is uncapped: when the cap covers the whole cloud from any query inside
-                    // 2x its box, when it cannot grow (a cap of 0: more than half of the sampled lanes sit on >= k coincident
-                    // points and eps is 0), or after 12 rounds
-                    const float grown = cap * PCPX_CAP_GROW;
-                    ++rounds;
-                    cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
-                    active = failed;
-                    tau = active ? fminf(kth, cap) : -1.f;
-                    cnt = 0;
-                    wa = col_addr;
-                    bool root_leaf = wk.start(t, need, st_expand);
-                    (void)root_leaf;
-                } else {
-                    running = false;
-                }
-            } else {
-                running = false;
-            }
-        }
+    round_done:
+        fold_if_needed(false, false);
+        if (!(cap < inf)) break;
+        // a capped round ended: lanes whose k-th distance is within the cap are exact; the others go round again with 4x the
+        // radius^2, accepting only the new shell (lo_d2, cap]
+        const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
+        const bool failed = active && !(kth <= cap);
+        if (!any_lane(failed)) break;
+        shell = true;
+        if (STATS) ++st_round2;
+        lo_d2 = cap;
+        const NodeBox root = load_const(t.nodes);
+        const float ex = root.hi[0] - root.lo[0], ey = root.hi[1] - root.lo[1], ez = root.hi[2] - root.lo[2];
+        const float diag2 = sq3(ex, ey, ez);
+        // next radius^2; the last round is uncapped: when the cap covers the whole cloud from any query inside 2x its box, when
+        // it cannot grow (a cap of 0: more than half of the sampled lanes sit on >= k coincident points and eps is 0), or
+        // after 12 rounds
+        const float grown = cap * PCPX_CAP_GROW;
+        ++rounds;
+        cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
+        active = failed;
+        tau = active ? fminf(kth, cap) : -1.f;
+        cnt = 0;
+        wa = col_addr;
     }
 
     if (STATS) {
-        if (!walking) st_seed_app = st_app;  // (a group whose walk never starts: everything was seed work)
         u32 app = st_app, sapp = st_seed_app;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -991,8 +932,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     const u32 wib = wave_in_block();
     u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI, MULTI ? 0 : KCAP) * 64 + lane;
     if (PCPX_COMPACT_BY8 && !MULTI && (KCAP <= 16 || PCPX_BY8_K32)) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
+        const u64 pad = pad_key_here();
 #pragma unroll
-        for (int j = 0; j < BUF; ++j) col[j * 64] = PAD_KEY;
+        for (int j = 0; j < BUF; ++j) col[j * 64] = pad;
     }
     const u32 ngroups = group_end - group_first;
     const u32 per = (ngroups + 7u) >> 3;
