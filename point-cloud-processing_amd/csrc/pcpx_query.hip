@@ -93,6 +93,29 @@ __device__ __forceinline__ void bitonic_sort(u64 (&a)[N])
     }
 }
 
+// Sorting networks with the fewest compare-exchanges known for their size (8: 19 against the bitonic 24; 4: 5 against 6;
+// checked on all 0/1 inputs): ascending.
+template <int N>
+__device__ __forceinline__ void sort_network(u64 (&a)[N])
+{
+    static_assert(N == 2 || N == 4 || N == 8, "sizes the compaction uses");
+    if constexpr (N == 2) {
+        ce(a[0], a[1]);
+    } else if constexpr (N == 4) {
+        ce(a[0], a[1]); ce(a[2], a[3]);
+        ce(a[0], a[2]); ce(a[1], a[3]);
+        ce(a[1], a[2]);
+    } else {
+        ce(a[0], a[1]); ce(a[2], a[3]); ce(a[4], a[5]); ce(a[6], a[7]);
+        ce(a[0], a[2]); ce(a[1], a[3]); ce(a[4], a[6]); ce(a[5], a[7]);
+        ce(a[1], a[2]); ce(a[5], a[6]); ce(a[0], a[4]); ce(a[3], a[7]);
+        ce(a[1], a[5]); ce(a[2], a[6]);
+        ce(a[1], a[4]); ce(a[3], a[6]);
+        ce(a[2], a[4]); ce(a[3], a[5]);
+        ce(a[3], a[4]);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 {
@@ -123,6 +146,10 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #endif
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
+#endif
+#ifndef PCPX_COMPACT_TIER4
+#define PCPX_COMPACT_TIER4 8  // largest KCAP whose compaction has a four-key tier (k <= 8: +2 %; k <= 16: the branch costs the kernel
+                              // scratch at 7 waves per SIMD and nothing at 6; k <= 32: no difference)
 #endif
 #ifndef PCPX_BY8_K32
 #define PCPX_BY8_K32 1  // the chunk-of-8 compaction (with its PAD invariant established) for the single-pass k <= 32 kernel too
@@ -216,27 +243,37 @@ __device__ __forceinline__ void drop_eps_box(u64 (&nw)[N], u64* __restrict__ col
     for (int j = 0; j < N; ++j) nw[j] = j < R ? col_r0[j * 64] : pad;
 #pragma unroll
     for (int j = 0; j < R; ++j) col_r0[j * 64] = pad;
-    bitonic_sort<N>(nw);
+    sort_network<N>(nw);
 }
 
 template <int KCAP, int BUF>
 __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt, const EpsFilter& f)
 {
     static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 8, "rows");
-    {   // (tried: a third tier that reads and sorts only 4 keys when no lane holds more -- 47 % of the compactions: the
-        // extra path costs the k <= 16 kernel 20 B/lane more scratch, 1275 -> 1235 Mq/s; k <= 8: +1 %)
+    if (KCAP <= PCPX_COMPACT_TIER4 && !any_lane(cnt > 4)) {  // about half of the compactions of a walk: four rows, five compare-exchanges
+        u64 nw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nw[j] = col[j * 64];
+        const u64 pad = pad_key_here();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) col[j * 64] = pad;
+        sort_network<4>(nw);
+        if (f.on) drop_eps_box<4, 4>(nw, col, f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+    } else {
         u64 nw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) nw[j] = col[j * 64];
         const u64 pad = pad_key_here();
 #pragma unroll
         for (int j = 0; j < 8; ++j) col[j * 64] = pad;
-        bitonic_sort<8>(nw);
+        sort_network<8>(nw);
         if (f.on) drop_eps_box<8, 8>(nw, col, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
-        bitonic_merge<KCAP>(best);
     }
+    bitonic_merge<KCAP>(best);  // (one copy for both tiers: only best[] crosses the join)
     if (BUF > 8 && any_lane(cnt > 8)) {
         constexpr int R = BUF > 8 ? BUF - 8 : 1;               // rows of the second chunk
         constexpr int N = R <= 2 ? 2 : R <= 4 ? 4 : 8;         // its sorting network (10 rows: one compare-exchange)
@@ -246,7 +283,7 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         for (int j = 0; j < N; ++j) nw[j] = j < R ? col[(8 + j) * 64] : pad;
 #pragma unroll
         for (int j = 8; j < BUF; ++j) col[j * 64] = pad;
-        bitonic_sort<N>(nw);
+        sort_network<N>(nw);
         if (f.on) drop_eps_box<R, N>(nw, col + 8 * 64, f);
 #pragma unroll
         for (int j = 0; j < N; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
@@ -679,29 +716,27 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     for (u32 rounds = 0;;) {
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
-        for (;;) {
-            // pop until the next leaf outside the seed range (a seed leaf was seen under a larger tau than any later one) --
-            // "is there one" stays in the control flow: see WalkerT::pop
-            u32 leaf = 0;
+        // pop until the next leaf outside the seed range (a seed leaf was seen under a larger tau than any later one) -- "is
+        // there one" stays in the control flow (see WalkerT::pop), written with labels so that it stays there
+        {
+            u32 loc;
+            int h;
+        walk_on:
             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-            for (;;) {
-                if (wk.done()) goto round_done;
-                u32 loc;
-                const int h = wk.pop(loc);
-                if (h != 0) {
-                    ++st_expand;
-                    wk.expand(t, h, loc, need);
-                    continue;
-                }
-                wk.at_leaf(loc);
-                if (loc - s0 >= seed_count) {
-                    leaf = loc;
-                    break;
-                }
+        pop_next:
+            if (wk.done()) goto round_done;
+            h = wk.pop(loc);
+            if (h != 0) {
+                ++st_expand;
+                wk.expand(t, h, loc, need);
+                goto pop_next;
             }
+            wk.at_leaf(loc);
+            if (loc - s0 < seed_count) goto pop_next;
             if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
             fold_if_needed(true, false);
-            candidates(leaf, shell);
+            candidates(loc, shell);
+            goto walk_on;
         }
     round_done:
         fold_if_needed(false, false);
