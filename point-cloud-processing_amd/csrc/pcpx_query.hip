@@ -116,7 +116,9 @@ __device__ __forceinline__ void sort_network(u64 (&a)[N])
     }
 }
 
-template <int N>
+// SKIP: the first SKIP elements are known to hold 0, the smallest key there is (the best-list's sentinels when k < KCAP): a
+// compare-exchange with one of them changes nothing and is left out (k = 15: 4 of the 32 of every merge).
+template <int N, int SKIP = 0>
 __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 {
 #pragma unroll
@@ -124,7 +126,7 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             int l = i ^ j;
-            if (l > i) ce(a[i], a[l]);
+            if (l > i && i >= SKIP) ce(a[i], a[l]);
         }
     }
 }
@@ -246,7 +248,7 @@ __device__ __forceinline__ void drop_eps_box(u64 (&nw)[N], u64* __restrict__ col
     sort_network<N>(nw);
 }
 
-template <int KCAP, int BUF>
+template <int KCAP, int BUF, int NZ>
 __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__ col, int& cnt, const EpsFilter& f)
 {
     static_assert(BUF >= 8 && BUF <= 16 && KCAP >= 8, "rows");
@@ -273,7 +275,7 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
     }
-    bitonic_merge<KCAP>(best);  // (one copy for both tiers: only best[] crosses the join)
+    bitonic_merge<KCAP, NZ>(best);  // (one copy for both tiers: only best[] crosses the join)
     if (BUF > 8 && any_lane(cnt > 8)) {
         constexpr int R = BUF > 8 ? BUF - 8 : 1;               // rows of the second chunk
         constexpr int N = R <= 2 ? 2 : R <= 4 ? 4 : 8;         // its sorting network (10 rows: one compare-exchange)
@@ -287,7 +289,7 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         if (f.on) drop_eps_box<R, N>(nw, col + 8 * 64, f);
 #pragma unroll
         for (int j = 0; j < N; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
-        bitonic_merge<KCAP>(best);
+        bitonic_merge<KCAP, NZ>(best);
     }
     cnt = 0;
 }
@@ -489,7 +491,8 @@ struct MultiPass {
 };
 
 // One query group (64 curve-consecutive queries, one per lane) from start to finish.
-template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH>
+// NZ: the caller guarantees k <= KCAP - NZ (NZ sentinel slots at the bottom of the best-list hold 0 throughout)
+template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH, int NZ>
 __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k_arg, const float eps,
                                           const float eps_thr, const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
                                           u64* __restrict__ col, const u32 lane)
@@ -601,7 +604,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             st_c3 += any_lane(cnt > 3) ? 0u : 1u;
             st_c4 += any_lane(cnt > 4) ? 0u : 1u;
         }
-        if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF>(best, col, cnt, eps_filter);
+        if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF, NZ>(best, col, cnt, eps_filter);
         else compact<KCAP, BUF>(best, col, cnt);
         float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         tau = active ? fminf(nt, cap) : -1.f;
@@ -956,7 +959,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 // under-reports on gfx950 (this grid is fully resident by construction).
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
-template <int KCAP, bool SELF, bool STATS, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS>
+template <int KCAP, bool SELF, bool STATS, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS, int NZ = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
     TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, float eps_thr, KnnOutputs o, MultiPass mp,
     u32* __restrict__ queue, unsigned long long* __restrict__ stats)
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
                 tg = __builtin_amdgcn_s_memrealtime();
                 tcg = __builtin_amdgcn_s_memtime();
             }
-            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH>(t, qv, group_first + qbeg + gi, k, eps, eps_thr, o, mp, stats, col, lane);
+            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, qv, group_first + qbeg + gi, k, eps, eps_thr, o, mp, stats, col, lane);
             if (STATS) {
                 if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
                 ++n_done;
@@ -1062,7 +1065,7 @@ static float eps_box_threshold(const Index& ix, float eps)
     return t <= 0.01 * spacing * spacing ? thr : -1.f;
 }
 
-template <int KCAP, bool SELF, bool EPS_EACH>
+template <int KCAP, bool SELF, bool EPS_EACH, int NZ>
 static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcount, u32 k, float eps, float thr, const KnnOutputs& o)
 {
     constexpr int BUF = buf_rows(KCAP);
@@ -1070,7 +1073,7 @@ static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcoun
     const u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
-    auto* fn = k_knn<KCAP, SELF, false, false, EPS_EACH>;
+    auto* fn = k_knn<KCAP, SELF, false, false, EPS_EACH, NZ>;
     const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WAVES_PER_BLOCK, lds, gcount);
     ProfileScope prof(ix, PCPX_K_KNN);
     fn<<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr);
@@ -1082,11 +1085,15 @@ static int launch_knn_t(Index& ix, const QueryView& qv, bool self, u64 gfirst, u
 {
     const float thr = eps_box_threshold(ix, eps);
     if (PCPX_DEFER_EPS && thr >= 0.f) {
-        return self ? launch_knn_form<KCAP, true, false>(ix, qv, gfirst, gcount, k, eps, thr, o)
-                    : launch_knn_form<KCAP, false, false>(ix, qv, gfirst, gcount, k, eps, thr, o);
+        if (k < static_cast<u32>(KCAP)) {  // at least one sentinel slot: its compare-exchanges are compiled out
+            return self ? launch_knn_form<KCAP, true, false, 1>(ix, qv, gfirst, gcount, k, eps, thr, o)
+                        : launch_knn_form<KCAP, false, false, 1>(ix, qv, gfirst, gcount, k, eps, thr, o);
+        }
+        return self ? launch_knn_form<KCAP, true, false, 0>(ix, qv, gfirst, gcount, k, eps, thr, o)
+                    : launch_knn_form<KCAP, false, false, 0>(ix, qv, gfirst, gcount, k, eps, thr, o);
     }
-    return self ? launch_knn_form<KCAP, true, true>(ix, qv, gfirst, gcount, k, eps, thr, o)
-                : launch_knn_form<KCAP, false, true>(ix, qv, gfirst, gcount, k, eps, thr, o);
+    return self ? launch_knn_form<KCAP, true, true, 0>(ix, qv, gfirst, gcount, k, eps, thr, o)
+                : launch_knn_form<KCAP, false, true, 0>(ix, qv, gfirst, gcount, k, eps, thr, o);
 }
 
 // ---- k > 32: stitch the per-pass keys of every query into its output row -----------------------------

@@ -46,11 +46,13 @@ while time.time() < t_end:
     pts, kind = cloud(n)
     n = len(pts)
     k = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 31, 32, 33, 40, 70]))
-    eps = float(rng.choice([1e-5, 0.0, 1e-3, 1e-7]))
+    eps = float(rng.choice([1e-5, 0.0, 1e-3, 1e-7, 3e-2]))
     coarse = bool(rng.integers(0, 2))  # PCPX_BUILD_COARSE_ORDER: same results by contract
     ix = pkg.Index(pts, coarse_order=coarse)
+    eps_mode = int(rng.integers(0, 3))  # where k_knn applies the eps-box test: same results by contract
+    ix.debug_eps_test_mode(eps_mode)
     sel = rng.choice(n, size=min(n, 300), replace=False)
-    what = {"n": n, "kind": kind, "k": k, "eps": eps, "coarse_order": coarse, "seed": seed, "case": cases}
+    what = {"n": n, "kind": kind, "k": k, "eps": eps, "coarse_order": coarse, "eps_test_mode": eps_mode, "seed": seed, "case": cases}
     print("case", json.dumps(what), flush=True)  # so that a hang names its case
     try:
         idx, cnt = ix.knn_self(k, eps)[:2]
