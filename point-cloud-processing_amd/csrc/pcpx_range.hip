@@ -44,23 +44,57 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
     u64 wpos = (FILL && valid) ? offsets[row] : 0;
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
 
-    Walker wk;
-    u32 leaf = 0, nexp = 0;
-    bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
-    if (!more) more = wk.next(t, need, leaf, nexp);
-    while (more) {
+    auto leaf_points = [&](const u32 leaf) {
         const Leaf lf = load_const(t.leaves + leaf);
+        if (!FILL) {
+            // count: the eight "inside" masks first (a scalar register pair each), then eight add-with-carry -- from
+            // `cnt += in` hipcc pairs the points up as compare, select 0/1 under VCC, compare, add-with-carry, and the select
+            // under a VCC that a compare has just written issues in 23 cycles on gfx950 (profiles/r03_valu_issue_rates.txt)
+            u64 inside[LEAF];
+#pragma unroll
+            for (int j = 0; j < LEAF; ++j) {
+                float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+                inside[j] = __builtin_amdgcn_ballot_w64(sq3(dx, dy, dz) <= r2);
+            }
+            static_assert(LEAF == 8, "eight masks");
+            u64 carry_out;  // (one statement: between two that pass a register on hipcc puts an s_nop)
+            asm("v_addc_co_u32_e64 %0, %1, %0, 0, %2\n\tv_addc_co_u32_e64 %0, %1, %0, 0, %3\n\t"
+                "v_addc_co_u32_e64 %0, %1, %0, 0, %4\n\tv_addc_co_u32_e64 %0, %1, %0, 0, %5\n\t"
+                "v_addc_co_u32_e64 %0, %1, %0, 0, %6\n\tv_addc_co_u32_e64 %0, %1, %0, 0, %7\n\t"
+                "v_addc_co_u32_e64 %0, %1, %0, 0, %8\n\tv_addc_co_u32_e64 %0, %1, %0, 0, %9"
+                : "+v"(cnt), "=&s"(carry_out)
+                : "s"(inside[0]), "s"(inside[1]), "s"(inside[2]), "s"(inside[3]), "s"(inside[4]), "s"(inside[5]), "s"(inside[6]),
+                  "s"(inside[7]));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
             float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
             bool in = sq3(dx, dy, dz) <= r2;
-            if (FILL) {
-                if (in) out_idx[wpos + cnt] = lf.id[j];
-            }
+            if (in) out_idx[wpos + cnt] = lf.id[j];
             cnt += in ? 1u : 0u;
         }
-        more = wk.next(t, need, leaf, nexp);
+    };
+    // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
+    Walker wk;
+    u32 nexp = 0;
+    if (wk.start(t, need, nexp)) {  // the root is the only leaf
+        leaf_points(0u);
+    } else {
+        u32 loc;
+        int h;
+    pop_next:
+        if (wk.done()) goto walked;
+        h = wk.pop(loc);
+        if (h != 0) {
+            wk.expand(t, h, loc, need);
+            goto pop_next;
+        }
+        wk.at_leaf(loc);
+        leaf_points(loc);
+        goto pop_next;
     }
+walked:
     if (valid && !FILL) out_cnt[row] = cnt;
 }
 
@@ -102,11 +136,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
         bool o = (n.hi[0] >= b0) & (n.hi[1] >= b1) & (n.hi[2] >= b2) & (n.lo[0] <= b3) & (n.lo[1] <= b4) & (n.lo[2] <= b5);
         return o & (n.poison == 0.f) & valid;
     };
-    Walker wk;
-    u32 leaf = 0, nexp = 0;
-    bool more = wk.start(t, need, nexp);
-    if (!more) more = wk.next(t, need, leaf, nexp);
-    while (more) {
+    auto leaf_points = [&](const u32 leaf) {
         const Leaf lf = load_const(t.leaves + leaf);
 #pragma unroll
         for (int j = 0; j < LEAF; ++j) {
@@ -117,8 +147,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
             }
             cnt += in ? 1u : 0u;
         }
-        more = wk.next(t, need, leaf, nexp);
+    };
+    Walker wk;
+    u32 nexp = 0;
+    if (wk.start(t, need, nexp)) {
+        leaf_points(0u);
+    } else {
+        u32 loc;
+        int h;
+    pop_next:
+        if (wk.done()) goto walked;
+        h = wk.pop(loc);
+        if (h != 0) {
+            wk.expand(t, h, loc, need);
+            goto pop_next;
+        }
+        wk.at_leaf(loc);
+        leaf_points(loc);
+        goto pop_next;
     }
+walked:
     if (valid && !FILL) out_cnt[p] = cnt;
 }
 
