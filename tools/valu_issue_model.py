@@ -1,40 +1,53 @@
 #!/usr/bin/env python3
-"""VALU issue-cycle model of k_knn (DESIGN.md "Roofline"): per-group event counts of the diagnostic build
-(profiles/<tag>_knn_phase_stats_uniform.json) x the VALU instructions each event issues (counted in the ISA, tools/isa_extract.py)
-x the measured issue cost of each instruction class (profiles/<tag>_valu_issue_rates.txt), against the SIMD cycles available per
-group at the measured kernel duration (profiles/<tag>_bench.json).  Writes profiles/<tag>_valu_issue_model.json."""
+"""Issue-cycle model of k_knn (DESIGN.md "Roofline"), vector pipe and scalar pipe side by side.
+Vector: per-group event counts of the diagnostic build (profiles/<tag>_knn_phase_stats_uniform.json) x the VALU instructions each
+event issues (counted in the ISA) x the measured issue cost of each instruction class (profiles/<tag>_valu_issue_rates.txt).
+Scalar: the launch's scalar-pipe instruction count from the counters (profiles/<tag>_pmc_summary.json: SALU + SMEM + branches +
+whatever SQ_INSTS has beyond the vector / LDS / memory classes: s_waitcnt, s_nop) x the measured 4.1 cycles of an s_add_u32.
+Both against the SIMD cycles available per group at the measured kernel duration (profiles/<tag>_bench.json).
+Writes profiles/<tag>_valu_issue_model.json."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
 st = json.load(open(P("knn_phase_stats_uniform.json")))["per_group"]
-bench = json.load(open(P("bench.json")))
-SIMPLE, THREE_OP, CMP, F64 = 2.4, 4.4, 4.1, 4.2  # cycles per wave-instruction per SIMD (valu_issue_rates.txt, >= 2 waves resident)
-candidate = 8 * SIMPLE + THREE_OP + 2 * CMP + 2 * SIMPLE      # distance (8) + v_max3 + 2 v_cmpx + address and position bumps
+bench = json.loads(open(P("bench.json")).read().strip().splitlines()[-1])
+SIMPLE, THREE_OP, CMP, F64, SCALAR = 2.4, 4.4, 4.1, 4.2, 4.1  # cycles per wave-instruction per SIMD (valu_issue_rates.txt, >= 2 waves resident)
+candidate = 10 * SIMPLE + CMP                                 # distance (8) + v_cmpx + address and position bumps (the eps-box test waits for the compaction)
 box = 14 * SIMPLE + 3 * THREE_OP + CMP                        # 6 sub, 3 mul, 3 add, poison add, ... + 3 v_max3 + v_cmp (16 VALU)
 ce = 2 * F64                                                  # compare-exchange = v_min_f64 + v_max_f64
-chunk = (24 + 32) * ce + 8 * F64 + 30   # one chunk of 8 keys: sort 8, 8 mins, merge 16, overhead (empty slots hold PAD_KEY: no masks)
-compact_short = chunk          # no lane holds more than 8 keys
-compact_full = 2 * chunk       # rows 8..BUF-1 as a second chunk
-leaves = st["leaves"] + st["seed_leaves"]
-steps = leaves + st["expansions"]
+chunk = (19 + 28) * ce + 8 * F64 + 30   # one chunk of 8 keys: 19-comparator sort, 8 mins, merge of 16 less the 4 sentinel exchanges (k = 15)
+second = (1 + 28) * ce + 2 * F64 + 10   # rows 8 .. 9: one compare-exchange, 2 mins, the merge again
 short_share = 0.85  # share of compactions in which no lane holds more than 8 keys (the trigger is "more than 2")
+leaves = st["leaves"] + st["seed_leaves"]
 parts = {
     "leaf_candidates": leaves * 8 * candidate,
     "box_tests": st["expansions"] * 4 * box,
-    "compactions": st["compactions"] * (short_share * compact_short + (1 - short_share) * compact_full),
-    "loop_control": steps * 25.0,
-    "cap_epilogue_setup": 4000.0,
+    "compactions": st["compactions"] * (chunk + (1 - short_share) * second),
+    "cap_epilogue_setup": 6000.0,
 }
 groups = bench["config"]["queries"] / 64
 clock_hz, simds = 2.4e9, 1024
 available = bench["roofline"]["avg_launch_ms"] * 1e-3 * clock_hz * simds / groups
 total = sum(parts.values())
-out = {"kernel": "k_knn<16,true,false,false>", "workload": bench["config"]["workload"],
+out = {"kernel": "k_knn<16,true,false,false,false,1>", "workload": bench["config"]["workload"],
        "valu_issue_cycles_per_group": {k: round(v) for k, v in parts.items()}, "valu_issue_cycles_per_group_total": round(total),
        "simd_cycles_available_per_group": round(available), "valu_issue_frac": round(total / available, 3),
-       "note": "issue costs were measured on streams of one instruction each; a value near 1 says the SIMDs are saturated with vector issue, not that the model is exact",
+       "note": "issue costs were measured on streams of one instruction each; a value near 1 says the pipe is saturated, not that the model is exact",
        "assumptions": {"clock_GHz": 2.4, "simds": simds, "short_compaction_share": short_share,
-                       "issue_cost_cycles": {"simple_vop2": SIMPLE, "three_operand": THREE_OP, "compare": CMP, "f64_min_max": F64}}}
+                       "issue_cost_cycles": {"simple_vop2": SIMPLE, "three_operand": THREE_OP, "compare": CMP, "f64_min_max": F64, "scalar": SCALAR}}}
+try:
+    pmc = json.load(open(P("pmc_summary.json")))
+    k = next(v for name, v in pmc.items() if name.startswith("k_knn<16,true,false,false"))
+    c = lambda n: k[n]["avg_per_dispatch"] if n in k else 0.0
+    other = max(0.0, c("SQ_INSTS") - c("SQ_INSTS_VALU") - c("SQ_INSTS_SALU") - c("SQ_INSTS_SMEM") - c("SQ_INSTS_LDS") - c("SQ_INSTS_BRANCH")) if c("SQ_INSTS") else 0.0
+    scalar = c("SQ_INSTS_SALU") + c("SQ_INSTS_SMEM") + c("SQ_INSTS_BRANCH") + other
+    out["counters_per_group"] = {"valu": round(c("SQ_INSTS_VALU") / groups), "salu": round(c("SQ_INSTS_SALU") / groups), "smem": round(c("SQ_INSTS_SMEM") / groups),
+                                 "lds": round(c("SQ_INSTS_LDS") / groups), "branch": round(c("SQ_INSTS_BRANCH") / groups),
+                                 "other (s_waitcnt, s_nop, vector memory ...)": round(other / groups)}
+    out["scalar_pipe_cycles_per_group"] = round(scalar / groups * SCALAR)
+    out["scalar_pipe_frac"] = round(scalar / groups * SCALAR / available, 3)
+except Exception as e:  # counters not collected yet
+    out["scalar_pipe_note"] = "no counters: %r" % (e,)
 json.dump(out, open(P("valu_issue_model.json"), "w"), indent=1)
 print(json.dumps(out))
