@@ -632,7 +632,7 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
         u32* done_count = ix->d_queue + 8 * 16 - 1;
         std::memcpy(stage + o_q, q_xyz, nq * 3 * sizeof(float));
         const u32 epoch = ++ix->few_epoch ? ix->few_epoch : ++ix->few_epoch;  // never 0
-        if ((st = launch_knn_few(*ix, reinterpret_cast<const float*>(stage + o_q), static_cast<u32>(nq), k, eps,
+        if ((st = launch_knn_few(*ix, reinterpret_cast<const float*>(stage + o_q), q_xyz, static_cast<u32>(nq), k, eps,
                                  reinterpret_cast<u32*>(stage + o_idx), reinterpret_cast<u32*>(stage + o_cnt),
                                  out_d2 ? reinterpret_cast<float*>(stage + o_d2) : nullptr, reinterpret_cast<u32*>(stage + o_flag),
                                  done_count, const_cast<u32*>(done), epoch)) != PCPX_OK)

@@ -5,16 +5,19 @@
 // a query one lane and walks the tree step by dependent step: ~190 dependent record fetches for a lone query, and a sort
 // of the batch in front of it.  Here a whole wavefront serves one query and the parallelism is INSIDE the query:
 //
-//   1. beam descent: level by level keep the 8 nodes whose boxes are nearest to the query (32 child boxes tested by
-//      32 lanes at once, ranked by counting) -> 8 leaves = 64 points, one per lane; tau0 = k-th smallest distance among
-//      them: an upper bound of the true k-th distance;
-//   2. pruned breadth-first sweep: per level every child of the frontier is tested by its own lane against tau0, the
-//      survivors are compacted (ballot + prefix count) into the next frontier in LDS;
+//   1. beam descent: the (up to 64) nodes of tree level 3 are tested by one lane each, then two levels per step -- the 16
+//      grandchildren of a node are contiguous in the heap layout, so the 4 nearest nodes give 64 boxes, one per lane --
+//      down to the 8 nearest leaves = 64 points, one per lane; tau0 = k-th smallest distance among them: an upper bound of
+//      the true k-th distance;
+//   2. pruned breadth-first sweep, again from level 3 (with the box distances step 1 already has) and two levels per
+//      step: every grandchild of the frontier is tested by its own lane against tau0, the survivors are compacted (ballot +
+//      prefix count) into the next frontier in LDS;
 //   3. the points of the surviving leaves, one per lane, with d2 <= tau0 outside the eps-box are the candidates (a
 //      superset of the answer); the k smallest by (d2, index) are found by counting ranks and written in order.
 //
-// About 2 x depth + 3 dependent memory round trips per query instead of ~190, no sort, no allocation, and the query
-// and the row can live in pinned host memory (the host-pointer entry points do exactly that: no copy is issued).
+// About depth + 3 dependent memory round trips per query (rounds 1-2: 2 x depth + 3) instead of ~190, no sort, no allocation;
+// the query and the row can live in pinned host memory (the host-pointer entry points do exactly that: no copy is issued),
+// and a single query travels in the kernel arguments (one PCIe read less).
 // Arithmetic is the reference's (d = p - q, dx*dx + dy*dy + dz*dz in float32 without FMA, eps-box exclusion), rows are
 // ascending in (d2, index): identical to the throughput kernel's rows except for WHICH of several points tied exactly at
 // the k-th distance is kept -- unspecified in the reference too (linked_octree_node.hpp:479-489).
@@ -50,8 +53,44 @@ __device__ __forceinline__ u32 rank_among(float v, u32 lane)
 
 __device__ __forceinline__ u32 level_base(int d) { return d == 0 ? 0u : (0x55555555u >> (32 - 2 * d)); }
 
-__global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restrict__ queries, u32 nq, u32 k, float eps,
-                                                u32* __restrict__ out_idx, u32* __restrict__ out_cnt, float* __restrict__ out_d2,
+// smallest value over the wave (DPP within rows of 16, then the four rows through scalar registers)
+__device__ __forceinline__ u32 wave_min_u32(u32 v)
+{
+    auto step = [](u32 x, auto ctrl) {
+        const u32 o = static_cast<u32>(__builtin_amdgcn_update_dpp(static_cast<int>(x), static_cast<int>(x), decltype(ctrl)::value, 0xF, 0xF, false));
+        return o < x ? o : x;
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+    v = step(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+    v = step(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane of a row holds the row's minimum
+    const u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
+              d = __builtin_amdgcn_readlane(v, 48);
+    const u32 ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// The `keep` lanes with the smallest finite non-negative `v` write `node` to out[0 .. count) in ascending order of v (ties and
+// the lowest 6 mantissa bits: by lane -- this only steers the beam); returns count.  Wave-uniform control flow.
+__device__ __forceinline__ u32 keep_nearest(float v, bool valid, u32 node, u32 keep, u32* __restrict__ out, u32 lane)
+{
+    const float inf = std::numeric_limits<float>::infinity();
+    u32 key = (valid && v < inf) ? ((__float_as_uint(v) & ~63u) | lane) : 0xFFFFFFFFu;
+    u32 count = 0;
+    for (; count < keep; ++count) {
+        const u32 m = wave_min_u32(key);
+        if (m == 0xFFFFFFFFu) break;
+        if (lane == (m & 63u)) {
+            out[count] = node;
+            key = 0xFFFFFFFFu;
+        }
+    }
+    return count;
+}
+
+// q_in_args != 0 (a single query): the query is q0x, q0y, q0z and `queries` is not read
+__global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restrict__ queries, u32 nq, u32 q_in_args, float q0x, float q0y, float q0z, u32 k,
+                                                float eps, u32* __restrict__ out_idx, u32* __restrict__ out_cnt, float* __restrict__ out_d2,
                                                 u32* __restrict__ flags, u32* __restrict__ done_count, u32* __restrict__ done_flag,
                                                 u32 epoch)
 {
@@ -74,7 +113,12 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
             }
         }
     };
-    const float qx = queries[3ull * qi], qy = queries[3ull * qi + 1], qz = queries[3ull * qi + 2];
+    float qx = q0x, qy = q0y, qz = q0z;
+    if (!q_in_args) {
+        qx = queries[3ull * qi];
+        qy = queries[3ull * qi + 1];
+        qz = queries[3ull * qi + 2];
+    }
     u32* row_idx = out_idx + static_cast<u64>(qi) * k;
     float* row_d2 = out_d2 ? out_d2 + static_cast<u64>(qi) * k : nullptr;
     if (lane == 0) flags[qi] = 0u;
@@ -88,25 +132,33 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
         return;
     }
 
-    // ---- 1. beam descent ----
-    u32 nbeam = 1;
-    if (lane == 0) front[0][0] = 0u;
-    __syncthreads();
-    int cur = 0;
-    for (int d = 0; d < t.depth; ++d) {
-        float bd = inf;
-        u32 node = 0;
-        if (lane < 4u * nbeam) {
-            node = front[cur][lane >> 2] * 4u + (lane & 3u);  // local index at level d + 1
-            const NodeBox b = t.nodes[level_base(d + 1) + node];
-            const float v = box_d2(b, qx, qy, qz);
-            bd = v == v ? v : inf;  // padding nodes (NaN) rank last
+    // real nodes of tree level l (the ones the build writes: the children of a real node need not be real)
+    auto nreal = [&](int l) { return (t.nleaves + (1u << (2 * (t.depth - l))) - 1u) >> (2 * (t.depth - l)); };
+    // box distance of node `node` of level l, +inf if it does not exist or is padding (NaN)
+    auto box_at = [&](int l, u32 node, bool mine) {
+        float v = inf;
+        if (mine && node < nreal(l)) {
+            const NodeBox b = t.nodes[level_base(l) + node];
+            const float w = box_d2(b, qx, qy, qz);
+            v = w == w ? w : inf;
         }
-        const u32 r = rank_among<4 * BEAM>(bd, lane);
-        const u64 keep = __builtin_amdgcn_ballot_w64(lane < 4u * nbeam && bd < inf && r < BEAM);
-        __syncthreads();
-        if (lane < 4u * nbeam && bd < inf && r < BEAM) front[cur ^ 1][r] = node;
-        nbeam = static_cast<u32>(__builtin_popcountll(keep));  // ranks of the finite values are 0 .. count-1: dense
+        return v;
+    };
+
+    // ---- 1. beam descent ----
+    const int l0 = t.depth < 3 ? t.depth : 3;  // first level looked at: at most 64 nodes, lane = node
+    const float bd0 = box_at(l0, lane, lane < (1u << (2 * l0)));
+    int cur = 0;
+    u32 nbeam = keep_nearest(bd0, true, lane, l0 == t.depth ? BEAM : 4u, front[0], lane);
+    __syncthreads();
+    for (int d = l0; d < t.depth;) {
+        const int s = t.depth - d >= 2 ? 2 : 1;  // levels this step goes down: 16 (or 4) descendants per beam node
+        const u32 fan = 1u << (2 * s);
+        const bool mine = lane < nbeam * fan;
+        const u32 node = mine ? front[cur][lane >> (2 * s)] * fan + (lane & (fan - 1u)) : 0u;
+        const float bd = box_at(d + s, node, mine);
+        d += s;
+        nbeam = keep_nearest(bd, mine, node, d == t.depth ? BEAM : 4u, front[cur ^ 1], lane);
         cur ^= 1;
         __syncthreads();
     }
@@ -129,29 +181,29 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
         if (kth != 0ull) tau0 = lane_value(d2, __builtin_ctzll(kth));
     }
 
-    // ---- 2. pruned breadth-first sweep ----
+    // ---- 2. pruned breadth-first sweep, from level l0 (whose box distances are in bd0) ----
     __syncthreads();
-    if (lane == 0) front[0][0] = 0u;
-    __syncthreads();
-    cur = 0;
-    u32 m = 1;  // frontier size at level d
+    u32 m = 0;  // frontier size at level d
     bool overflow = false;
-    {   // the root itself
-        const NodeBox rb = t.nodes[0];
-        const float v = box_d2(rb, qx, qy, qz);
-        if (!(v <= tau0)) m = 0;
+    {
+        const bool need = bd0 <= tau0;  // (+inf: no such node; tau0 = +inf keeps every real one)
+        const bool keep0 = need && bd0 < inf;
+        const u64 mask = __builtin_amdgcn_ballot_w64(keep0);
+        const u32 below = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mask), 0u));
+        if (keep0) front[0][below] = lane;
+        m = static_cast<u32>(__builtin_popcountll(mask));
     }
-    for (int d = 0; d < t.depth && m > 0; ++d) {
+    cur = 0;
+    __syncthreads();
+    for (int d = l0; d < t.depth && m > 0;) {
+        const int s = t.depth - d >= 2 ? 2 : 1;
+        const u32 fan = 1u << (2 * s);
         u32 next = 0;
-        for (u32 c0 = 0; c0 < 4u * m; c0 += 64u) {
+        for (u32 c0 = 0; c0 < fan * m; c0 += 64u) {
             const u32 c = c0 + lane;
-            bool need = false;
-            u32 node = 0;
-            if (c < 4u * m) {
-                node = front[cur][c >> 2] * 4u + (c & 3u);
-                const NodeBox b = t.nodes[level_base(d + 1) + node];
-                need = box_d2(b, qx, qy, qz) <= tau0;  // false for padding nodes (NaN)
-            }
+            const bool mine = c < fan * m;
+            const u32 node = mine ? front[cur][c >> (2 * s)] * fan + (c & (fan - 1u)) : 0u;
+            const bool need = box_at(d + s, node, mine) <= tau0 && mine && node < nreal(d + s);
             const u64 mask = __builtin_amdgcn_ballot_w64(need);
             const u32 below = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mask), 0u));
             const u32 slot = next + below;
@@ -162,6 +214,7 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
             overflow = true;
             next = FRONTIER;
         }
+        d += s;
         m = next;
         cur ^= 1;
         __syncthreads();
@@ -222,12 +275,15 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
 }  // namespace
 
 // queries (nq x 3), rows and flags may be device memory or pinned host memory mapped into the device
-int launch_knn_few(Index& ix, const float* q_aos, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2, u32* flags,
-                   u32* done_count, u32* done_flag, u32 epoch)
+int launch_knn_few(Index& ix, const float* q_aos, const float* q_host, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2,
+                   u32* flags, u32* done_count, u32* done_flag, u32 epoch)
 {
     if (nq == 0) return PCPX_OK;
     ProfileScope prof(ix, PCPX_K_KNN);
-    k_knn_few<<<nq, 64, 0, ix.stream>>>(ix.view(), q_aos, nq, k, sanitize_eps(eps), out_idx, out_cnt, out_d2, flags, done_count, done_flag,
+    // a single query travels in the kernel arguments when the caller can read it (q_host: the same query on the host side)
+    const bool in_args = nq == 1 && q_host != nullptr;
+    k_knn_few<<<nq, 64, 0, ix.stream>>>(ix.view(), q_aos, nq, in_args ? 1u : 0u, in_args ? q_host[0] : 0.f, in_args ? q_host[1] : 0.f,
+                                        in_args ? q_host[2] : 0.f, k, sanitize_eps(eps), out_idx, out_cnt, out_d2, flags, done_count, done_flag,
                                         epoch);
     return check_hip(hipGetLastError(), "k_knn_few launch", __FILE__, __LINE__);
 }

@@ -252,8 +252,9 @@ int orient_normals_device(const float* d_xyz, u64 n, const u32* d_nbr, const u32
 // kNN + whatever per-neighbourhood products are requested (any pointer may be nullptr); all fused in k_knn
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
                const KnnOutputs& o);
-int launch_knn_few(Index& ix, const float* q_aos, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2, u32* flags,
-                   u32* done_count, u32* done_flag, u32 epoch);
+// (q_host: the queries where the host can read them, or nullptr -- a single query is then passed in the kernel arguments)
+int launch_knn_few(Index& ix, const float* q_aos, const float* q_host, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2,
+                   u32* flags, u32* done_count, u32* done_flag, u32 epoch);
 int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, const float* d_known_d2 = nullptr);
 int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, float radius,
                        const float* d_radii, u32* d_out_cnt);

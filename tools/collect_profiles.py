@@ -25,7 +25,8 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("rebuild_10m_clustered.json", "rebuild_10m_clustered.json"), ("rebuild_10m_coarse.json", "rebuild_10m_coarse_order.json"),
                   ("rebuild_50m_coarse.json", "rebuild_50m_coarse_order.json"),
                   ("pmc_range/range_kernel_stats.txt", "range_kernel_stats.txt"), ("pmc_range/range_under_prof.json", "range_count_10m.json"),
-                  ("valu_issue_rates.txt", "valu_issue_rates.txt"), ("filter_bench.json", "filter_bench.json"),
+                  ("valu_issue_rates.txt", "valu_issue_rates.txt"), ("pmc_latency/latency_kernel_stats.txt", "latency_kernel_stats.txt"),
+                  ("pmc_latency/latency_under_prof.json", "latency_under_rocprofv3.json"), ("filter_bench.json", "filter_bench.json"),
                   ("fuzz_filters.json", "fuzz_filters.json")):
     if os.path.exists(os.path.join(src, name)):
         cp(name, out)
@@ -47,7 +48,7 @@ if r50:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), r50[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rebuild_50m_kernel_stats.txt"), "w").write(
         "rocprofv3 --kernel-trace --stats -- python3 tools/rebuild_loop.py 5e7 5   (7 rebuilds of 50 M points, auto bounding box)\n" + txt)
-for sub, name in (("pmc_rebuild", "pmc_rebuild"), ("pmc_range", "pmc_range")):
+for sub, name in (("pmc_rebuild", "pmc_rebuild"), ("pmc_range", "pmc_range"), ("pmc_latency", "pmc_latency")):
     f = os.path.join(src, sub, "pmc_summary.json")
     if os.path.exists(f):
         d = json.load(open(f))

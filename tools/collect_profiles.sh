@@ -42,6 +42,7 @@ if [ "$part" = all ] || [ "$part" = host ]; then
 timeout -k 10 300 python3 tools/pcie_inclusive.py > "$out/pcie_inclusive.json" 2>> "$out/bench.err" || echo "pcie failed"
 timeout -k 10 600 python3 tools/latency_report.py "$out/latency.json" > "$out/latency.log" 2>&1 || { echo "latency failed"; tail -3 "$out/latency.log"; }
 hipcc -O2 --offload-arch=gfx950 tools/pcie_rate.hip -o /tmp/pcie_rate -pthread && timeout -k 10 120 /tmp/pcie_rate > "$out/pcie_rate.json" 2>> "$out/bench.err"
+bash tools/pmc_latency.sh "$out/pmc_latency" > "$out/pmc_latency.txt" 2>&1 || echo "pmc latency failed"
 echo "host side done"
 fi
 if [ "$part" = all ] || [ "$part" = build ]; then
