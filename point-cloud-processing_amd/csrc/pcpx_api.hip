@@ -736,15 +736,14 @@ constexpr u32 RANGE_ONE_CAP = 4096;
 static int range_one_to_host(Index* ix, bool aabb, const float* range6, uint64_t* out_offsets, uint32_t* out_idx, uint64_t idx_capacity)
 {
     int st;
-    const size_t o_done = 0, o_range = 64, o_cnt = 128, o_idx = 192, total = o_idx + RANGE_ONE_CAP * sizeof(u32);
+    const size_t o_done = 0, o_cnt = 128, o_idx = 192, total = o_idx + RANGE_ONE_CAP * sizeof(u32);
     const bool fresh = ix->pinned.bytes < total;
     if ((st = ix->pinned.ensure(total)) != PCPX_OK) return st;
     char* stage = static_cast<char*>(ix->pinned.p);
     volatile u32* done = reinterpret_cast<volatile u32*>(stage + o_done);
     if (fresh) *done = 0u;
-    std::memcpy(stage + o_range, range6, (aabb ? 6 : 4) * sizeof(float));
     const u32 epoch = ++ix->few_epoch ? ix->few_epoch : ++ix->few_epoch;  // never 0 (shared with the k-NN latency path: same word)
-    if ((st = launch_range_one(*ix, aabb, reinterpret_cast<const float*>(stage + o_range), RANGE_ONE_CAP, reinterpret_cast<u32*>(stage + o_idx),
+    if ((st = launch_range_one(*ix, aabb, range6, RANGE_ONE_CAP, reinterpret_cast<u32*>(stage + o_idx),
                                reinterpret_cast<u32*>(stage + o_cnt), const_cast<u32*>(done), epoch)) != PCPX_OK)
         return st;
     bool seen = false;

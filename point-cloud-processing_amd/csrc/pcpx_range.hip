@@ -171,47 +171,96 @@ walked:
 }
 
 // ONE range, latency form (the reference's per-call shape: benchmark/spatial_data_structures_benchmark.cpp:169-213): a single
-// wavefront walks the tree for the one range (every lane holds the same range, so the wave-uniform walk is the range's own), lane
-// j < 8 tests point j of a leaf, matches are appended in walk order through a ballot.  The range, the count and up to `cap` indices
-// live in the handle's pinned stage (host memory the device reads and writes in place), and the host polls the completion word:
-// one launch, no copy, no stream synchronisation -- the count / scan / fill sequence of the batch form is two launches and two
-// synchronisations (41 us per call for a range that holds a handful of points).
+// wavefront sweeps the tree breadth first for the one range -- the (up to 64) nodes of level 3 by one lane each, then two
+// levels per step (a node's 16 grandchildren are contiguous in the heap layout), the surviving nodes compacted by ballot +
+// prefix count into a frontier in LDS, in ascending order: the leaves come out in curve order like the batch form's walk --,
+// then one lane per point of the surviving leaves.  depth / 2 + 2 dependent round trips (the depth-first walk of the batch
+// kernels: one per node and leaf on the way).  The range travels in the kernel arguments; the count and up to `cap` indices
+// live in the handle's pinned stage (host memory the device writes in place), and the host polls the completion word: one
+// launch, no copy, no stream synchronisation -- the count / scan / fill sequence of the batch form is two launches and two
+// synchronisations (41 us per call for a range that holds a handful of points).  A frontier of more than RANGE_FRONTIER nodes
+// reports cap + 1 matches: the caller takes the batch form then, as for more than cap matches.
+constexpr u32 RANGE_FRONTIER = 2048;
 template <bool AABB>
-__global__ __launch_bounds__(64) void k_range_one(TreeView t, const float* __restrict__ range, u32 cap, u32* __restrict__ out_idx,
-                                                  u32* __restrict__ out_cnt, u32* __restrict__ done_flag, u32 epoch)
+__global__ __launch_bounds__(64) void k_range_one(TreeView t, float a0, float a1, float a2, float a3, float a4, float a5, u32 cap,
+                                                  u32* __restrict__ out_idx, u32* __restrict__ out_cnt, u32* __restrict__ done_flag,
+                                                  u32 epoch)
 {
+    __shared__ u32 front[2][RANGE_FRONTIER];
     const u32 lane = threadIdx.x;
-    const float a0 = range[0], a1 = range[1], a2 = range[2], a3 = range[3], a4 = AABB ? range[4] : 0.f, a5 = AABB ? range[5] : 0.f;
     const float r2 = a3 * a3;  // sphere.hpp:34 radius * radius in float
     auto need = [&](const NodeBox& b) -> bool {
         if (AABB) return (b.hi[0] >= a0) & (b.hi[1] >= a1) & (b.hi[2] >= a2) & (b.lo[0] <= a3) & (b.lo[1] <= a4) & (b.lo[2] <= a5) & (b.poison == 0.f);
-        return box_d2(b, a0, a1, a2) <= r2;
+        return box_d2(b, a0, a1, a2) <= r2;  // (NaN for a padding node)
     };
-    u32 cnt = 0;
-    Walker wk;
-    u32 leaf = 0, nexp = 0;
-    bool more = wk.start(t, need, nexp);  // true: the root is the only leaf
-    if (!more) more = wk.next(t, need, leaf, nexp);
-    while (more) {
-        bool in = false;
-        u32 id = 0;
-        if (lane < static_cast<u32>(LEAF)) {
-            const Leaf& lf = t.leaves[leaf];
-            const float x = lf.x[lane], y = lf.y[lane], z = lf.z[lane];  // (NaN padding fails every comparison below)
-            id = lf.id[lane];
-            if (AABB) {
-                in = (x >= a0) & (y >= a1) & (z >= a2) & (x <= a3) & (y <= a4) & (z <= a5);
-            } else {
-                const float dx = x - a0, dy = y - a1, dz = z - a2;
-                in = sq3(dx, dy, dz) <= r2;
+    auto level_base = [](int d) { return d == 0 ? 0u : (0x55555555u >> (32 - 2 * d)); };
+    // real nodes of tree level l (the ones the build writes: the children of a real node need not be real)
+    auto nreal = [&](int l) { return (t.nleaves + (1u << (2 * (t.depth - l))) - 1u) >> (2 * (t.depth - l)); };
+    u32 cnt = 0, m = 0;
+    bool overflow = false;
+    int cur = 0;
+    if (t.nleaves > 0) {
+        const int l0 = t.depth < 3 ? t.depth : 3;
+        bool keep = false;
+        if (lane < (1u << (2 * l0)) && lane < nreal(l0)) keep = need(t.nodes[level_base(l0) + lane]);
+        const u64 mask = __builtin_amdgcn_ballot_w64(keep);
+        const u32 below = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mask), 0u));
+        if (keep) front[0][below] = lane;
+        m = static_cast<u32>(__builtin_popcountll(mask));
+        __syncthreads();
+        for (int d = l0; d < t.depth && m > 0;) {
+            const int s = t.depth - d >= 2 ? 2 : 1;
+            const u32 fan = 1u << (2 * s);
+            u32 next = 0;
+            for (u32 c0 = 0; c0 < fan * m; c0 += 64u) {
+                const u32 c = c0 + lane;
+                bool k2 = false;
+                u32 node = 0;
+                if (c < fan * m) {
+                    node = front[cur][c >> (2 * s)] * fan + (c & (fan - 1u));
+                    if (node < nreal(d + s)) k2 = need(t.nodes[level_base(d + s) + node]);
+                }
+                const u64 mk = __builtin_amdgcn_ballot_w64(k2);
+                const u32 bl = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mk >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mk), 0u));
+                if (k2 && next + bl < RANGE_FRONTIER) front[cur ^ 1][next + bl] = node;
+                next += static_cast<u32>(__builtin_popcountll(mk));
             }
+            if (next > RANGE_FRONTIER) {
+                overflow = true;
+                next = RANGE_FRONTIER;
+            }
+            d += s;
+            m = next;
+            cur ^= 1;
+            __syncthreads();
         }
-        const u64 m = __builtin_amdgcn_ballot_w64(in);
-        const u32 at = cnt + __builtin_amdgcn_mbcnt_lo(static_cast<u32>(m), 0u);  // (only lanes 0..7 can be set)
-        if (in && at < cap) out_idx[at] = id;
-        cnt += static_cast<u32>(__builtin_popcountll(m));
-        more = wk.next(t, need, leaf, nexp);
+        // the points of the surviving leaves, one per lane, in leaf (= curve) order
+        for (u32 c0 = 0; c0 < 8u * m && !overflow; c0 += 64u) {
+            const u32 c = c0 + lane;
+            bool in = false;
+            u32 id = 0;
+            if (c < 8u * m) {
+                const u32 leaf = front[cur][c >> 3];
+                if (leaf < t.nleaves) {
+                    const Leaf& lf = t.leaves[leaf];
+                    const u32 sl = c & 7u;
+                    const float x = lf.x[sl], y = lf.y[sl], z = lf.z[sl];  // (NaN padding fails every comparison below)
+                    id = lf.id[sl];
+                    if (AABB) {
+                        in = (x >= a0) & (y >= a1) & (z >= a2) & (x <= a3) & (y <= a4) & (z <= a5);
+                    } else {
+                        const float dx = x - a0, dy = y - a1, dz = z - a2;
+                        in = sq3(dx, dy, dz) <= r2;
+                    }
+                }
+            }
+            const u64 mk = __builtin_amdgcn_ballot_w64(in);
+            const u32 at = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<u32>(mk >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(mk), 0u));
+            if (in && at < cap) out_idx[at] = id;
+            cnt += static_cast<u32>(__builtin_popcountll(mk));
+        }
     }
+    if (overflow) cnt = cap + 1u;
     if (lane == 0) *out_cnt = cnt;
     __threadfence_system();  // the row and the count are visible to the host before the completion word
     if (lane == 0) __hip_atomic_store(done_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -219,11 +268,12 @@ __global__ __launch_bounds__(64) void k_range_one(TreeView t, const float* __res
 
 }  // namespace
 
+// range: on the host -- sphere {x, y, z, r} or box {min x, y, z, max x, y, z}: it travels in the kernel arguments
 int launch_range_one(Index& ix, bool aabb, const float* range, u32 cap, u32* out_idx, u32* out_cnt, u32* done_flag, u32 epoch)
 {
     ProfileScope prof(ix, PCPX_K_RANGE);
-    if (aabb) k_range_one<true><<<1, 64, 0, ix.stream>>>(ix.view(), range, cap, out_idx, out_cnt, done_flag, epoch);
-    else k_range_one<false><<<1, 64, 0, ix.stream>>>(ix.view(), range, cap, out_idx, out_cnt, done_flag, epoch);
+    if (aabb) k_range_one<true><<<1, 64, 0, ix.stream>>>(ix.view(), range[0], range[1], range[2], range[3], range[4], range[5], cap, out_idx, out_cnt, done_flag, epoch);
+    else k_range_one<false><<<1, 64, 0, ix.stream>>>(ix.view(), range[0], range[1], range[2], range[3], 0.f, 0.f, cap, out_idx, out_cnt, done_flag, epoch);
     return check_hip(hipGetLastError(), "k_range_one launch", __FILE__, __LINE__);
 }
 
