@@ -172,6 +172,7 @@ struct DeviceShared {
     std::mutex mu;
     DevPool pool;
     PinnedStage pinned;
+    u32 normal_epoch = 0;  // launch counter of pcpx_estimate_normal's polled form
 };
 DeviceShared& shared_of(int device)
 {
@@ -1081,6 +1082,23 @@ int pcpx_estimate_normal(const float* xyz, uint64_t m, int device, float out_nor
     if (!out_normal || (m > 0 && !xyz)) return PCPX_ERR_INVALID;
     DeviceShared& shared = shared_of(device);
     std::lock_guard<std::mutex> lock(shared.mu);
+    if (m >= 1 && m <= NORMAL_ARG_POINTS) {
+        // the reference's per-point shape (k neighbours, then their normal): the points travel in the kernel arguments, the
+        // normal and a completion word come back through the device's pinned stage, which the host polls
+        if ((st = shared.pinned.ensure(64 * sizeof(float))) != PCPX_OK) return st;
+        float* stage = static_cast<float*>(shared.pinned.p);
+        volatile u32* done = reinterpret_cast<volatile u32*>(stage + 8);
+        const u32 epoch = ++shared.normal_epoch ? shared.normal_epoch : ++shared.normal_epoch;  // never 0
+        if (*done == epoch) *done = 0u;  // (a fresh stage may hold anything)
+        if ((st = launch_normal_args(xyz, static_cast<u32>(m), stage, const_cast<u32*>(done), epoch, nullptr)) != PCPX_OK) return st;
+        bool seen = false;
+        if (!g_few_no_poll)
+            for (u32 spin = 0; spin < 400000u && !seen; ++spin) seen = *done == epoch;
+        if (!seen) PCPX_HIP(hipStreamSynchronize(nullptr));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(out_normal, stage, 3 * sizeof(float));
+        return PCPX_OK;
+    }
     if (m <= 4096) {
         // one neighbourhood: no allocation and no copy -- the points go into the device's pinned stage, the kernel reads
         // them and writes the normal there (host memory mapped into the device's address space)

@@ -266,6 +266,8 @@ int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offs
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
                    float* d_out, float* d_evals, float* d_centroids = nullptr, float* d_meandist = nullptr);
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
+constexpr u32 NORMAL_ARG_POINTS = 64;  // largest neighbourhood that travels in the kernel arguments (launch_normal_args)
+int launch_normal_args(const float* xyz_host, u32 m, float* out3_pinned, u32* done_flag_pinned, u32 epoch, hipStream_t s);
 int launch_normals_csr(const float* d_xyz, const u64* d_offsets, u64 nrows, float* d_out, hipStream_t s);
 // filter.hip: the loops that consume sphere ranges (bilateral filter, WLOP), fused into the range walk
 size_t leaf_record_bytes(u64 points, int components);  // components: 3 (32-byte records), 1 or 0 (16-byte records)

@@ -86,6 +86,49 @@ __global__ void k_normal_single(const float* __restrict__ xyz, u64 m, float* __r
     eig3_smallest(c00, c10, c20, c11, c21, c22, out3, ev);
 }
 
+// The same for up to NORMAL_ARG_POINTS points that travel in the kernel arguments (the per-call shape of the reference:
+// examples/simple_example.cpp:83-99 -- k nearest neighbours, then estimate_normal of them, point by point): one wavefront, lane j
+// fetches point j (so the argument block's cache lines are requested together, not one after the other across PCIe), the sums
+// are then formed in index order exactly as above from the lanes' values, the normal goes to `out3` (pinned host memory) and
+// the host polls `done_flag` for `epoch`.
+struct NormalPointsArg {
+    float v[3 * NORMAL_ARG_POINTS];
+};
+__global__ __launch_bounds__(64) void k_normal_args(NormalPointsArg pts, u32 m, float* __restrict__ out3, u32* __restrict__ done_flag,
+                                                    u32 epoch)
+{
+    const u32 lane = threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (lane < m) {
+        x = pts.v[3 * lane];
+        y = pts.v[3 * lane + 1];
+        z = pts.v[3 * lane + 2];
+    }
+    auto at = [](float v, u32 j) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j)); };
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (u32 j = 0; j < m; ++j) {
+        const float xj = at(x, j), yj = at(y, j), zj = at(z, j);
+        if (j == 0) { sx = xj; sy = yj; sz = zj; }
+        else { sx += xj; sy += yj; sz += zj; }
+    }
+    const float fn = static_cast<float>(m);
+    const float mx = sx / fn, my = sy / fn, mz = sz / fn;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    for (u32 j = 0; j < m; ++j) {
+        const float vx = at(x, j) - mx, vy = at(y, j) - my, vz = at(z, j) - mz;
+        c00 += vx * vx; c10 += vy * vx; c11 += vy * vy; c20 += vz * vx; c21 += vz * vy; c22 += vz * vz;
+    }
+    float nrm[3], ev[3];
+    eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
+    if (lane == 0) {
+        out3[0] = nrm[0];
+        out3[1] = nrm[1];
+        out3[2] = nrm[2];
+    }
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(done_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // estimate_normal over many explicit point sets at once: row r = points [offsets[r], offsets[r+1]) of xyz (relative to
 // offsets[0]); one thread per row, same arithmetic and order as k_normal_single
 __global__ __launch_bounds__(256) void k_normals_csr(const float* __restrict__ xyz, const u64* __restrict__ offsets, u64 nrows,
@@ -133,6 +176,15 @@ int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_r
     k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
                                                                      d_evals, d_centroids, d_meandist);
     return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);
+}
+
+// xyz: on the host, m <= NORMAL_ARG_POINTS points; out3 and done_flag: pinned host memory the device writes in place
+int launch_normal_args(const float* xyz, u32 m, float* out3, u32* done_flag, u32 epoch, hipStream_t s)
+{
+    NormalPointsArg pts;
+    std::memcpy(pts.v, xyz, static_cast<size_t>(m) * 3 * sizeof(float));
+    k_normal_args<<<1, 64, 0, s>>>(pts, m, out3, done_flag, epoch);
+    return check_hip(hipGetLastError(), "k_normal_args launch", __FILE__, __LINE__);
 }
 
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s)
