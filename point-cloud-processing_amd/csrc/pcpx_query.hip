@@ -719,29 +719,26 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     for (u32 rounds = 0;;) {
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
-        // pop until the next leaf outside the seed range (a seed leaf was seen under a larger tau than any later one) -- "is
-        // there one" stays in the control flow (see WalkerT::pop), written with labels so that it stays there
-        {
+        // one pop per trip: a node is expanded, a leaf outside the seed range (a seed leaf was seen under a larger tau than any
+        // later one) is looked at -- "is there another leaf" is the loop's own control flow (see WalkerT::pop)
+        if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
+        while (!wk.done()) {
             u32 loc;
-            int h;
-        walk_on:
-            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-        pop_next:
-            if (wk.done()) goto round_done;
-            h = wk.pop(loc);
+            const int h = wk.pop(loc);
             if (h != 0) {
                 ++st_expand;
                 wk.expand(t, h, loc, need);
-                goto pop_next;
+            } else {
+                wk.at_leaf(loc);
+                if (loc - s0 >= seed_count) {
+                    if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
+                    fold_if_needed(true, false);
+                    candidates(loc, shell);
+                    if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
+                }
             }
-            wk.at_leaf(loc);
-            if (loc - s0 < seed_count) goto pop_next;
-            if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
-            fold_if_needed(true, false);
-            candidates(loc, shell);
-            goto walk_on;
         }
-    round_done:
+        if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
         fold_if_needed(false, false);
         if (!(cap < inf)) break;
         // a capped round ended: lanes whose k-th distance is within the cap are exact; the others go round again with 4x the

@@ -78,23 +78,17 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
     // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
     Walker wk;
     u32 nexp = 0;
-    if (wk.start(t, need, nexp)) {  // the root is the only leaf
-        leaf_points(0u);
-    } else {
+    if (wk.start(t, need, nexp)) leaf_points(0u);  // the root is the only leaf
+    while (!wk.done()) {  // one pop per trip: a node is expanded, a leaf looked at
         u32 loc;
-        int h;
-    pop_next:
-        if (wk.done()) goto walked;
-        h = wk.pop(loc);
+        const int h = wk.pop(loc);
         if (h != 0) {
             wk.expand(t, h, loc, need);
-            goto pop_next;
+        } else {
+            wk.at_leaf(loc);
+            leaf_points(loc);
         }
-        wk.at_leaf(loc);
-        leaf_points(loc);
-        goto pop_next;
     }
-walked:
     if (valid && !FILL) out_cnt[row] = cnt;
 }
 
@@ -150,23 +144,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
     };
     Walker wk;
     u32 nexp = 0;
-    if (wk.start(t, need, nexp)) {
-        leaf_points(0u);
-    } else {
+    if (wk.start(t, need, nexp)) leaf_points(0u);
+    while (!wk.done()) {  // one pop per trip: a node is expanded, a leaf looked at
         u32 loc;
-        int h;
-    pop_next:
-        if (wk.done()) goto walked;
-        h = wk.pop(loc);
+        const int h = wk.pop(loc);
         if (h != 0) {
             wk.expand(t, h, loc, need);
-            goto pop_next;
+        } else {
+            wk.at_leaf(loc);
+            leaf_points(loc);
         }
-        wk.at_leaf(loc);
-        leaf_points(loc);
-        goto pop_next;
     }
-walked:
     if (valid && !FILL) out_cnt[p] = cnt;
 }
 
