@@ -533,6 +533,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             qz = qv.qz[p];
         }
     }
+    // (the query's coordinates are waited for here, once: left pending, hipcc puts three s_waitcnt vmcnt in front of their first
+    //  use in every block of the search loop -- six scalar-pipe instructions per leaf + expansion)
+    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
     u64 lo_key = 0;
     bool has_lo = false;
     if (MULTI && mp.lo && valid) {
