@@ -5,7 +5,8 @@
 //
 // Same template parameters <Element, K, CoordinateMap>, constructor, member names and result conventions
 // (ascending kNN, eps-coincident points skipped per coordinate, range results unordered and including the
-// query point).  Only K == 3 with float coordinates is the hot path and is what is implemented.  The
+// query point).  K = 1, 2 or 3 (the reference is generic in K; the device index is three-dimensional: missing axes are
+// carried as 0, which changes no distance, no eps-box test and no box containment); K > 3 does not compile.  The
 // construction parameters are accepted for source compatibility: they shaped the reference's median-split
 // tree (depth, leaf size), not the query results.  Storage keeps the elements in input order (the
 // reference permutes its storage with nth_element; that order was never specified).
@@ -42,7 +43,13 @@ struct construction_params_t
 template <class Element, std::size_t K, class CoordinateMap>
 class basic_linked_kdtree_t
 {
-    static_assert(K == 3, "the GPU hot path indexes 3-dimensional points");
+    static_assert(K >= 1 && K <= 3, "the device index holds up to 3 coordinates per point");
+    // coordinate a of a K-dimensional point as the device sees it (0 beyond K)
+    template <class C>
+    static float axis(C const& c, std::size_t a)
+    {
+        return a < K ? static_cast<float>(c[a]) : 0.f;
+    }
 
   public:
     using self_type        = basic_linked_kdtree_t;
@@ -66,9 +73,9 @@ class basic_linked_kdtree_t
         for (auto const& e : storage_)
         {
             auto const c = coordinate_map_(e);
-            xyz_.push_back(static_cast<float>(c[0]));
-            xyz_.push_back(static_cast<float>(c[1]));
-            xyz_.push_back(static_cast<float>(c[2]));
+            xyz_.push_back(axis(c, 0));
+            xyz_.push_back(axis(c, 1));
+            xyz_.push_back(axis(c, 2));
         }
         aabb_ = kd_bounding_box<coordinate_type, K, CoordinateMap, const_iterator>(storage_.cbegin(), storage_.cend(),
                                                                                   coordinate_map_);
@@ -94,7 +101,7 @@ class basic_linked_kdtree_t
                                                  coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
     {
         if (k == 0 || storage_.empty()) return {};
-        float const q[3] = {static_cast<float>(target[0]), static_cast<float>(target[1]), static_cast<float>(target[2])};
+        float const q[3] = {axis(target, 0), axis(target, 1), axis(target, 2)};
         auto const row = index().knn_one(q, static_cast<std::uint32_t>(k), static_cast<float>(eps));
         return gather(row.data(), row.size());
     }
@@ -115,16 +122,15 @@ class basic_linked_kdtree_t
         if (storage_.empty()) return {};
         std::vector<std::uint64_t> off;
         std::vector<std::uint32_t> idx;
-        if constexpr (std::is_same_v<Range, sphere_a<coordinate_type>>)
+        if constexpr (K == 3 && std::is_same_v<Range, sphere_a<coordinate_type>>)
         {
-            float const c[3] = {static_cast<float>(range.position[0]), static_cast<float>(range.position[1]),
-                                static_cast<float>(range.position[2])};
+            float const c[3] = {axis(range.position, 0), axis(range.position, 1), axis(range.position, 2)};
             idx = index().range_sphere_one(c, static_cast<float>(range.radius));
         }
         else if constexpr (std::is_same_v<Range, aabb_type>)
         {
-            float const b[6] = {static_cast<float>(range.min[0]), static_cast<float>(range.min[1]), static_cast<float>(range.min[2]),
-                                static_cast<float>(range.max[0]), static_cast<float>(range.max[1]), static_cast<float>(range.max[2])};
+            float const b[6] = {axis(range.min, 0), axis(range.min, 1), axis(range.min, 2),
+                                axis(range.max, 0), axis(range.max, 1), axis(range.max, 2)};
             index().range_boxes(b, 1, off, idx);
         }
         else
@@ -146,9 +152,9 @@ class basic_linked_kdtree_t
         for (; begin != end; ++begin)
         {
             auto const c = coordinate_map_(*begin);
-            q.push_back(static_cast<float>(c[0]));
-            q.push_back(static_cast<float>(c[1]));
-            q.push_back(static_cast<float>(c[2]));
+            q.push_back(axis(c, 0));
+            q.push_back(axis(c, 1));
+            q.push_back(axis(c, 2));
         }
         std::size_t const nq = q.size() / 3;
         std::vector<std::vector<element_type>> rows(nq);

@@ -1,0 +1,65 @@
+// The kd-tree container in 1 and 2 dimensions (the reference's basic_linked_kdtree_t is generic in K:
+// include/pcp/kdtree/linked_kdtree.hpp:64-65): k nearest neighbours and box ranges against brute force on the host.
+// Missing axes travel as 0 to the device index, so every distance and every containment test is the K-dimensional one.
+#include "pcp/kdtree/linked_kdtree.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+template <std::size_t K>
+int run(unsigned seed)
+{
+    using coords = std::array<float, K>;
+    struct element { coords c; int id; };
+    auto const map = [](element const& e) { return e.c; };
+    std::mt19937 gen(seed);
+    std::uniform_real_distribution<float> u(-5.f, 5.f);
+    std::vector<element> pts(3000);
+    for (std::size_t i = 0; i < pts.size(); ++i)
+    {
+        for (std::size_t a = 0; a < K; ++a) pts[i].c[a] = u(gen);
+        pts[i].id = static_cast<int>(i);
+    }
+    pcp::basic_linked_kdtree_t<element, K, decltype(map)> tree(pts.begin(), pts.end(), map);
+    int bad = 0;
+    auto d2 = [](coords const& a, coords const& b) {
+        float s = 0.f;  // the reference's order: x, y, z products summed left to right
+        for (std::size_t i = 0; i < K; ++i) s = i == 0 ? (a[i] - b[i]) * (a[i] - b[i]) : s + (a[i] - b[i]) * (a[i] - b[i]);
+        return s;
+    };
+    for (int q = 0; q < 40; ++q)
+    {
+        coords target;
+        for (std::size_t a = 0; a < K; ++a) target[a] = u(gen);
+        std::size_t const k = 1 + static_cast<std::size_t>(q % 12);
+        auto const got = tree.nearest_neighbours(target, k);
+        std::vector<std::pair<float, int>> all;
+        for (auto const& e : pts) all.push_back({d2(e.c, target), e.id});
+        std::sort(all.begin(), all.end());
+        if (got.size() != k) { ++bad; continue; }
+        for (std::size_t j = 0; j < k; ++j)
+            if (d2(got[j].c, target) != all[j].first) ++bad;  // (ids may differ only where distances tie exactly)
+        // a box around the target
+        pcp::kd_axis_aligned_bounding_box_t<float, K> box;
+        for (std::size_t a = 0; a < K; ++a) { box.min[a] = target[a] - 0.4f; box.max[a] = target[a] + 0.4f; }
+        auto const in = tree.range_search(box);
+        std::size_t expect = 0;
+        for (auto const& e : pts) expect += box.contains(e.c) ? 1u : 0u;
+        if (in.size() != expect) ++bad;
+        for (auto const& e : in) if (!box.contains(e.c)) ++bad;
+    }
+    auto const bb = tree.aabb();
+    for (auto const& e : pts) if (!bb.contains(e.c)) ++bad;
+    std::printf("K = %zu: %d mismatches\n", K, bad);
+    return bad;
+}
+
+int main()
+{
+    int bad = run<1>(11) + run<2>(12) + run<3>(13);
+    std::printf(bad == 0 ? "ok\n" : "FAILED\n");
+    return bad == 0 ? 0 : 1;
+}
