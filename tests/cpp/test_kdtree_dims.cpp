@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdio>
 #include <random>
 #include <vector>
@@ -37,18 +38,27 @@ int run(unsigned seed)
         std::size_t const k = 1 + static_cast<std::size_t>(q % 12);
         auto const got = tree.nearest_neighbours(target, k);
         std::vector<std::pair<float, int>> all;
-        for (auto const& e : pts) all.push_back({d2(e.c, target), e.id});
+        for (auto const& e : pts)
+        {
+            float far = 0.f;  // the reference skips points within eps of the target on every axis (vector3d_queries.hpp:47-64)
+            for (std::size_t i = 0; i < K; ++i) far = std::max(far, std::fabs(e.c[i] - target[i]));
+            if (far >= 1e-5f) all.push_back({d2(e.c, target), e.id});
+        }
         std::sort(all.begin(), all.end());
-        if (got.size() != k) { ++bad; continue; }
+        if (got.size() != k) { ++bad; std::printf("  query %d: %zu neighbours for k = %zu\n", q, got.size(), k); continue; }
         for (std::size_t j = 0; j < k; ++j)
-            if (d2(got[j].c, target) != all[j].first) ++bad;  // (ids may differ only where distances tie exactly)
+            if (d2(got[j].c, target) != all[j].first)  // (ids may differ only where distances tie exactly)
+            {
+                ++bad;
+                std::printf("  query %d: neighbour %zu at d2 %.9g, brute force %.9g\n", q, j, d2(got[j].c, target), all[j].first);
+            }
         // a box around the target
         pcp::kd_axis_aligned_bounding_box_t<float, K> box;
         for (std::size_t a = 0; a < K; ++a) { box.min[a] = target[a] - 0.4f; box.max[a] = target[a] + 0.4f; }
         auto const in = tree.range_search(box);
         std::size_t expect = 0;
         for (auto const& e : pts) expect += box.contains(e.c) ? 1u : 0u;
-        if (in.size() != expect) ++bad;
+        if (in.size() != expect) { ++bad; std::printf("  query %d: %zu in the box, brute force %zu\n", q, in.size(), expect); }
         for (auto const& e : in) if (!box.contains(e.c)) ++bad;
     }
     auto const bb = tree.aabb();
