@@ -118,7 +118,9 @@ __device__ __forceinline__ void sort_network(u64 (&a)[N])
 
 // SKIP: the first SKIP elements are known to hold 0, the smallest key there is (the best-list's sentinels when k < KCAP): a
 // compare-exchange with one of them changes nothing and is left out (k = 15: 4 of the 32 of every merge).
-template <int N, int SKIP = 0>
+// FRESH: only the last FRESH elements differ from an ascending list (the compaction has just put new keys there): in the first
+// stage a pair that lies wholly below them is in order already (KCAP = 32, 8 new keys: 8 of the stage's 16).
+template <int N, int SKIP = 0, int FRESH = N>
 __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 {
 #pragma unroll
@@ -126,7 +128,7 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             int l = i ^ j;
-            if (l > i && i >= SKIP) ce(a[i], a[l]);
+            if (l > i && i >= SKIP && (j != (N >> 1) || l >= N - FRESH)) ce(a[i], a[l]);
         }
     }
 }
@@ -275,7 +277,7 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
     }
-    bitonic_merge<KCAP, NZ>(best);  // (one copy for both tiers: only best[] crosses the join)
+    bitonic_merge<KCAP, NZ, 8>(best);  // (one copy for both tiers: only best[] crosses the join)
     if (BUF > 8 && any_lane(cnt > 8)) {
         constexpr int R = BUF > 8 ? BUF - 8 : 1;               // rows of the second chunk
         constexpr int N = R <= 2 ? 2 : R <= 4 ? 4 : 8;         // its sorting network (10 rows: one compare-exchange)
@@ -289,7 +291,7 @@ __device__ __forceinline__ void compact_by8(u64 (&best)[KCAP], u64* __restrict__
         if (f.on) drop_eps_box<R, N>(nw, col + 8 * 64, f);
 #pragma unroll
         for (int j = 0; j < N; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
-        bitonic_merge<KCAP, NZ>(best);
+        bitonic_merge<KCAP, NZ, N>(best);
     }
     cnt = 0;
 }
