@@ -168,6 +168,19 @@ def test_gpu_normals_against_float64_eigh(pkg, bunny, cloud):
     assert nwell >= 0.9 * len(rows)
 
 
+def test_estimate_normal_forms_agree_with_the_oracle_bit_for_bit(pkg, oracle):
+    """pcpx_estimate_normal has three forms by neighbourhood size -- up to 64 points in the kernel arguments with a polled
+    completion word (the reference's per-point shape), up to 4096 through the pinned stage, more through device buffers: the
+    same sums in the same order, so the same bits as the oracle's restatement (normal_estimation.hpp:41-77) at every size,
+    on both sides of each boundary, and call after call (the completion word is reused)."""
+    rng = np.random.default_rng(23)
+    for m in (1, 2, 3, 7, 15, 63, 64, 65, 100, 4096, 4097, 6000, 10, 64, 9):
+        pts = (rng.standard_normal((m, 3)) * np.array([1.0, 0.3, 0.02]) + np.array([5.0, -2.0, 0.5])).astype(np.float32)
+        n_gpu = pkg.estimate_normal(pts)
+        n_orc = oracle.estimate_normal(pts)
+        assert np.array_equal(n_gpu.view(np.uint32), n_orc.view(np.uint32)), m
+
+
 def test_gpu_normals_on_analytic_cases(pkg, oracle):
     """Closed-form normals over exact scatter matrices that force the solver's Householder step and >= 2 QR steps
     (conftest.analytic_normal_cases): GPU == analytic within 1e-6 cosine and == the oracle bit for bit, both through
