@@ -104,6 +104,10 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
     // made its row visible system-wide it stores the launch's epoch into *done_flag (pinned host memory).
     auto signal_done = [&]() {
         __threadfence_system();  // this block's row, count and flag are visible to the host before the counter moves
+        if (nq == 1u) {  // the only block: no counter to consult (one device-memory atomic round trip less on the way out)
+            if (lane == 0 && done_flag) __hip_atomic_store(done_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
         if (lane == 0 && done_count) {
             const u32 prev = atomicAdd(done_count, 1u);
             if (prev == nq - 1u) {
