@@ -151,6 +151,9 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_ASM_ACCEPT
 #define PCPX_ASM_ACCEPT 1
 #endif
+#ifndef PCPX_SEED_DIRECT
+#define PCPX_SEED_DIRECT 8  // largest KCAP whose seed leaves skip the append buffer (k <= 16 / 32: scratch in the seed phase)
+#endif
 #ifndef PCPX_COMPACT_TIER4
 #define PCPX_COMPACT_TIER4 8  // largest KCAP whose compaction has a four-key tier (k <= 8: +2 %; k <= 16: the branch costs the kernel
                               // scratch at 7 waves per SIMD and nothing at 6; k <= 32: no difference)
@@ -707,8 +710,35 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     };
 
     // ---- the seed leaves ----
+    // Early in the seed phase nearly every lane accepts nearly every point (tau starts at +inf), so a seed leaf's eight keys
+    // skip the append buffer: built in registers, sorted, filtered for the eps-box and merged like a chunk of the buffer
+    // (the same best-list as accepting them one by one: a key beyond tau falls off its end).  Not for the cloud's last leaf
+    // (its padding slots are NaN, which the compare-exchange network cannot carry) and not in the per-candidate eps form.
+    constexpr bool direct_seeds = KCAP <= PCPX_SEED_DIRECT && fast && !EPS_EACH && !STATS && PCPX_COMPACT_BY8 && (KCAP <= 16 || PCPX_BY8_K32);
+    auto seed_direct = [&](const u32 leaf) {
+        const Leaf lf = load_const(t.leaves + leaf);
+        const u32 posbase = leaf * LEAF;
+        u64 nw[LEAF];
+        float qx_here = qx;
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) {
+            float dx = lf.x[j] - qx_here, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
+            nw[j] = (static_cast<u64>(__float_as_uint(sq3(dx, dy, dz))) << 32) | (posbase + j);
+            asm volatile("" : "+v"(qx_here));  // one key's differences at a time (all eight at once cost registers the best-list needs)
+        }
+        sort_network<LEAF>(nw);
+        if (eps_filter.on) drop_eps_box<LEAF, LEAF>(nw, col, eps_filter);  // (the buffer is empty: its rows are the filter's scratch)
+#pragma unroll
+        for (int j = 0; j < LEAF; ++j) best[KCAP - 1 - j] = key_min(best[KCAP - 1 - j], nw[j]);
+        bitonic_merge<KCAP, NZ, LEAF>(best);
+        tau = active ? fminf(__uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32)), cap) : -1.f;
+    };
     for (u32 leaf = s0;; ++leaf) {
         const bool more = leaf < s1;
+        if (direct_seeds && more && leaf + 1u != t.nleaves) {
+            seed_direct(leaf);
+            continue;
+        }
         fold_if_needed(more, true);
         if (!more) break;
         candidates(leaf, false);
