@@ -2,6 +2,10 @@
 #include "pcpx_curve.h"
 #include "pcpx_device.h"
 
+#ifndef PCPX_QUERY_SORT_FIRST_BIT
+#define PCPX_QUERY_SORT_FIRST_BIT 40
+#endif
+
 #include <algorithm>
 
 namespace pcpx {
@@ -110,7 +114,9 @@ int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv)
         const int cmp_shift = std::max(ix.sorted_from_bit, std::max(qbits, ix.idx_bits));  // (the binary search needs bits the index is ordered on)
         const u32 cblocks = (n32 + QCODES_BLOCK - 1) / QCODES_BLOCK;
         k_query_codes<<<cblocks < 512u ? cblocks : 512u, QCODES_BLOCK, 0, s>>>(d_q, n32, d_box, qbits, codes0);
-        if ((st = sort_keys_u64(base + o_tmp, tb, codes0, codes1, nq, s, SORT_FIRST_BIT)) != PCPX_OK) return st;
+        // (queries are only grouped by the sort -- 64 consecutive ones per wavefront --, so the top 24 bits of the curve key (256
+        //  cells per axis) are enough: three passes instead of five)
+        if ((st = sort_keys_u64(base + o_tmp, tb, codes0, codes1, nq, s, PCPX_QUERY_SORT_FIRST_BIT)) != PCPX_OK) return st;
         k_query_gather<<<(n32 + 255) / 256, 256, 0, s>>>(d_q, codes1, qbits, n32, qx, qy, qz, row);
         k_query_seeds<<<static_cast<u32>((ngroups + 255) / 256), 256, 0, s>>>(
             codes1, n32, ix.sorted_codes(), static_cast<u32>(ix.n), ix.nleaves, cmp_shift, seed, static_cast<u32>(ngroups));
