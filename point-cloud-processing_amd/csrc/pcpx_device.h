@@ -107,11 +107,14 @@ __device__ __forceinline__ u32 lds_address(const void* p)
 // stored: heap id = (4^d - 1)/3 + local index at tree level d, and a leaf's local index is its number).
 // X16: the child boxes come as two 64-byte loads (load_node4) -- fewer scalar instructions, four more SGPRs at once; the
 // kernel picks (k_knn for k <= 8, at 8 waves per SIMD, is faster without).
-template <bool X16>
+// KEEP: the lanes that needed each of the last expanded node's children are kept (leaf_need) -- k_knn looks at a leaf that few
+// lanes need in a form of its own.
+template <bool X16, bool KEEP = false>
 struct WalkerT {
     u64 pend;
     u32 ploc;
     int l;
+    u64 leaf_need[W];  // KEEP: valid for the children of the most recently expanded node (the leaves popped next, if it was a last-level node)
 
     // first heap id of tree level d >= 1: (4^d - 1) / 3 = 0b0101...01 (d pairs)
     static __device__ __forceinline__ u32 level_base(int d) { return 0x55555555u >> (32 - 2 * d); }
@@ -129,6 +132,7 @@ struct WalkerT {
 #pragma unroll
         for (int c = W - 1; c >= 0; --c) {
             const u64 lanes = __builtin_amdgcn_ballot_w64(need(cb.c[c]));
+            if (KEEP) leaf_need[c] = lanes;
             asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(m) : "s"(lanes) : "scc");
         }
         return m;
@@ -199,7 +203,7 @@ struct WalkerT {
         return false;
     }
 };
-using Walker = WalkerT<true>;
+using Walker = WalkerT<true, false>;
 
 inline u32 grid_for_groups(u64 groups)
 {

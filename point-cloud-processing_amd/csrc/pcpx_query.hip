@@ -154,6 +154,9 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_SEED_DIRECT
 #define PCPX_SEED_DIRECT 8  // largest KCAP whose seed leaves skip the append buffer (k <= 16 / 32: scratch in the seed phase)
 #endif
+#ifndef PCPX_SPARSE_LEAVES
+#define PCPX_SPARSE_LEAVES 3
+#endif
 #ifndef PCPX_COMPACT_TIER4
 #define PCPX_COMPACT_TIER4 8  // largest KCAP whose compaction has a four-key tier (k <= 8: +2 %; k <= 16: the branch costs the kernel
                               // scratch at 7 waves per SIMD and nothing at 6; k <= 32: no difference)
@@ -748,10 +751,61 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     tau = active ? fminf(tau, cap) : -1.f;
 
     // ---- walk rounds ----
-    WalkerT<(KCAP > 8)> wk;
+    constexpr bool sparse_leaves = PCPX_SPARSE_LEAVES > 0 && fast && !EPS_EACH && !STATS;
+    WalkerT<(KCAP > 8), sparse_leaves> wk;
+    // A leaf that at most PCPX_SPARSE_LEAVES lanes need (a third of the walk's leaves are needed by <= 3 of the 64) is looked at
+    // the other way round: lane j < 8 holds point j of the leaf, and for each needing lane in turn the eight distances to ITS
+    // query are formed at once, compared with its tau and appended to its column -- ~18 vector instructions per needing lane
+    // against 91 for the leaf in the lane-per-query form.  (Which lanes: the ballots of the parent's box tests, taken under a
+    // tau that can only have shrunk since.)
+    auto sparse_leaf = [&](const u32 leaf, u64 todo) {
+        const u32 j = lane & 7u;
+        const float* rec = reinterpret_cast<const float*>(t.leaves + leaf);
+        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        const u32 posj = leaf * LEAF + j;
+        // (one statement: v_cmpx .. v_writelane keeps the >= 4 instructions the hardware wants between a vector write of EXEC and a
+        //  lane write; nothing here depends on a compiler-inserted wait state)
+        u64 saved;
+        u32 ox, oy, oz, otau, owa, owner;
+        float d, e;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n"
+            "1:\n\t"
+            "s_ff1_i32_b64 %[L], %[todo]\n\t"
+            "s_bitset0_b64 %[todo], %[L]\n\t"
+            "s_mov_b32 m0, %[L]\n\t"
+            "v_readlane_b32 %[sx], %[qx], m0\n\t"
+            "v_readlane_b32 %[sy], %[qy], m0\n\t"
+            "v_readlane_b32 %[sz], %[qz], m0\n\t"
+            "v_readlane_b32 %[st], %[tau], m0\n\t"
+            "v_readlane_b32 %[sw], %[wa], m0\n\t"
+            "s_mov_b64 exec, 0xff\n\t"
+            "v_subrev_f32_e32 %[d], %[sx], %[cx]\n\t"
+            "v_subrev_f32_e32 %[e], %[sy], %[cy]\n\t"
+            "v_mul_f32_e32 %[d], %[d], %[d]\n\t"
+            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
+            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
+            "v_subrev_f32_e32 %[e], %[sz], %[cz]\n\t"
+            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
+            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
+            "v_cmpx_ge_f32_e32 %[st], %[d]\n\t"
+            "s_bcnt1_i32_b64 %[L], exec\n\t"
+            "v_mbcnt_lo_u32_b32 %[e], exec_lo, 0\n\t"
+            "v_lshl_add_u32 %[e], %[e], 9, %[sw]\n\t"
+            "ds_write2_b32 %[e], %[pos], %[d] offset1:1\n\t"
+            "s_lshl_b32 %[L], %[L], 9\n\t"
+            "s_add_u32 %[sw], %[sw], %[L]\n\t"
+            "s_cmp_lg_u64 %[todo], 0\n\t"
+            "v_writelane_b32 %[wa], %[sw], m0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [sv] "=&s"(saved), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [st] "=&s"(otau), [sw] "=&s"(owa),
+              [d] "=&v"(d), [e] "=&v"(e), [wa] "+v"(wa), [todo] "+s"(todo)
+            : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [tau] "v"(tau), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [pos] "v"(posj)
+            : "m0", "vcc", "scc", "memory");
+    };
     const u32 seed_count = s1 - s0;
-    bool shell = false;
-    for (u32 rounds = 0;;) {
+    for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
         // one pop per trip: a node is expanded, a leaf outside the seed range (a seed leaf was seen under a larger tau than any
@@ -768,7 +822,23 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 if (loc - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
                     fold_if_needed(true, false);
-                    candidates(loc, shell);
+                    if (sparse_leaves && rounds == 0u) {
+                        const u32 c = loc & (W - 1u);
+                        u64 who;
+                        u32 how_many;
+                        asm("s_cmp_eq_u32 %[c], 2\n\ts_cselect_b64 %[w], %[n2], %[n3]\n\t"
+                            "s_cmp_eq_u32 %[c], 1\n\ts_cselect_b64 %[w], %[n1], %[w]\n\t"
+                            "s_cmp_eq_u32 %[c], 0\n\ts_cselect_b64 %[w], %[n0], %[w]\n\t"
+                            "s_bcnt1_i32_b64 %[m], %[w]"
+                            : [w] "=&s"(who), [m] "=s"(how_many)
+                            : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
+                            : "scc");
+                        if (how_many <= static_cast<u32>(PCPX_SPARSE_LEAVES)) {
+                            sparse_leaf(loc, who);
+                            continue;
+                        }
+                    }
+                    candidates(loc, rounds != 0u);
                     if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                 }
             }
@@ -781,7 +851,6 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         const bool failed = active && !(kth <= cap);
         if (!any_lane(failed)) break;
-        shell = true;
         if (STATS) ++st_round2;
         lo_d2 = cap;
         const NodeBox root = load_const(t.nodes);
