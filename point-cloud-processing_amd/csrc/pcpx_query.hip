@@ -516,7 +516,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // STATS build only (pcpx_debug_knn_stats): [0] leaves visited, [1] node expansions, [2] compactions,
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
-    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0, st_c3 = 0, st_c4 = 0;
+    u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0, st_sparse = 0, st_owners = 0;
     // [7] shader cycles in the walker (pop + node expansions), [8] in compactions, [9] in leaf candidates,
     // [10] in the whole search loop, [11] whole group incl. the epilogue (id gather, tie repair, stores, fused normal)
     unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0;
@@ -611,10 +611,6 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     auto fold = [&](bool in_seed_phase) {
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
         if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
-        if (STATS) {  // how full is the fullest lane when a compaction runs?
-            st_c3 += any_lane(cnt > 3) ? 0u : 1u;
-            st_c4 += any_lane(cnt > 4) ? 0u : 1u;
-        }
         if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF, NZ>(best, col, cnt, eps_filter);
         else compact<KCAP, BUF>(best, col, cnt);
         float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
@@ -751,7 +747,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     tau = active ? fminf(tau, cap) : -1.f;
 
     // ---- walk rounds ----
-    constexpr bool sparse_leaves = PCPX_SPARSE_LEAVES > 0 && fast && !EPS_EACH && !STATS;
+    constexpr bool sparse_leaves = PCPX_SPARSE_LEAVES > 0 && fast && !EPS_EACH;
     WalkerT<(KCAP > 8), sparse_leaves> wk;
     // A leaf that at most PCPX_SPARSE_LEAVES lanes need (a third of the walk's leaves are needed by <= 3 of the 64) is looked at
     // the other way round: lane j < 8 holds point j of the leaf, and for each needing lane in turn the eight distances to ITS
@@ -834,7 +830,15 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                             : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
                             : "scc");
                         if (how_many <= static_cast<u32>(PCPX_SPARSE_LEAVES)) {
+                            const u32 wa_was = wa;
+                            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                             sparse_leaf(loc, who);
+                            if (STATS) {
+                                ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;
+                                const u64 now = __builtin_amdgcn_s_memtime();
+                                tc_leaf += now - tc_mark;
+                                tc_mark = now;
+                            }
                             continue;
                         }
                     }
@@ -881,8 +885,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             atomicAdd(&stats[2], static_cast<unsigned long long>(st_compact));
             atomicAdd(&stats[12], static_cast<unsigned long long>(st_seed_compact));
             atomicAdd(&stats[13], static_cast<unsigned long long>(sapp));
-            atomicAdd(&stats[14], static_cast<unsigned long long>(st_c3));
-            atomicAdd(&stats[15], static_cast<unsigned long long>(st_c4));
+            atomicAdd(&stats[14], static_cast<unsigned long long>(st_sparse));  // leaves looked at point-per-lane ...
+            atomicAdd(&stats[15], static_cast<unsigned long long>(st_owners));  // ... and the lanes they were looked at for
             atomicAdd(&stats[3], static_cast<unsigned long long>(app));
             atomicAdd(&stats[4], 1ull);
             atomicAdd(&stats[5], static_cast<unsigned long long>(s1 - s0));

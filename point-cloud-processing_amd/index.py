@@ -284,7 +284,7 @@ class Index:
         check(self._lib.pcpx_debug_knn_stats(self._h, k, eps, out, cap | ((1 << 63) if floor else 0)))
         names = ["leaves", "expansions", "compactions", "appended", "waves", "seed_leaves", "second_round_groups",
                  "cycles_walk", "cycles_compact", "cycles_leaf", "cycles_search_loop", "cycles_group",
-                 "seed_compactions", "seed_appended", "compactions_max3", "compactions_max4"]
+                 "seed_compactions", "seed_appended", "sparse_leaves", "sparse_leaf_lanes"]
         d = {n: int(out[i]) for i, n in enumerate(names)}
         if want_waves:
             w = np.frombuffer(out, dtype=np.uint64)[16:].reshape(-1, 5)

@@ -19,9 +19,12 @@ ce = 2 * F64                                                  # compare-exchange
 chunk = (19 + 28) * ce + 8 * F64 + 30   # one chunk of 8 keys: 19-comparator sort, 8 mins, merge of 16 less the 4 sentinel exchanges (k = 15)
 second = (1 + 28) * ce + 2 * F64 + 10   # rows 8 .. 9: one compare-exchange, 2 mins, the merge again
 short_share = 0.85  # share of compactions in which no lane holds more than 8 keys (the trigger is "more than 2")
-leaves = st["leaves"] + st["seed_leaves"]
+sparse, owners = st.get("sparse_leaves", 0.0), st.get("sparse_leaf_lanes", 0.0)  # leaves looked at point-per-lane, and the lanes they were looked at for
+leaves = st["leaves"] + st["seed_leaves"] - sparse
+owner = 5 * CMP + 8 * SIMPLE + CMP + CMP + THREE_OP + CMP  # 5 v_readlane, the distance, v_cmpx, v_mbcnt, address, v_writelane
 parts = {
     "leaf_candidates": leaves * 8 * candidate,
+    "sparse_leaf_candidates": sparse * (2 * THREE_OP + 4 * SIMPLE) + owners * owner,
     "box_tests": st["expansions"] * 4 * box,
     "compactions": st["compactions"] * (chunk + (1 - short_share) * second),
     "cap_epilogue_setup": 6000.0,
