@@ -154,6 +154,9 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_SEED_DIRECT
 #define PCPX_SEED_DIRECT 8  // largest KCAP whose seed leaves skip the append buffer (k <= 16 / 32: scratch in the seed phase)
 #endif
+#ifndef PCPX_FOLD_FOR_NEEDERS
+#define PCPX_FOLD_FOR_NEEDERS 1
+#endif
 #ifndef PCPX_SPARSE_LEAVES
 #define PCPX_SPARSE_LEAVES 3
 #endif
@@ -767,9 +770,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         asm volatile(
             "s_mov_b64 %[sv], exec\n"
             "1:\n\t"
-            "s_ff1_i32_b64 %[L], %[todo]\n\t"
-            "s_bitset0_b64 %[todo], %[L]\n\t"
-            "s_mov_b32 m0, %[L]\n\t"
+            "s_ff1_i32_b64 m0, %[todo]\n\t"
+            "s_bitset0_b64 %[todo], m0\n\t"
             "v_readlane_b32 %[sx], %[qx], m0\n\t"
             "v_readlane_b32 %[sy], %[qy], m0\n\t"
             "v_readlane_b32 %[sz], %[qz], m0\n\t"
@@ -801,6 +803,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             : "m0", "vcc", "scc", "memory");
     };
     const u32 seed_count = s1 - s0;
+    u32 sparse_limit = PCPX_SPARSE_LEAVES;  // 0 in the shell rounds (they also want lo_d2 < d2; a visited leaf has a lane that needs it)
     for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
@@ -817,8 +820,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 wk.at_leaf(loc);
                 if (loc - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
-                    fold_if_needed(true, false);
-                    if (sparse_leaves && rounds == 0u) {
+                    if (!sparse_leaves) {
+                        fold_if_needed(true, false);
+                        candidates(loc, rounds != 0u);
+                    } else {
                         const u32 c = loc & (W - 1u);
                         u64 who;
                         u32 how_many;
@@ -829,20 +834,21 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                             : [w] "=&s"(who), [m] "=s"(how_many)
                             : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
                             : "scc");
-                        if (how_many <= static_cast<u32>(PCPX_SPARSE_LEAVES)) {
+                        // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
+                        // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
+                        if (PCPX_FOLD_FOR_NEEDERS ? (__builtin_amdgcn_ballot_w64(wa >= wa_full) & who) != 0 : any_lane(wa >= wa_full)) fold(false);
+                        if (how_many <= sparse_limit) {
                             const u32 wa_was = wa;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                             sparse_leaf(loc, who);
                             if (STATS) {
                                 ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;
-                                const u64 now = __builtin_amdgcn_s_memtime();
-                                tc_leaf += now - tc_mark;
-                                tc_mark = now;
+                                tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
                             }
-                            continue;
+                        } else {
+                            candidates(loc, rounds != 0u);
                         }
                     }
-                    candidates(loc, rounds != 0u);
                     if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                 }
             }
@@ -865,6 +871,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         // after 12 rounds
         const float grown = cap * PCPX_CAP_GROW;
         ++rounds;
+        sparse_limit = 0;
         cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
         active = failed;
         tau = active ? fminf(kth, cap) : -1.f;

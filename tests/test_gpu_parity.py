@@ -277,6 +277,22 @@ def test_knn_clustered_and_degenerate(pkg, oracle):
     _check_knn_exact(pkg, oracle, big, None, 10, self_query=True)
 
 
+@pytest.mark.parametrize("k", [7, 15, 32])
+def test_knn_when_few_lanes_of_a_group_need_a_leaf(pkg, oracle, k):
+    """Tight blobs with stragglers between them: in most 64-query groups a few lanes reach leaves no other lane needs, which
+    k_knn looks at point-per-lane for those lanes only (pcpx_query.hip: sparse_leaf); eight-fold coincident points make such
+    a leaf fill a lane's append buffer in one go."""
+    rng = np.random.default_rng(77 + k)
+    centres = rng.random((60, 3), dtype=np.float32)
+    blobs = (centres[rng.integers(0, 60, 36000)] + rng.normal(0, 2e-3, (36000, 3))).astype(np.float32)
+    stragglers = rng.random((4000, 3), dtype=np.float32)
+    repeated = np.repeat(rng.random((250, 3), dtype=np.float32), 8, axis=0)
+    pts = np.concatenate([blobs, stragglers, repeated])[rng.permutation(42000)]
+    ix = _check_knn_exact(pkg, oracle, pts, None, k, self_query=True)
+    queries = np.concatenate([stragglers[:900] + np.float32(1e-3), blobs[:900], rng.random((248, 3), dtype=np.float32) * 3 - 1])
+    _check_knn_exact(pkg, oracle, pts, queries[rng.permutation(len(queries))], k, eps=0.0, ix=ix)
+
+
 def test_rebuild_reuses_handle(pkg, oracle):
     rng = np.random.default_rng(21)
     a = rng.random((5000, 3), dtype=np.float32)
