@@ -2,6 +2,13 @@
 // walk as the kNN kernel (pcpx_device.h), one lane = one range, count or CSR fill.
 #include "pcpx_device.h"
 
+#ifndef PCPX_RANGE_SPARSE_LEAVES
+#define PCPX_RANGE_SPARSE_LEAVES 3
+#endif
+#ifndef PCPX_RANGE_DIRECT_LEAVES
+#define PCPX_RANGE_DIRECT_LEAVES 1
+#endif
+
 namespace pcpx {
 
 namespace {
@@ -44,8 +51,7 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
     u64 wpos = (FILL && valid) ? offsets[row] : 0;
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
 
-    auto leaf_points = [&](const u32 leaf) {
-        const Leaf lf = load_const(t.leaves + leaf);
+    auto leaf_record_points = [&](const Leaf& lf) {
         if (!FILL) {
             // count: the eight "inside" masks first (a scalar register pair each), then eight add-with-carry -- from
             // `cnt += in` hipcc pairs the points up as compare, select 0/1 under VCC, compare, add-with-carry, and the select
@@ -75,15 +81,69 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
             cnt += in ? 1u : 0u;
         }
     };
+    auto leaf_points = [&](const u32 leaf) { leaf_record_points(load_const(t.leaves + leaf)); };
+    // A leaf that at most PCPX_RANGE_SPARSE_LEAVES lanes need is counted point-per-lane, once per needing lane (k_knn's
+    // sparse_leaf, pcpx_query.hip): lane j holds point j & 7, the needing lane's centre comes through v_readlane.
+    constexpr bool sparse_leaves = PCPX_RANGE_SPARSE_LEAVES > 0 && !FILL;
+    auto sparse_leaf = [&](const Leaf* record, u64 todo) {
+        const u32 j = lane & 7u;
+        const float* rec = reinterpret_cast<const float*>(record);
+        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        u32 ox, oy, oz, or2, ocnt, owner;
+        float d, e;
+        asm volatile(
+            "1:\n\t"
+            "s_ff1_i32_b64 m0, %[todo]\n\t"
+            "s_bitset0_b64 %[todo], m0\n\t"
+            "v_readlane_b32 %[sx], %[qx], m0\n\t"
+            "v_readlane_b32 %[sy], %[qy], m0\n\t"
+            "v_readlane_b32 %[sz], %[qz], m0\n\t"
+            "v_readlane_b32 %[sr], %[r2], m0\n\t"
+            "v_readlane_b32 %[sc], %[cnt], m0\n\t"
+            "v_subrev_f32_e32 %[d], %[sx], %[cx]\n\t"
+            "v_subrev_f32_e32 %[e], %[sy], %[cy]\n\t"
+            "v_mul_f32_e32 %[d], %[d], %[d]\n\t"
+            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
+            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
+            "v_subrev_f32_e32 %[e], %[sz], %[cz]\n\t"
+            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
+            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
+            "v_cmp_ge_f32_e32 vcc, %[sr], %[d]\n\t"  // (a NaN padding point fails)
+            "s_and_b32 %[L], vcc_lo, 0xff\n\t"
+            "s_bcnt1_i32_b32 %[L], %[L]\n\t"
+            "s_add_u32 %[sc], %[sc], %[L]\n\t"
+            "s_cmp_lg_u64 %[todo], 0\n\t"
+            "v_writelane_b32 %[cnt], %[sc], m0\n\t"
+            "s_cbranch_scc1 1b"
+            : [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [sr] "=&s"(or2), [sc] "=&s"(ocnt), [d] "=&v"(d), [e] "=&v"(e),
+              [cnt] "+v"(cnt), [todo] "+s"(todo)
+            : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [r2] "v"(r2), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz)
+            : "m0", "vcc", "scc");
+    };
     // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
-    Walker wk;
+    WalkerT<true, sparse_leaves> wk;
     u32 nexp = 0;
     if (wk.start(t, need, nexp)) leaf_points(0u);  // the root is the only leaf
-    while (!wk.done()) {  // one pop per trip: a node is expanded, a leaf looked at
+    // A last-level node looks at its needed leaves itself (WalkerT::leaves_of) instead of pushing and popping them: the four
+    // children written out, so that a child's record is an immediate offset from the node's first leaf and its lanes' ballot a
+    // register pair known at compile time (height 0 is popped only when the root's own children are leaves).
+    while (!wk.done()) {  // one pop per trip
         u32 loc;
         const int h = wk.pop(loc);
-        if (h != 0) {
+        if (h > 1 || (!PCPX_RANGE_DIRECT_LEAVES && h == 1)) {
             wk.expand(t, h, loc, need);
+        } else if (h == 1) {
+            const u32 needed = wk.leaves_of(t, loc, need);
+            const Leaf* records = t.leaves + (loc << LOGW);
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                if ((needed >> c) & 1u) {
+                    u32 how_many = GROUP;
+                    if (sparse_leaves) asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
+                    if (sparse_leaves && how_many <= static_cast<u32>(PCPX_RANGE_SPARSE_LEAVES)) sparse_leaf(records + c, wk.leaf_need[c]);
+                    else leaf_record_points(load_const(records + c));
+                }
+            }
         } else {
             wk.at_leaf(loc);
             leaf_points(loc);

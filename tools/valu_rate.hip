@@ -259,6 +259,107 @@ __global__ __launch_bounds__(64) void k_candidate(float* out, float seed)
     out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x] + wa + pos;
 }
 
+// lane exchanges through the scalar file, as the point-per-lane leaf form of k_knn uses them (pcpx_query.hip: sparse_leaf)
+__global__ __launch_bounds__(64) void k_readlane(float* out, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    unsigned s0, s1, s2, s3, acc = 0;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b32 m0, 5\n" REP8("v_readlane_b32 %0, %4, m0\nv_readlane_b32 %1, %5, m0\n"
+                                             "v_readlane_b32 %2, %6, m0\nv_readlane_b32 %3, %7, m0\n")
+                     : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                     : "m0");
+        acc += s0 ^ s1 ^ s2 ^ s3;
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + acc;
+}
+// each read followed by a vector instruction that takes the scalar just written as an operand
+__global__ __launch_bounds__(64) void k_readlane_use(float* out, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    unsigned s0, s1, s2, s3;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b32 m0, 5\n" REP4("v_readlane_b32 %0, %4, m0\nv_readlane_b32 %1, %5, m0\n"
+                                             "v_readlane_b32 %2, %6, m0\nv_readlane_b32 %3, %7, m0\n"
+                                             "v_subrev_f32_e32 %4, %0, %4\nv_subrev_f32_e32 %5, %1, %5\n"
+                                             "v_subrev_f32_e32 %6, %2, %6\nv_subrev_f32_e32 %7, %3, %7\n")
+                     : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     :
+                     : "m0");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+__global__ __launch_bounds__(64) void k_writelane(float* out, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b32 m0, 5\n" REP8("v_writelane_b32 %0, 7, m0\nv_writelane_b32 %1, 7, m0\n"
+                                             "v_writelane_b32 %2, 7, m0\nv_writelane_b32 %3, 7, m0\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     :
+                     : "m0");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+__global__ __launch_bounds__(64) void k_mbcnt(float* out, float seed)
+{
+    unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    unsigned s0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(seed) | 0xf0f0u);
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile(REP8("v_mbcnt_lo_u32_b32 %0, %4, %0\nv_mbcnt_lo_u32_b32 %1, %4, %1\n"
+                          "v_mbcnt_lo_u32_b32 %2, %4, %2\nv_mbcnt_lo_u32_b32 %3, %4, %3\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     : "s"(s0));
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = static_cast<float>(a0 + a1 + a2 + a3);
+}
+// one needing lane of a sparse leaf as k_knn issues it: 5 v_readlane, 8 distance ops, v_cmpx, rank, address, LDS write,
+// v_writelane (17 VALU + 1 LDS + 8 SALU + the loop branch, which is left out here)
+__global__ __launch_bounds__(64) void k_sparse_owner(float* out, float seed)
+{
+    __shared__ float buf[64 * 16];
+    float qx = seed + threadIdx.x, qy = qx * 0.5f, qz = qx * 0.25f, tau = -1.f, cx = seed, cy = seed * 2, cz = seed * 3;
+    unsigned wa = threadIdx.x * 4, pos = threadIdx.x;
+    unsigned long long saved, todo = ~0ull;
+    unsigned ox, oy, oz, otau, owa, owner;
+    float d, e;
+    for (int i = 0; i < ITER; ++i) {
+        asm volatile("s_mov_b64 %[sv], exec\n\t" REP8("s_ff1_i32_b64 m0, %[todo]\n\t"
+                                                     "s_bitset1_b64 %[todo], m0\n\t"
+                                                     "v_readlane_b32 %[sx], %[qx], m0\n\t"
+                                                     "v_readlane_b32 %[sy], %[qy], m0\n\t"
+                                                     "v_readlane_b32 %[sz], %[qz], m0\n\t"
+                                                     "v_readlane_b32 %[st], %[tau], m0\n\t"
+                                                     "v_readlane_b32 %[sw], %[wa], m0\n\t"
+                                                     "s_mov_b64 exec, 0xff\n\t"
+                                                     "v_subrev_f32_e32 %[d], %[sx], %[cx]\n\t"
+                                                     "v_subrev_f32_e32 %[e], %[sy], %[cy]\n\t"
+                                                     "v_mul_f32_e32 %[d], %[d], %[d]\n\t"
+                                                     "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
+                                                     "v_add_f32_e32 %[d], %[d], %[e]\n\t"
+                                                     "v_subrev_f32_e32 %[e], %[sz], %[cz]\n\t"
+                                                     "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
+                                                     "v_add_f32_e32 %[d], %[d], %[e]\n\t"
+                                                     "v_cmpx_ge_f32_e32 %[st], %[d]\n\t"
+                                                     "s_bcnt1_i32_b64 %[L], exec\n\t"
+                                                     "v_mbcnt_lo_u32_b32 %[e], exec_lo, 0\n\t"
+                                                     "v_lshl_add_u32 %[e], %[e], 9, %[sw]\n\t"
+                                                     "ds_write2_b32 %[e], %[pos], %[d] offset1:1\n\t"
+                                                     "s_lshl_b32 %[L], %[L], 9\n\t"
+                                                     "s_add_u32 %[sw], %[sw], %[L]\n\t"
+                                                     "s_cmp_lg_u64 %[todo], 0\n\t"
+                                                     "v_writelane_b32 %[wa], %[sw], m0\n\t"
+                                                     "s_mov_b64 exec, %[sv]\n\t")
+                     : [sv] "=&s"(saved), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [st] "=&s"(otau),
+                       [sw] "=&s"(owa), [d] "=&v"(d), [e] "=&v"(e), [wa] "+v"(wa), [todo] "+s"(todo)
+                     : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [tau] "v"(tau), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [pos] "v"(pos)
+                     : "m0", "vcc", "scc", "memory");
+    }
+    __syncthreads();
+    out[blockIdx.x * 64 + threadIdx.x] = buf[threadIdx.x] + wa;
+}
+
 #define LDS_KERNEL(name, body, clob)                                                  \
     __global__ __launch_bounds__(64) void name(float* out, float seed)                 \
     {                                                                                 \
@@ -316,6 +417,11 @@ int main()
         {"accept seq (x1)", k_accept_seq, 8},
         {"accept seq no LDS", k_accept_seq_nolds, 8},
         {"candidate (x1)", k_candidate, 8},
+        {"v_readlane_b32", k_readlane, 32},
+        {"v_readlane + use x4", k_readlane_use, 32},
+        {"v_writelane_b32", k_writelane, 32},
+        {"v_mbcnt_lo", k_mbcnt, 32},
+        {"sparse owner (x1)", k_sparse_owner, 8},
     };
     std::printf("%-18s %10s %10s %10s   (cycles per wave-instruction [or per sequence] per SIMD at 1, 2, 4, 5 waves/SIMD)\n", "instruction", "w=1", "w=2",
                 "w=4 (w=5)");
