@@ -357,7 +357,7 @@ def main():
         # write + 12 B normal write per query (84 B at k = 15); the fused k_knn launch does exactly that
         bytes_per_q = 12 + 4 * k + (0 if args.workload in STREAMING else 12)
         achieved = q_per_launch * bytes_per_q / avg_s
-        roofline = {"bound": "hbm", "limiter": "instruction issue (vector pipe ~96 %, scalar pipe ~62 % of the SIMD cycles)", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
+        roofline = {"bound": "hbm", "limiter": "instruction issue, vector and scalar pipes (profiles/r03_valu_issue_model.json: ~93 % and ~72 % of the SIMD cycles)", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_query": bytes_per_q, "queries_per_launch": q_per_launch,
