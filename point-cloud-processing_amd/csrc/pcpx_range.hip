@@ -19,7 +19,10 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // One group of 64 curve-consecutive queries, one per lane: the wave-uniform walk of pcpx_device.h, a leaf's 8 points
 // broadcast from SGPRs, the count kept per lane (compare + add-with-carry: 2 VALU per candidate on top of the 8 of the
-// distance -- an exec-masked form would not be shorter).
+// distance -- an exec-masked form would not be shorter).  The kernel sits on both issue pipes, so what pays is what takes
+// instructions off both: a last-level node looks at its own leaves (no push and pop), and a leaf that few lanes need is
+// counted point-per-lane for those lanes only (count form; the fill form keeps the lane-per-range leaf).  Measured one at
+// a time each gave nothing, together 2.56 -> 2.40 ms per 10 M counts at r = 0.01 (profiles/experiments/README.md).
 template <bool SELF, bool FILL>
 __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& qv, const u32 g, const float radius,
                                             const float* __restrict__ radii, u32* __restrict__ out_cnt,
