@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define PCPX_ABI_VERSION 3
+#define PCPX_ABI_VERSION 4
 
 typedef enum pcpx_status {
     PCPX_OK = 0,
@@ -76,11 +76,36 @@ typedef struct pcpx_index pcpx_index; /* opaque: device buffers + stream */
                                      are a little less compact (k-NN 3 % slower at 10 M clustered points, the rebuild 5 %    \
                                      faster at 50 M uniform).  Additive: the reference has no counterpart.                 */
 
+#define PCPX_BUILD_SHARD 4u /* RANK-LOCAL index for the multi-GPU path (one process per GPU, the cloud replicated): the     \
+                              handle indexes only what shard `shard_rank` of `shard_world` of the curve-sorted queries      \
+                              (pcpx_shard_range over pcpx_index_size) can reach -- the cells of the curve that hold the     \
+                              shard and a halo of cells around them -- instead of the whole cloud: curve keys for every     \
+                              point, then sort + leaves + boxes for about 1 / world of them.  The *_self_dev entry points    \
+                              then take slices INSIDE that shard (positions of the WHOLE cloud's order, as before) and       \
+                              return exactly what the whole-cloud index returns: every query's k-th distance is checked      \
+                              against the cells the handle holds, and a query whose search ball leaves them is answered      \
+                              again after the handle has taken the missing cells in (it keeps them: a static index pays     \
+                              once).  Because of that check these calls synchronise the stream before they return.          \
+                              pcpx_index_size / _bbox describe the whole cloud.  Entry points that need the whole cloud      \
+                              indexed (arbitrary query batches, range lists, host-pointer forms) fail with                   \
+                              PCPX_ERR_UNSUPPORTED on such a handle.  No collective is involved: ranks agree on the grid     \
+                              beforehand (PCPX_BUILD_USE_GRID, pcpx_comm_global_grid_dev).  Additive: the reference is        \
+                              single-process.                                                                             */
+#define PCPX_BUILD_BORROW_CLOUD 8u /* *_dev builds only: the handle reads the caller's d_xyz in place instead of copying it    \
+                                      (12 B/point less to write per rebuild); the array must stay valid and unchanged until   \
+                                      the handle is rebuilt or destroyed.  Without the flag the handle copies, like the       \
+                                      reference's containers do (linked_kdtree.hpp:107).                                   */
+
 typedef struct pcpx_build_params {
-    uint32_t struct_size; /* = sizeof(pcpx_build_params) */
+    uint32_t struct_size; /* = sizeof(pcpx_build_params) (callers built against ABI 3 pass its first 32 bytes: accepted) */
     uint32_t flags;
     float grid_min[3];
     float grid_max[3];
+    /* PCPX_BUILD_SHARD */
+    uint32_t shard_rank;
+    uint32_t shard_world;
+    uint32_t shard_k_hint; /* the k the shard will be asked for: sizes the halo (0 = 32).  Only a performance hint. */
+    uint32_t reserved;     /* 0 */
 } pcpx_build_params;
 
 int pcpx_abi_version(void);
@@ -100,6 +125,11 @@ void pcpx_index_destroy(pcpx_index* idx);
 int pcpx_index_size(pcpx_index* idx, uint64_t* out_n);
 /* voxel_grid() / aabb(): {minx,miny,minz,maxx,maxy,maxz} (linked_octree.hpp:144, linked_kdtree.hpp:187). */
 int pcpx_index_bbox(pcpx_index* idx, float out6[6]);
+/* A rank-local handle (PCPX_BUILD_SHARD) described: out[0] points in the local tree, [1] first global curve position of its
+ * core, [2] points of the core, [3] / [4] the shard (first position, count), [5] halo width in cells of the selection grid
+ * (64 per axis), [6] queries the last coverage check sent round again, [7] times the handle has taken more cells in.
+ * PCPX_ERR_INVALID for a whole-cloud handle. */
+int pcpx_index_shard_info(pcpx_index* idx, uint64_t out[8]);
 /* pcp::bounding_box over a host slice (axis_aligned_bounding_box.hpp:214-251): the per-rank step
  * before the bounding-box all-gather of the multi-GPU path. */
 int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6]);
@@ -120,6 +150,16 @@ int pcpx_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_fi
                       uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
 int pcpx_knn_batch_dev(pcpx_index* idx, const float* d_q_xyz, uint64_t nq, uint32_t k, float eps,
                        uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
+/* Rows by CURVE POSITION, device resident (additive): row p of every output belongs to the p-th point of the curve order,
+ * i.e. to input point perm[p] (pcpx_index_perm_dev); neighbour indices inside the rows are input indices as everywhere.
+ * A wavefront's 64 rows are then one contiguous piece of each output (the input-order form scatters 60-byte rows over the
+ * whole array).  Any of d_opt_normals / d_opt_d2 may be NULL; slice arguments as pcpx_knn_self_dev. */
+int pcpx_knn_self_curve_order_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                                  uint32_t* d_out_idx, uint32_t* d_out_count, float* d_opt_d2, float* d_opt_normals);
+/* The curve order itself: d_out_perm[p] = input index of the p-th point (pcpx_index_size entries; a rank-local handle: the
+ * entries of its core only, at their global positions), d_opt_out_position_of[i] = position of input point i (n entries,
+ * 0xFFFFFFFF for a point that is not indexed).  Either may be NULL.  Enqueued on the handle's stream. */
+int pcpx_index_perm_dev(pcpx_index* idx, uint32_t* d_out_perm, uint32_t* d_opt_out_position_of);
 
 /* ---- radius search: replaces range_search ------------------------------------------------ */
 /* Count only (what examples/filter_point_cloud_noise_by_density.cpp:81-90 consumes). */

@@ -10,7 +10,7 @@ f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 
-ABI_VERSION = 3  # include/pcpx.h PCPX_ABI_VERSION
+ABI_VERSION = 4  # include/pcpx.h PCPX_ABI_VERSION
 PCPX_OK = 0
 PCPX_ERR_INVALID = -1
 PCPX_ERR_DEVICE = -2
@@ -19,12 +19,15 @@ PCPX_ERR_CAPACITY = -4
 PCPX_ERR_UNSUPPORTED = -5
 PCPX_BUILD_USE_GRID = 1
 PCPX_BUILD_COARSE_ORDER = 2
+PCPX_BUILD_SHARD = 4
+PCPX_BUILD_BORROW_CLOUD = 8
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 
 class BuildParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("grid_min", C.c_float * 3),
-                ("grid_max", C.c_float * 3)]
+                ("grid_max", C.c_float * 3), ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32),
+                ("shard_k_hint", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Profile(C.Structure):
@@ -53,6 +56,10 @@ SIGNATURES = {
     "pcpx_index_destroy": (None, [C.c_void_p]),
     "pcpx_index_size": (C.c_int, [C.c_void_p, u64p]),
     "pcpx_index_trim": (C.c_int, [C.c_void_p]),
+    "pcpx_index_shard_info": (C.c_int, [C.c_void_p, u64p]),
+    "pcpx_knn_self_curve_order_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]),
+    "pcpx_index_perm_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcpx_estimate_normals_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "pcpx_index_bbox": (C.c_int, [C.c_void_p, f32p]),
     "pcpx_bounding_box": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, f32p]),

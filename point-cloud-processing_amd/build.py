@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ_DIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libpcpx.so")
-SOURCES = ["pcpx_query.hip", "pcpx_few.hip", "pcpx_range.hip", "pcpx_filter.hip", "pcpx_normals.hip", "pcpx_prep.hip", "pcpx_orient.hip", "pcpx_build.hip", "pcpx_sort.hip",
+SOURCES = ["pcpx_query.hip", "pcpx_few.hip", "pcpx_range.hip", "pcpx_filter.hip", "pcpx_normals.hip", "pcpx_prep.hip", "pcpx_orient.hip", "pcpx_build.hip", "pcpx_shard.hip", "pcpx_sort.hip",
            "pcpx_comm.hip", "pcpx_api.hip"]
 HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(CSRC, "pcpx_device.h"), os.path.join(CSRC, "pcpx_eig3.h"), os.path.join(CSRC, "pcpx_curve.h"),
            os.path.join(CSRC, "pcpx_curve_table.h"),
@@ -23,8 +23,9 @@ ARCH = "gfx950"
 # -fno-slp-vectorize: SLP packs the scalar f32 distance code into v_pk_* ops plus v_mov shuffles; packed
 # f32 is not faster than scalar VALU on gfx950 and the shuffles cost ~4 % (measured, tools/ab_variants.py).
 # -Wall -Werror=uninitialized: a self-initialised index (`u32 tid = tid;`) once reached the GPU as a wild address.
+# -Werror=inline-asm: no reserved register (m0, ...) on an asm clobber list -- hipcc only warns that it "may not be preserved".
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=" + ARCH,
-         "-Wall", "-Werror=uninitialized", "-I" + INCLUDE]
+         "-Wall", "-Werror=uninitialized", "-Werror=inline-asm", "-I" + INCLUDE]
 
 
 def _hipcc():

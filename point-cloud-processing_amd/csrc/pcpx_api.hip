@@ -255,6 +255,37 @@ int no_throw(const char* what, Body&& body)
     }
 }
 
+// pcpx_build_params as this library knows it, from what the caller passed: ABI 3 callers pass the first 32 bytes
+constexpr size_t BUILD_PARAMS_ABI3 = 32;
+int normalise_params(const pcpx_build_params* in, bool device_form, pcpx_build_params& out, const pcpx_build_params*& use)
+{
+    use = nullptr;
+    if (!in) return PCPX_OK;
+    if (in->struct_size != sizeof(pcpx_build_params) && in->struct_size != BUILD_PARAMS_ABI3) {
+        set_error("pcpx: params->struct_size mismatch");
+        return PCPX_ERR_INVALID;
+    }
+    std::memset(&out, 0, sizeof(out));
+    std::memcpy(&out, in, in->struct_size);
+    out.struct_size = sizeof(pcpx_build_params);
+    if (in->struct_size == BUILD_PARAMS_ABI3) out.flags &= (PCPX_BUILD_USE_GRID | PCPX_BUILD_COARSE_ORDER);
+    if ((out.flags & PCPX_BUILD_BORROW_CLOUD) && !device_form) {
+        set_error("pcpx: PCPX_BUILD_BORROW_CLOUD needs a device-pointer build (the host-pointer forms stage the cloud in a temporary)");
+        return PCPX_ERR_INVALID;
+    }
+    if ((out.flags & PCPX_BUILD_BORROW_CLOUD) && !(out.flags & PCPX_BUILD_SHARD)) {
+        set_error("pcpx: PCPX_BUILD_BORROW_CLOUD is a property of rank-local builds (PCPX_BUILD_SHARD)");
+        return PCPX_ERR_INVALID;
+    }
+    use = &out;
+    return PCPX_OK;
+}
+
+#define PCPX_WHOLE_CLOUD_ONLY(ix, name)                              \
+    do {                                                             \
+        if ((ix)->shard.on) return shard_unsupported(*(ix), name);   \
+    } while (0)
+
 void slice_to_groups(const Index& ix, u64 sorted_first, u64 sorted_count, u64& gfirst, u64& gcount)
 {
     u64 n = ix.n;
@@ -286,6 +317,7 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_scratch);
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
+    free_shard(*ix);
     if (ix->copy_stream) (void)hipStreamDestroy(ix->copy_stream);
     if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;  // (the pool and the pinned stage free their memory in their destructors, while the device is still current)
@@ -332,13 +364,12 @@ static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_bui
         set_error("pcpx_index_create: null argument");
         return PCPX_ERR_INVALID;
     }
-    if (params && params->struct_size != sizeof(pcpx_build_params)) {
-        set_error("pcpx_index_create: params->struct_size mismatch");
-        return PCPX_ERR_INVALID;
-    }
     *out = nullptr;
+    pcpx_build_params full;
+    int st = normalise_params(params, on_device, full, params);
+    if (st != PCPX_OK) return st;
     DeviceScope dscope;
-    int st = dscope.select(device);
+    st = dscope.select(device);
     if (st != PCPX_OK) return st;
     Index* ix = new (std::nothrow) Index();
     if (!ix) return PCPX_ERR_ALLOC;
@@ -400,6 +431,8 @@ int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_b
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !xyz) return PCPX_ERR_INVALID;
+    pcpx_build_params full;
+    if ((st = normalise_params(params, false, full, params)) != PCPX_OK) return st;
     DevBuf staged(ix->pool, true);
     if (n > 0) {
         if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
@@ -419,6 +452,8 @@ int pcpx_index_rebuild_dev(pcpx_index* h, const float* d_xyz, uint64_t n, const 
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
     if (n > 0 && !d_xyz) return PCPX_ERR_INVALID;
+    pcpx_build_params full;
+    if ((st = normalise_params(params, true, full, params)) != PCPX_OK) return st;
     return build_index(*ix, d_xyz, n, params);
 }
 
@@ -427,7 +462,26 @@ void pcpx_index_destroy(pcpx_index* h) { free_index(reinterpret_cast<Index*>(h))
 int pcpx_index_size(pcpx_index* h, uint64_t* out_n)
 {
     if (!h || !out_n) return PCPX_ERR_INVALID;
-    *out_n = reinterpret_cast<Index*>(h)->n;
+    const Index* ix = reinterpret_cast<Index*>(h);
+    *out_n = ix->shard.on ? ix->shard.n_glob : ix->n;  // (a rank-local handle: the whole cloud's inserted points)
+    return PCPX_OK;
+}
+int pcpx_index_shard_info(pcpx_index* h, uint64_t out[8])
+{
+    const Index* ix = reinterpret_cast<Index*>(h);
+    if (!ix || !out || !ix->shard.on) {
+        set_error("pcpx_index_shard_info: not a rank-local index");
+        return PCPX_ERR_INVALID;
+    }
+    const Index::Shard& sh = ix->shard;
+    out[0] = ix->n;
+    out[1] = sh.core_g0;
+    out[2] = sh.core_count;
+    out[3] = sh.g_first;
+    out[4] = sh.g_count;
+    out[5] = sh.everything ? 64 : sh.halo_cells;
+    out[6] = sh.last_failed;
+    out[7] = sh.enlargements;
     return PCPX_OK;
 }
 int pcpx_index_bbox(pcpx_index* h, float out6[6])
@@ -508,14 +562,62 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
         set_error("pcpx_knn_self_dev: sorted_first must be a multiple of %d", GROUP);
         return PCPX_ERR_INVALID;
     }
-    u64 gf, gc;
-    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
-    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
     KnnOutputs o;
     o.idx = d_out_idx;
     o.cnt = d_out_count;
     o.d2 = d_out_d2;
+    if (ix->shard.on) return shard_knn_self(*ix, sorted_first, sorted_count, k, eps, o);
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
     return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
+}
+
+int pcpx_knn_self_curve_order_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count, uint32_t* d_out_idx,
+                                  uint32_t* d_out_count, float* d_opt_d2, float* d_opt_normals)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    if (k == 0) return PCPX_OK;
+    if (!d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
+    if (sorted_first % GROUP != 0) {
+        set_error("pcpx_knn_self_curve_order_dev: sorted_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
+    }
+    KnnOutputs o;
+    o.idx = d_out_idx;
+    o.cnt = d_out_count;
+    o.d2 = d_opt_d2;
+    o.normals = d_opt_normals;
+    o.by_position = 1;
+    if (k > 32 && o.normals) {
+        set_error("pcpx_knn_self_curve_order_dev: fused normals need k <= 32");
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    if (ix->shard.on) return shard_knn_self(*ix, sorted_first, sorted_count, k, eps, o);
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    return launch_knn(*ix, qv, true, gf, gc, k, eps, o);
+}
+
+int pcpx_index_perm_dev(pcpx_index* h, uint32_t* d_out_perm, uint32_t* d_opt_out_position_of)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    if (!d_out_perm && !d_opt_out_position_of) return PCPX_ERR_INVALID;
+    if (d_opt_out_position_of) PCPX_HIP(hipMemsetAsync(d_opt_out_position_of, 0xFF, ix->n_in * sizeof(u32), ix->stream));
+    if (ix->shard.on) return shard_perm(*ix, d_out_perm, d_opt_out_position_of);
+    if (ix->n == 0) return PCPX_OK;
+    if (d_out_perm) PCPX_HIP(hipMemcpyAsync(d_out_perm, ix->d_perm, ix->n * sizeof(u32), hipMemcpyDeviceToDevice, ix->stream));
+    if (d_opt_out_position_of) return launch_invert_perm(ix->d_perm, ix->n, d_opt_out_position_of, ix->stream);
+    return PCPX_OK;
 }
 
 // Self queries with HOST outputs (pcpx_knn_self, pcpx_normals_knn_self): device staging from the handle's pool (no
@@ -575,6 +677,7 @@ int pcpx_knn_self(pcpx_index* h, uint32_t k, float eps, uint32_t* out_idx, uint3
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_knn_self");
     if (!out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
     if (k == 0) {  // linked_octree_node.hpp:464: k == 0 -> {}
         std::memset(out_count, 0, ix->n_in * sizeof(u32));
@@ -591,6 +694,7 @@ int pcpx_knn_batch_dev(pcpx_index* h, const float* d_q_xyz, uint64_t nq, uint32_
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_knn_batch_dev");
     if (k == 0 || nq == 0) return PCPX_OK;
     if (!d_q_xyz || !d_out_idx || !d_out_count) return PCPX_ERR_INVALID;
     QueryView qv;
@@ -610,6 +714,7 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_knn_batch");
     if (nq == 0) return PCPX_OK;
     if (!q_xyz || !out_count || (k > 0 && !out_idx)) return PCPX_ERR_INVALID;
     if (k == 0) {
@@ -685,6 +790,7 @@ int pcpx_range_count_self_dev(pcpx_index* h, float radius, uint64_t sorted_first
         set_error("pcpx_range_count_self_dev: sorted_first must be a multiple of %d", GROUP);
         return PCPX_ERR_INVALID;
     }
+    if (ix->shard.on) return shard_range_count_self(*ix, radius, sorted_first, sorted_count, d_out_count);
     u64 gf, gc;
     slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
@@ -698,6 +804,7 @@ int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_range_count_self");
     if (!out_count) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dc(ix->pool);
@@ -716,6 +823,7 @@ int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_range_count_batch");
     if (nq == 0) return PCPX_OK;
     if (!q_xyz || !out_count) return PCPX_ERR_INVALID;
     DevBuf dq(ix->pool), dc(ix->pool);
@@ -774,6 +882,7 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_range_sphere_batch");
     if (!out_offsets || (nq > 0 && !q_xyz)) return PCPX_ERR_INVALID;
     if (nq == 0) {
         out_offsets[0] = 0;
@@ -825,6 +934,7 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_range_aabb_batch");
     if (!out_offsets || (nb > 0 && !boxes6)) return PCPX_ERR_INVALID;
     if (nb == 0) {
         out_offsets[0] = 0;
@@ -881,6 +991,13 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     o.idx = d_opt_out_idx;
     o.cnt = d_opt_out_count;
     o.normals = d_out_normals;
+    if (ix->shard.on) {
+        if (k > 32 && (!o.idx || !o.cnt)) {
+            set_error("pcpx_normals_knn_self_dev: a rank-local index with k > 32 needs the row outputs too");
+            return PCPX_ERR_UNSUPPORTED;
+        }
+        return shard_knn_self(*ix, sorted_first, sorted_count, k, eps, o);
+    }
     if (k > 32 && (!o.idx || !o.cnt)) {  // the multi-pass path materialises rows: keep them in index scratch
         size_t need_idx = (static_cast<size_t>(ix->n_in) * k * sizeof(u32) + 255) / 256 * 256;
         if ((st = ensure_scratch(*ix, need_idx + static_cast<size_t>(ix->n_in) * sizeof(u32))) != PCPX_OK) return st;
@@ -911,6 +1028,13 @@ int pcpx_neighbourhoods_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t 
     o.normals = d_opt_normals;
     o.centroids = d_opt_centroids;
     o.meandist = d_opt_mean_dist;
+    if (ix->shard.on) {
+        if (k > 32) {
+            set_error("pcpx_neighbourhoods_self_dev: a rank-local index answers this for k <= 32");
+            return PCPX_ERR_UNSUPPORTED;
+        }
+        return shard_knn_self(*ix, sorted_first, sorted_count, k, eps, o);
+    }
     if (k > 32) {  // the multi-pass path materialises rows: keep them in index scratch
         size_t need_idx = (static_cast<size_t>(ix->n_in) * k * sizeof(u32) + 255) / 256 * 256;
         if ((st = ensure_scratch(*ix, need_idx + static_cast<size_t>(ix->n_in) * sizeof(u32))) != PCPX_OK) return st;
@@ -927,6 +1051,7 @@ int pcpx_tangent_planes_knn_self(pcpx_index* h, uint32_t k, float eps, float* ou
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_tangent_planes_knn_self");
     if (!out_centroids || !out_normals || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dc(ix->pool), dn(ix->pool);
@@ -948,6 +1073,7 @@ int pcpx_mean_knn_distance_self(pcpx_index* h, uint32_t k, float eps, float* out
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_mean_knn_distance_self");
     if (!out_mean_dist || k == 0) return PCPX_ERR_INVALID;
     u64 rows = ix->n_in;
     DevBuf dm(ix->pool);
@@ -967,6 +1093,7 @@ int pcpx_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* out_norma
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_normals_knn_self");
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
     return self_queries_to_host(ix, k, eps, out_normals, opt_out_idx, opt_out_count, nullptr);
 }
@@ -982,6 +1109,7 @@ int pcpx_normals_knn_self_curve_order(pcpx_index* h, uint32_t k, float eps, floa
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_normals_knn_self_curve_order");
     if (k == 0 || !out_idx || !out_count) return PCPX_ERR_INVALID;
     const u64 rows = ix->n;  // inserted points only: a point outside the voxel grid has no position on the curve
     if (opt_out_position_of && ix->n != ix->n_in) std::memset(opt_out_position_of, 0xFF, ix->n_in * sizeof(u32));
@@ -1045,6 +1173,7 @@ int pcpx_normals_from_knn(pcpx_index* h, const uint32_t* nbr_idx, const uint32_t
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_normals_from_knn");
     if (nq == 0) return PCPX_OK;
     if (!nbr_idx || !count || !out_normals || k == 0) return PCPX_ERR_INVALID;
     for (u64 q = 0; q < nq; ++q) {
@@ -1166,6 +1295,7 @@ int pcpx_debug_knn_stats(pcpx_index* h, uint32_t k, float eps, uint64_t* out_sta
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_debug_knn_stats");
     if (!out_stats || capacity < 16 || k == 0 || k > 16) return PCPX_ERR_INVALID;
     DevBuf ds(ix->pool);
     const size_t cap = 16 + 5 * 65536;  // 16 counters + 5-word records of up to 65536 persistent waves
@@ -1282,6 +1412,7 @@ int pcpx_oriented_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* 
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_oriented_normals_knn_self");
     if (!out_normals || k == 0) return PCPX_ERR_INVALID;
     if (ix->n != ix->n_in) {
         set_error("pcpx_oriented_normals_knn_self: %llu of %llu points lie outside the voxel grid and have no neighbourhood",
@@ -1311,6 +1442,7 @@ int pcpx_orient_normals_knn_self(pcpx_index* h, uint32_t k, float eps, float* no
     int st = dscope.use(ix);
     if (st != PCPX_OK) return st;
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);  // one call at a time per handle (queries share its scratch)
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_orient_normals_knn_self");
     if (!normals || k == 0) return PCPX_ERR_INVALID;
     if (ix->n != ix->n_in) {
         set_error("pcpx_orient_normals_knn_self: %llu of %llu points lie outside the voxel grid and have no neighbourhood",

@@ -149,10 +149,15 @@ __global__ void k_build_begin(u32* __restrict__ scalars)
 // scalars: Index::d_scalars.
 constexpr int CODES_BLOCK = 1024;
 __global__ __launch_bounds__(CODES_BLOCK) void k_codes(const float* __restrict__ xyz, u64 n, u32* __restrict__ scalars, bool decode_box, int idx_bits,
-                                                        u64* __restrict__ codes, float* __restrict__ xyz_copy, u32* __restrict__ tile_hist)
+                                                        u64* __restrict__ codes, float* __restrict__ xyz_copy, u32* __restrict__ tile_hist,
+                                                        u32* __restrict__ hist12)
 {
     __shared__ u32 hist[256];
     __shared__ u32 htab[HILBERT_TABLE_WORDS];
+    __shared__ u32 cells[4096];  // hist12 (a rank-local build): points per level-4 cell of the curve, this block's share
+    if (hist12) {
+        for (u32 c = threadIdx.x; c < 4096u; c += CODES_BLOCK) cells[c] = 0;
+    }
     float* box6 = reinterpret_cast<float*>(scalars + 8);
     float b[6];
 #pragma unroll
@@ -182,12 +187,19 @@ __global__ __launch_bounds__(CODES_BLOCK) void k_codes(const float* __restrict__
                 const u64 word = ok ? sort_word(curve_key_inside(x, y, z, grid, htab, idx_bits), i, idx_bits) : outside_word(i, idx_bits);
                 codes[i] = word;
                 outside += ok ? 0u : 1u;
-                atomicAdd(&hist[static_cast<u32>(word >> 56)], 1u);
+                if (tile_hist) atomicAdd(&hist[static_cast<u32>(word >> 56)], 1u);
+                if (hist12 && ok) atomicAdd(&cells[static_cast<u32>(word >> 52)], 1u);
             }
         }
         __syncthreads();
-        if (threadIdx.x < 256) tile_hist[tile * 256 + threadIdx.x] = hist[threadIdx.x];
+        if (tile_hist && threadIdx.x < 256) tile_hist[tile * 256 + threadIdx.x] = hist[threadIdx.x];
         __syncthreads();
+    }
+    if (hist12) {
+        for (u32 c = threadIdx.x; c < 4096u; c += CODES_BLOCK) {
+            const u32 v = cells[c];
+            if (v) atomicAdd(&hist12[c], v);
+        }
     }
     const u64 some_outside = __builtin_amdgcn_ballot_w64(outside != 0u);
     if (some_outside) {  // rare: one atomic per wave that saw any
@@ -474,6 +486,178 @@ int ensure_scratch(Index& ix, size_t bytes)
     return PCPX_OK;
 }
 
+// Device arrays of a handle come in two groups with a capacity each: the CLOUD arrays (the index's copy of the input and one
+// sort word per input point) and the TREE arrays (sorted words, permutation, records, leaves, boxes, the sort's temporary
+// storage).  For the whole-cloud index both hold n points; a rank-local index (pcpx_shard.hip) keeps the cloud arrays at n and
+// the tree arrays at the size of its selection.  Growing: every new buffer is allocated first and swapped in only when all
+// allocations have succeeded, so a failure (e.g. out of memory on a 50 M-point rebuild) leaves the handle on its previous,
+// still valid index.
+static int grow_arrays(Index& ix, u64 need_cloud, u64 need_tree, bool want_xyz)
+{
+    const bool grow_cloud = need_cloud > ix.cap || !ix.d_codes[0] || (want_xyz && (!ix.d_xyz || need_cloud > ix.cap_xyz));
+    const bool grow_tree = need_tree > ix.cap_tree || !ix.d_leaves;
+    if (!grow_cloud && !grow_tree) return PCPX_OK;
+    PCPX_HIP(hipStreamSynchronize(ix.stream));
+    struct Fresh {
+        float* xyz = nullptr;
+        u64* codes[2] = {nullptr, nullptr};
+        u32* perm = nullptr;
+        float4* rec = nullptr;
+        Leaf* leaves = nullptr;
+        NodeBox* nodes = nullptr;
+        void* sort_tmp = nullptr;
+        bool keep = false;
+        ~Fresh()
+        {
+            if (keep) return;
+            (void)hipFree(xyz);
+            (void)hipFree(codes[0]); (void)hipFree(codes[1]);
+            (void)hipFree(perm);
+            (void)hipFree(rec);
+            (void)hipFree(leaves); (void)hipFree(nodes); (void)hipFree(sort_tmp);
+        }
+    } nw;
+    int st;
+    const u64 ccap = need_cloud < 64 ? 64 : need_cloud, tcap = need_tree < 64 ? 64 : need_tree;
+    u64 nodes = 0;
+    size_t tb = 0;
+    if (grow_cloud) {
+        if (want_xyz && (st = dev_alloc(nw.xyz, ccap * 3, &ix.pool)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.codes[0], ccap, &ix.pool)) != PCPX_OK) return st;
+    }
+    if (grow_tree) {
+        if ((st = dev_alloc(nw.codes[1], tcap, &ix.pool)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.perm, tcap, &ix.pool)) != PCPX_OK) return st;
+        if ((st = dev_alloc(nw.rec, tcap, &ix.pool)) != PCPX_OK) return st;
+        u32 nl = static_cast<u32>((tcap + LEAF - 1) / LEAF);
+        if ((st = dev_alloc(nw.leaves, nl, &ix.pool)) != PCPX_OK) return st;
+        nodes = level_start(depth_for(nl) + 1);
+        if ((st = dev_alloc(nw.nodes, nodes, &ix.pool)) != PCPX_OK) return st;
+        if ((st = sort_keys_u64(nullptr, tb, nullptr, nullptr, tcap, ix.stream)) != PCPX_OK) return st;
+        char* tmp = nullptr;
+        if ((st = dev_alloc(tmp, tb ? tb : 16, &ix.pool)) != PCPX_OK) return st;
+        nw.sort_tmp = tmp;
+    }
+    if (grow_cloud) {
+        (void)hipFree(ix.d_xyz);
+        ix.d_xyz = nw.xyz;
+        ix.cap_xyz = want_xyz ? ccap : 0;
+        (void)hipFree(ix.d_codes[0]);
+        ix.d_codes[0] = nw.codes[0];
+        ix.cap = ccap;
+    }
+    if (grow_tree) {
+        (void)hipFree(ix.d_codes[1]);
+        ix.d_codes[1] = nw.codes[1];
+        (void)hipFree(ix.d_perm);
+        ix.d_perm = nw.perm;
+        (void)hipFree(ix.d_rec);
+        ix.d_rec = nw.rec;
+        (void)hipFree(ix.d_leaves);
+        (void)hipFree(ix.d_nodes);
+        (void)hipFree(ix.d_sort_tmp);
+        ix.d_leaves = nw.leaves;
+        ix.d_nodes = nw.nodes;
+        ix.d_sort_tmp = nw.sort_tmp;
+        ix.nodes_cap = nodes;
+        ix.sort_tmp_bytes = tb;
+        ix.cap_tree = tcap;
+    }
+    nw.keep = true;
+    // the old index is gone: until this build completes the handle holds an empty one
+    ix.n = ix.n_in = 0;
+    ix.nleaves = 0;
+    ix.depth = 0;
+    ix.leaf0 = 0;
+    return PCPX_OK;
+}
+
+int build_grow_cloud_arrays(Index& ix, u64 n, bool want_copy)
+{
+    int st = grow_arrays(ix, n, 0, want_copy);
+    if (st != PCPX_OK) return st;
+    if (!ix.d_scalars && (st = dev_alloc(ix.d_scalars, SCALARS, &ix.pool)) != PCPX_OK) return st;
+    return PCPX_OK;
+}
+int build_grow_tree_arrays(Index& ix, u64 m) { return grow_arrays(ix, 0, m, false); }
+
+// Box (unless the caller gave the grid) and one sort word per point; copy_cloud: the index's copy of the input rides on the
+// sweep; d_tile_hist: per-tile counts of the words' top digit for the sort's first pass (or nullptr); d_hist12: points per
+// level-4 cell of the curve (4096 counters, zeroed here; or nullptr).
+int build_box_and_codes(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params, bool copy_cloud, u32* d_tile_hist,
+                        u32* d_hist12)
+{
+    hipStream_t s = ix.stream;
+    const bool use_grid = params && (params->flags & PCPX_BUILD_USE_GRID);
+    // d_scalars: [0, 6) the box in its order-preserving integer form, [6] points outside the grid, [7] the sort's failure
+    // flag, [8, 14) the box
+    float* d_box = reinterpret_cast<float*>(ix.d_scalars + 8);
+    k_build_begin<<<1, 64, 0, s>>>(ix.d_scalars);
+    if (d_hist12) PCPX_HIP(hipMemsetAsync(d_hist12, 0, 4096 * sizeof(u32), s));
+    if (use_grid) {
+        float g[6] = {params->grid_min[0], params->grid_min[1], params->grid_min[2],
+                      params->grid_max[0], params->grid_max[1], params->grid_max[2]};
+        PCPX_HIP(hipMemcpyAsync(d_box, g, sizeof(g), hipMemcpyHostToDevice, s));
+        PCPX_HIP(hipStreamSynchronize(s));  // g is a stack temporary
+    } else if (n > 0) {
+        launch_bbox(d_xyz_src, n, s, ix.d_scalars);
+    }
+    u64 blocks = (n + SORT_TILE_WORDS - 1) / SORT_TILE_WORDS;  // a block takes whole tiles
+    if (blocks > 512) blocks = 512;  // two resident blocks per CU
+    if (blocks < 1) blocks = 1;       // (n = 0: the launch still decodes the box)
+    ix.idx_bits = index_bits_for(n);
+    k_codes<<<static_cast<unsigned>(blocks), CODES_BLOCK, 0, s>>>(d_xyz_src, n, ix.d_scalars, !use_grid, ix.idx_bits, ix.d_codes[0],
+                                                                 copy_cloud ? ix.d_xyz : nullptr, d_tile_hist, d_hist12);
+    return check_hip(hipGetLastError(), "k_codes launch", __FILE__, __LINE__);
+}
+
+// The implicit tree over the sorted words d_codes[1][0 .. nvalid) (their low idx_bits name the points' records in d_rec):
+// leaf records, leaf boxes and the three levels above them in one pass, then up to five levels per launch: real nodes only
+// (+ the padding siblings of the last group of four of a level, the only padding a query can read).
+int build_tree_from_sorted(Index& ix, u32 nvalid)
+{
+    hipStream_t s = ix.stream;
+    ix.n = nvalid;
+    u32 nleaves = (nvalid + LEAF - 1) / LEAF;
+    ix.nleaves = nleaves;
+    int depth = depth_for(nleaves);
+    if (depth > MAXDEPTH) {
+        set_error("pcpx: tree deeper than %d levels", MAXDEPTH);
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    ix.depth = depth;
+    ix.leaf0 = static_cast<u32>(level_start(depth));
+    if (level_start(depth + 1) > ix.nodes_cap) {
+        set_error("pcpx: internal error, node capacity");
+        return PCPX_ERR_INVALID;
+    }
+    if (nleaves == 0) return PCPX_OK;
+    const TreeShape ts{nleaves, depth};
+    const u32 nslots = ts.nwrite(depth) * LEAF;
+    u32 fblocks = (nslots + FILL_SLOTS - 1) / FILL_SLOTS;
+    for (int j = 1; j <= 3 && j <= depth; ++j) {  // a block owns 128 >> 2j nodes of level depth - j
+        const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
+        const u32 need = (ts.nwrite(depth - j) + per_block - 1) / per_block;
+        if (need > fblocks) fblocks = need;
+    }
+    const u32 fgrid = (fblocks + 7u) & ~7u;
+    const bool from_rec = PCPX_BUILD_RECORDS || ix.shard.on;
+    k_fill_leaves<<<fgrid, FILL_BLOCK, 0, s>>>(from_rec ? reinterpret_cast<const float4*>(ix.d_rec) : nullptr, ix.d_xyz, ix.d_codes[1], ix.idx_bits,
+                                                nvalid, ts, fblocks, ix.d_leaves, ix.d_perm, ix.d_nodes);
+    for (int c = depth - 3; c > 0;) {
+        const int levels = c < 5 ? c : 5;
+        u32 ublocks = 1;
+        for (int j = 1; j <= levels; ++j) {
+            const u32 per_block = static_cast<u32>(UPPER_BLOCK) >> (2 * (j - 1));
+            const u32 need = (ts.nwrite(c - j) + per_block - 1) / per_block;
+            if (need > ublocks) ublocks = need;
+        }
+        k_upper_levels<<<ublocks, UPPER_BLOCK, 0, s>>>(ix.d_nodes, ts, c, levels);
+        c -= levels;
+    }
+    return check_hip(hipGetLastError(), "tree kernels", __FILE__, __LINE__);
+}
+
 // d_xyz_src: device pointer to n x 3 floats (copied into the index: the reference containers copy
 // their elements too, linked_kdtree.hpp:107).
 int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params)
@@ -490,104 +674,17 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
                 return PCPX_ERR_INVALID;
             }
     }
+    if (params && (params->flags & PCPX_BUILD_SHARD)) return build_shard_index(ix, d_xyz_src, n, params);
     hipStream_t s = ix.stream;
     ProfileScope prof(ix, PCPX_K_BUILD);
-    if (n > ix.cap || !ix.d_xyz) {
-        // Grow: every new buffer is allocated first and swapped in only when all allocations have succeeded, so a
-        // failure (e.g. out of memory on a 50 M-point rebuild) leaves the handle on its previous, still valid index.
-        PCPX_HIP(hipStreamSynchronize(s));
-        u64 cap = n < 64 ? 64 : n;
-        struct Fresh {
-            float* xyz = nullptr;
-            u64* codes[2] = {nullptr, nullptr};
-            u32* perm = nullptr;
-            float4* rec = nullptr;
-            Leaf* leaves = nullptr;
-            NodeBox* nodes = nullptr;
-            void* sort_tmp = nullptr;
-            bool keep = false;
-            ~Fresh()
-            {
-                if (keep) return;
-                (void)hipFree(xyz);
-                (void)hipFree(codes[0]); (void)hipFree(codes[1]);
-                (void)hipFree(perm);
-                (void)hipFree(rec);
-                (void)hipFree(leaves); (void)hipFree(nodes); (void)hipFree(sort_tmp);
-            }
-        } nw;
-        int st;
-        if ((st = dev_alloc(nw.xyz, cap * 3, &ix.pool)) != PCPX_OK) return st;
-        for (int b = 0; b < 2; ++b)
-            if ((st = dev_alloc(nw.codes[b], cap, &ix.pool)) != PCPX_OK) return st;
-        if ((st = dev_alloc(nw.perm, cap, &ix.pool)) != PCPX_OK) return st;
-        if ((st = dev_alloc(nw.rec, cap, &ix.pool)) != PCPX_OK) return st;
-        u32 nl = static_cast<u32>((cap + LEAF - 1) / LEAF);
-        if ((st = dev_alloc(nw.leaves, nl, &ix.pool)) != PCPX_OK) return st;
-        u64 nodes = level_start(depth_for(nl) + 1);
-        if ((st = dev_alloc(nw.nodes, nodes, &ix.pool)) != PCPX_OK) return st;
-        size_t tb = 0;
-        if ((st = sort_keys_u64(nullptr, tb, nullptr, nullptr, cap, s)) != PCPX_OK) return st;
-        {
-            char* tmp = nullptr;
-            if ((st = dev_alloc(tmp, tb ? tb : 16, &ix.pool)) != PCPX_OK) return st;
-            nw.sort_tmp = tmp;
-        }
-        (void)hipFree(ix.d_xyz);
-        for (int b = 0; b < 2; ++b) {
-            (void)hipFree(ix.d_codes[b]);
-            ix.d_codes[b] = nw.codes[b];
-        }
-        (void)hipFree(ix.d_perm);
-        ix.d_perm = nw.perm;
-        (void)hipFree(ix.d_rec);
-        ix.d_rec = nw.rec;
-        (void)hipFree(ix.d_leaves);
-        (void)hipFree(ix.d_nodes);
-        (void)hipFree(ix.d_sort_tmp);
-        ix.d_xyz = nw.xyz;
-        ix.d_leaves = nw.leaves;
-        ix.d_nodes = nw.nodes;
-        ix.d_sort_tmp = nw.sort_tmp;
-        nw.keep = true;
-        ix.nodes_cap = nodes;
-        ix.sort_tmp_bytes = tb;
-        ix.cap = cap;
-        // the old index is gone: until this build completes the handle holds an empty one
-        ix.n = ix.n_in = 0;
-        ix.nleaves = 0;
-        ix.depth = 0;
-        ix.leaf0 = 0;
-    }
-    if (!ix.d_scalars) {
-        int st;
-        if ((st = dev_alloc(ix.d_scalars, SCALARS, &ix.pool)) != PCPX_OK) return st;
-    }
+    ix.shard.on = false;
+    int st;
+    if ((st = grow_arrays(ix, n, n, true)) != PCPX_OK) return st;
+    if (!ix.d_scalars && (st = dev_alloc(ix.d_scalars, SCALARS, &ix.pool)) != PCPX_OK) return st;
     ix.n_in = n;
     const bool copy_cloud = n > 0 && d_xyz_src != ix.d_xyz;  // (the copy rides on k_codes' sweep over the coordinates)
-
-    // d_scalars: [0, 6) the box in its order-preserving integer form, [6] points outside the grid, [7] the sort's failure
-    // flag, [8, 14) the box
-    float* d_box = reinterpret_cast<float*>(ix.d_scalars + 8);
-    k_build_begin<<<1, 64, 0, s>>>(ix.d_scalars);
-    if (use_grid) {
-        float g[6] = {params->grid_min[0], params->grid_min[1], params->grid_min[2],
-                      params->grid_max[0], params->grid_max[1], params->grid_max[2]};
-        PCPX_HIP(hipMemcpyAsync(d_box, g, sizeof(g), hipMemcpyHostToDevice, s));
-        PCPX_HIP(hipStreamSynchronize(s));  // g is a stack temporary
-    } else if (n > 0) {
-        launch_bbox(d_xyz_src, n, s, ix.d_scalars);
-    }
+    if ((st = build_box_and_codes(ix, d_xyz_src, n, params, copy_cloud, sort_tile_hist_buffer(ix.d_sort_tmp, n), nullptr)) != PCPX_OK) return st;
     u32 nvalid = 0;
-    {
-        u64 blocks = (n + SORT_TILE_WORDS - 1) / SORT_TILE_WORDS;  // a block takes whole tiles
-        if (blocks > 512) blocks = 512;  // two resident blocks per CU
-        if (blocks < 1) blocks = 1;       // (n = 0: the launch still decodes the box)
-        ix.idx_bits = index_bits_for(n);
-        k_codes<<<static_cast<unsigned>(blocks), CODES_BLOCK, 0, s>>>(d_xyz_src, n, ix.d_scalars, !use_grid, ix.idx_bits, ix.d_codes[0],
-                                                                     copy_cloud ? ix.d_xyz : nullptr, sort_tile_hist_buffer(ix.d_sort_tmp, n));
-        PCPX_HIP(hipGetLastError());
-    }
     if (n > 0) {
         size_t tb = ix.sort_tmp_bytes;
         SortPayload pl;
@@ -599,7 +696,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         const bool coarse = params && (params->flags & PCPX_BUILD_COARSE_ORDER);
         pl.adaptive_margin_bits = coarse ? PCPX_BUILD_ADAPTIVE_MARGIN : 0;
         ix.sorted_from_bit = coarse ? 40 : SORT_FIRST_BIT;
-        int st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
+        st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
         if (st != PCPX_OK) return st;
     }
     float hb[8];
@@ -618,50 +715,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
         }
         nvalid = static_cast<u32>(n) - outside;
     }
-    ix.n = nvalid;
-
-    // implicit tree, heap layout
-    u32 nleaves = (nvalid + LEAF - 1) / LEAF;
-    ix.nleaves = nleaves;
-    int depth = depth_for(nleaves);
-    if (depth > MAXDEPTH) {
-        set_error("pcpx: tree deeper than %d levels", MAXDEPTH);
-        return PCPX_ERR_UNSUPPORTED;
-    }
-    ix.depth = depth;
-    ix.leaf0 = static_cast<u32>(level_start(depth));
-    if (level_start(depth + 1) > ix.nodes_cap) {
-        set_error("pcpx: internal error, node capacity");
-        return PCPX_ERR_INVALID;
-    }
-    if (nleaves > 0) {
-        // leaf records, leaf boxes and the three levels above them in one pass, then up to five levels per launch: real
-        // nodes only (+ the padding siblings of the last group of four of a level, the only padding a query can read)
-        const TreeShape ts{nleaves, depth};
-        const u32 nslots = ts.nwrite(depth) * LEAF;
-        u32 fblocks = (nslots + FILL_SLOTS - 1) / FILL_SLOTS;
-        for (int j = 1; j <= 3 && j <= depth; ++j) {  // a block owns 128 >> 2j nodes of level depth - j
-            const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
-            const u32 need = (ts.nwrite(depth - j) + per_block - 1) / per_block;
-            if (need > fblocks) fblocks = need;
-        }
-        const u32 fgrid = (fblocks + 7u) & ~7u;
-        k_fill_leaves<<<fgrid, FILL_BLOCK, 0, s>>>(PCPX_BUILD_RECORDS ? reinterpret_cast<const float4*>(ix.d_rec) : nullptr, ix.d_xyz, ix.d_codes[1], ix.idx_bits,
-                                                    nvalid, ts, fblocks, ix.d_leaves, ix.d_perm, ix.d_nodes);
-        for (int c = depth - 3; c > 0;) {
-            const int levels = c < 5 ? c : 5;
-            u32 ublocks = 1;
-            for (int j = 1; j <= levels; ++j) {
-                const u32 per_block = static_cast<u32>(UPPER_BLOCK) >> (2 * (j - 1));
-                const u32 need = (ts.nwrite(c - j) + per_block - 1) / per_block;
-                if (need > ublocks) ublocks = need;
-            }
-            k_upper_levels<<<ublocks, UPPER_BLOCK, 0, s>>>(ix.d_nodes, ts, c, levels);
-            c -= levels;
-        }
-        PCPX_HIP(hipGetLastError());
-    }
-    return PCPX_OK;
+    return build_tree_from_sorted(ix, nvalid);
 }
 
 }  // namespace pcpx

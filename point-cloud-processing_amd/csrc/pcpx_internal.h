@@ -91,6 +91,11 @@ struct KnnOutputs {
     float* meandist = nullptr;  // rows: mean Euclidean distance to the row's neighbours
     u32 by_position = 0;        // self queries only: 1 = row index = the query's SORTED position instead of its input index (rows
                                 // of a slice of the curve order are then one contiguous piece of every output array)
+    // self queries: only sorted positions [pos_lo, pos_hi) are answered (the other lanes of their groups idle); 0, ~0 = all
+    u32 pos_lo = 0, pos_hi = 0xFFFFFFFFu;
+    u32 pos_bias = 0;           // by_position: row = position + pos_bias (a rank-local index: local -> global curve position)
+    float* tau = nullptr;       // self queries: d2 of the k-th neighbour (+inf: fewer than k found) of sorted position p at [p]
+                                // -- what the coverage check of a rank-local index needs (pcpx_shard.hip)
 };
 
 // Queries of a batch, in curve-sorted order.  For self queries qx == nullptr and the query of
@@ -102,6 +107,7 @@ struct QueryView {
     const u32* row;   // output row of sorted query p
     const u32* seed;  // first leaf of the seed range of group g
     u32 nq;
+    u32 pos_lo = 0, pos_hi = 0xFFFFFFFFu;  // k_range, self ranges: only sorted positions [pos_lo, pos_hi) are answered
 };
 
 // Device allocations that outlive a call: the host-pointer entry points stage through device buffers, and a
@@ -143,7 +149,9 @@ struct Index {
 
     u64 n_in = 0;     // input points
     u64 n = 0;        // inserted points
-    u64 cap = 0;      // capacity (points) of the device buffers
+    u64 cap = 0;      // capacity (points) of the cloud arrays: d_codes[0] (and d_xyz: cap_xyz)
+    u64 cap_xyz = 0;
+    u64 cap_tree = 0; // capacity (points) of the tree arrays: d_codes[1], d_perm, d_rec, d_leaves, d_nodes, d_sort_tmp
     float bbox[6] = {0, 0, 0, 0, 0, 0};
 
     float* d_xyz = nullptr;      // n_in x 3, input order
@@ -184,6 +192,41 @@ struct Index {
     u32 few_epoch = 0;   // launch counter of the latency path (its completion flag carries the epoch)
     int eps_test_mode = 0;  // k_knn's eps-box test: 0 = where it is cheaper (query.hip: eps_box_threshold), 1 = in the compaction, 2 = per candidate
 
+    // ---- rank-local index (PCPX_BUILD_SHARD, pcpx_shard.hip): the tree holds only the points a rank's shard of the curve-sorted
+    // queries can reach -- the CORE (the cells of the curve that hold the shard) and a HALO of cells around it; n, nleaves, the
+    // leaves and the boxes are those of the local tree, n_glob is the size of the whole cloud's index.
+    struct Shard {
+        bool on = false;
+        u32 rank = 0, world = 1;
+        u64 n_glob = 0;              // inserted points of the whole cloud
+        u64 g_first = 0, g_count = 0;  // the shard: global curve positions [g_first, g_first + g_count)
+        u64 core_g0 = 0;             // global curve position of the core's first point ...
+        u64 core_l0 = 0;             // ... and its position in the local tree; the core is contiguous in both orders
+        u64 core_count = 0;
+        u32 halo_cells = 0;          // cells (of the selection grid) the core was dilated by
+        u32 k_hint = 0;
+        bool everything = false;     // the selection covers the whole grid: nothing to verify
+        bool borrowed = false;       // the cloud is read in the caller's array (PCPX_BUILD_BORROW_CLOUD)
+        const float* cloud = nullptr;  // n_in x 3, input order: the index's copy or the caller's array
+        u32* d_sel = nullptr;        // selection bitmap over the cells of the curve at level SHARD_SEL_LEVEL, indexed by curve prefix
+        u32* d_need = nullptr;       // cells a failed coverage check asks for
+        u32* d_grid = nullptr;       // scratch: the selection on the xyz grid (one byte per cell, two buffers)
+        u32* d_hist12 = nullptr;     // points per level-4 cell of the curve (4096), whole cloud
+        u32* d_plan = nullptr;       // device scalars of the plan (see pcpx_shard.hip)
+        u32* d_big = nullptr;        // coverage check: the search boxes too large for one thread
+        u32* d_tile_cnt = nullptr;   // selected words per tile of the codes
+        u64 tile_cap = 0;
+        u64* d_words = nullptr;      // the selected words, compacted in input order (the local sort's input)
+        float* d_tau = nullptr;      // k-th squared distance per local position (coverage check)
+        u32* d_fail = nullptr;       // [0] failed queries of the last check, then their local positions
+        u64 cap_loc = 0;             // capacity (points) of the local arrays
+        // the coverage check of a static index need not be repeated for the same question
+        u32 verified_k = 0;
+        float verified_eps = -1.f;
+        u64 verified_first = 0, verified_count = 0;
+        u64 last_failed = 0, total_failed = 0, enlargements = 0;  // diagnostics
+    } shard;
+
     u64* sorted_codes() const { return d_codes[1]; }
     u32* perm() const { return d_perm; }
     TreeView view() const { return TreeView{d_leaves, d_nodes, nleaves, static_cast<u32>(n), depth, leaf0}; }
@@ -221,6 +264,20 @@ int check_hip(hipError_t e, const char* what, const char* file, int line);
 
 // build.hip
 int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
+// the pieces of build_index that the rank-local build (pcpx_shard.hip) shares with it
+int build_grow_cloud_arrays(Index& ix, u64 n, bool want_copy);           // d_xyz (if want_copy), d_codes[0], d_scalars
+int build_grow_tree_arrays(Index& ix, u64 m);                            // d_codes[1], d_perm, d_rec, d_leaves, d_nodes, d_sort_tmp for m points
+int build_box_and_codes(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params, bool copy_cloud, u32* d_tile_hist,
+                        u32* d_hist12);
+int build_tree_from_sorted(Index& ix, u32 nvalid);                       // leaf records, boxes, levels from d_codes[1] / d_rec
+void free_shard(Index& ix);
+// shard.hip
+int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
+// self queries of a rank-local index: translate the global slice, run, check coverage, enlarge and re-run what failed
+int shard_knn_self(Index& ix, u64 sorted_first, u64 sorted_count, u32 k, float eps, KnnOutputs o);
+int shard_range_count_self(Index& ix, float radius, u64 sorted_first, u64 sorted_count, u32* d_out_cnt);
+int shard_unsupported(const Index& ix, const char* what);
+int shard_perm(Index& ix, u32* d_out_perm, u32* d_out_pos);
 int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6);
 // stable radix sort of 64-bit words by their bits [first_bit, 64) (first_bit a multiple of 8); words that agree on
 // those bits keep their input order.  sort_failure_flag: device word of the temporary storage that the sort sets if its
@@ -231,6 +288,8 @@ struct SortPayload {
     const float* xyz = nullptr;           // n x 3 in the words' input order: with `rec` and `idx_bits`, the first pass moves {x, y, z, index}
     float4* rec = nullptr;                //   of every element to its word's position after that pass and writes that position into the
     int idx_bits = 0;                     //   word's low idx_bits (which held the element's index)
+    const float4* rec_in = nullptr;       // instead of xyz: the elements' records {x, y, z, id} in the words' input order, moved as they are
+                                          //   (a rank-local index: the id is the point's index in the whole cloud, not in the sorted subset)
     u32* tile_hist_ready = nullptr;       // counts of the words' top digit (bits [56, 64)) per tile of SORT_TILE_WORDS consecutive words,
                                           //   [tile][256], if the caller has them already (scanned in place by the sort)
     int adaptive_margin_bits = 0;         // > 0: a bucket (words sharing the top digit) of c words is sorted on ceil((ceil(log2 c) + margin) / 8)
@@ -264,7 +323,7 @@ int launch_range_one(Index& ix, bool aabb, const float* range, u32 cap, u32* out
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt);
 int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx);
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
-                   float* d_out, float* d_evals, float* d_centroids = nullptr, float* d_meandist = nullptr);
+                   float* d_out, float* d_evals, float* d_centroids = nullptr, float* d_meandist = nullptr, u32 row_bias = 0);
 int launch_normal_single(const float* d_xyz, u64 m, float* d_out3, hipStream_t s);
 constexpr u32 NORMAL_ARG_POINTS = 64;  // largest neighbourhood that travels in the kernel arguments (launch_normal_args)
 int launch_normal_args(const float* xyz_host, u32 m, float* out3_pinned, u32* done_flag_pinned, u32 epoch, hipStream_t s);

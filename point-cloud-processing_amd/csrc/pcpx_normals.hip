@@ -10,11 +10,11 @@ namespace {
 __global__ __launch_bounds__(256) void k_normals(const float* __restrict__ xyz, const u32* __restrict__ nbr,
                                                  const u32* __restrict__ cnt, const u32* __restrict__ rowmap, u64 first,
                                                  u64 count, u32 k, float* __restrict__ out, float* __restrict__ evals,
-                                                 float* __restrict__ centroids, float* __restrict__ meandist)
+                                                 float* __restrict__ centroids, float* __restrict__ meandist, u32 row_bias)
 {
     u64 i = blockIdx.x * static_cast<u64>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
-    u64 row = rowmap ? rowmap[first + i] : first + i;
+    u64 row = rowmap ? rowmap[first + i] : static_cast<u32>(static_cast<u32>(first + i) + row_bias);
     u32 n = cnt ? cnt[row] : k;
     const u32* nb = nbr + row * k;
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -167,14 +167,14 @@ int launch_normals_csr(const float* d_xyz, const u64* d_offsets, u64 nrows, floa
 }
 
 int launch_normals(Index& ix, const u32* d_nbr, const u32* d_cnt, const u32* d_rowmap, u64 first, u64 count, u32 k,
-                   float* d_out, float* d_evals, float* d_centroids, float* d_meandist)
+                   float* d_out, float* d_evals, float* d_centroids, float* d_meandist, u32 row_bias)
 {
     if (count == 0) return PCPX_OK;
     ProfileScope prof(ix, PCPX_K_NORMALS);
     hipStream_t s = ix.stream;
-    const float* d_xyz = ix.d_xyz;
+    const float* d_xyz = ix.shard.on ? ix.shard.cloud : ix.d_xyz;  // (rows hold indices into the whole cloud)
     k_normals<<<static_cast<u32>((count + 255) / 256), 256, 0, s>>>(d_xyz, d_nbr, d_cnt, d_rowmap, first, count, k, d_out,
-                                                                     d_evals, d_centroids, d_meandist);
+                                                                     d_evals, d_centroids, d_meandist, row_bias);
     return check_hip(hipGetLastError(), "k_normals launch", __FILE__, __LINE__);
 }
 

@@ -530,7 +530,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     asm volatile("" : "+v"(p_here));  // (opaque: or the lane-only pieces of every address formed from p stay pinned in VGPR pairs across groups)
     const u32 p = p_here;
     const u32 nq = SELF ? t.n : qv.nq;
-    const bool valid = p < nq;
+    // (self queries: only the positions [pos_lo, pos_hi) the caller asked for -- a slice that starts or ends inside a group)
+    const bool valid = p < nq && (!SELF || p - o.pos_lo < o.pos_hi - o.pos_lo);
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (valid) {
         if (SELF) {
@@ -765,10 +766,11 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         // (one statement: v_cmpx .. v_writelane keeps the >= 4 instructions the hardware wants between a vector write of EXEC and a
         //  lane write; nothing here depends on a compiler-inserted wait state)
         u64 saved;
-        u32 ox, oy, oz, otau, owa, owner;
+        u32 ox, oy, oz, otau, owa, owner, which;  // (`which`: m0 as the statement found it, put back at its end: v_writelane takes its lane from m0 when its value is an SGPR -- one scalar operand per vector instruction on gfx9 -- and inline asm must not clobber m0)
         float d, e;
         asm volatile(
-            "s_mov_b64 %[sv], exec\n"
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b32 %[ln], m0\n"
             "1:\n\t"
             "s_ff1_i32_b64 m0, %[todo]\n\t"
             "s_bitset0_b64 %[todo], m0\n\t"
@@ -796,11 +798,12 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             "s_cmp_lg_u64 %[todo], 0\n\t"
             "v_writelane_b32 %[wa], %[sw], m0\n\t"
             "s_cbranch_scc1 1b\n\t"
-            "s_mov_b64 exec, %[sv]"
-            : [sv] "=&s"(saved), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [st] "=&s"(otau), [sw] "=&s"(owa),
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_mov_b32 m0, %[ln]"
+            : [ln] "=&s"(which), [sv] "=&s"(saved), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [st] "=&s"(otau), [sw] "=&s"(owa),
               [d] "=&v"(d), [e] "=&v"(e), [wa] "+v"(wa), [todo] "+s"(todo)
             : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [tau] "v"(tau), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [pos] "v"(posj)
-            : "m0", "vcc", "scc", "memory");
+            : "vcc", "scc", "memory");
     };
     const u32 seed_count = s1 - s0;
     u32 sparse_limit = PCPX_SPARSE_LEAVES;  // 0 in the shell rounds (they also want lo_d2 < d2; a visited leaf has a lane that needs it)
@@ -981,7 +984,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     u32 p_row = g_again * GROUP + lane;
     asm volatile("" : "+v"(p_row));
     u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : qv.row[p_row];
-    if (SELF && o.by_position) row = p_row;
+    if (SELF && o.by_position) row = p_row + o.pos_bias;
+    if (SELF && o.tau) o.tau[p_row] = key_d2(best[KCAP - 1]);  // (+inf when the row holds fewer than k)
     u32 found = 0;
     u32 okmask = 0;
     const u64 ob = static_cast<u64>(row) * k;
@@ -1220,7 +1224,8 @@ __global__ __launch_bounds__(256) void k_assemble(TreeView t, QueryView qv, u32 
     const u32 p = slot0 + i;
     const u32 nq = SELF ? t.n : qv.nq;
     if (p >= nq) return;
-    const u32 row = (SELF && o.by_position) ? p : SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
+    if (SELF && !(p - o.pos_lo < o.pos_hi - o.pos_lo)) return;
+    const u32 row = (SELF && o.by_position) ? p + o.pos_bias : SELF ? t.leaves[p / LEAF].id[p % LEAF] : qv.row[p];
     u64* r = keys + static_cast<u64>(i) * stride;
     u32 found = 0;
     for (u32 j = 0; j < k; ++j) {
@@ -1243,6 +1248,7 @@ __global__ __launch_bounds__(256) void k_assemble(TreeView t, QueryView qv, u32 
         if (o.d2) o.d2[ob + j] = ok ? __uint_as_float(static_cast<u32>(r[j] >> 32)) : std::numeric_limits<float>::infinity();
     }
     if (o.cnt) o.cnt[row] = found;
+    if (SELF && o.tau) o.tau[p] = found == k ? __uint_as_float(static_cast<u32>(r[k - 1] >> 32)) : std::numeric_limits<float>::infinity();
 }
 
 static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 gfirst, u64 gcount, u32 k, float eps,
@@ -1295,8 +1301,11 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
         const u32 kp = (pass + 1 < npass) ? KCAP : k - pass * KCAP;
         int st = prepare_queue(ix);
         if (st != PCPX_OK) return st;
-        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, KnnOutputs{}, mp, ix.d_queue, nullptr);
-        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, KnnOutputs{}, mp, ix.d_queue, nullptr);
+        KnnOutputs range_only;  // (a pass writes keys, not rows; it still answers the asked positions only)
+        range_only.pos_lo = o.pos_lo;
+        range_only.pos_hi = o.pos_hi;
+        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr);
+        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr);
     }
     const u32 n32 = static_cast<u32>(nslots);
     if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
@@ -1309,9 +1318,15 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
         }
         // rows are complete in HBM: PCA normal per row (row order: sorted slots -> rows)
         const u32* rowmap = (self && o.by_position) ? nullptr : self ? ix.perm() : qv.row;
-        return launch_normals(ix, o.idx, o.cnt, rowmap, static_cast<u64>(gf) * GROUP,
-                              (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP < nslots ? (self ? ix.n : qv.nq) - static_cast<u64>(gf) * GROUP : nslots,
-                              k, o.normals, nullptr, o.centroids, o.meandist);
+        u64 first = static_cast<u64>(gf) * GROUP, end = first + nslots;
+        const u64 nq = self ? ix.n : qv.nq;
+        if (end > nq) end = nq;
+        if (self) {
+            if (first < o.pos_lo) first = o.pos_lo;
+            if (end > o.pos_hi) end = o.pos_hi;
+        }
+        if (end <= first) return PCPX_OK;
+        return launch_normals(ix, o.idx, o.cnt, rowmap, first, end - first, k, o.normals, nullptr, o.centroids, o.meandist, o.pos_bias);
     }
     return PCPX_OK;
 }

@@ -30,7 +30,7 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
 {
     const u32 p = g * GROUP + lane;
     const u32 nq = SELF ? t.n : qv.nq;
-    const bool valid = p < nq;
+    const bool valid = p < nq && (!SELF || p - qv.pos_lo < qv.pos_hi - qv.pos_lo);  // (self ranges: only the asked positions)
     float qx = 0.f, qy = 0.f, qz = 0.f;
     u32 row = 0;
     if (valid) {
@@ -92,9 +92,10 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
         const u32 j = lane & 7u;
         const float* rec = reinterpret_cast<const float*>(record);
         const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
-        u32 ox, oy, oz, or2, ocnt, owner;
+        u32 ox, oy, oz, or2, ocnt, owner, which;  // (`which`: m0 as the statement found it, put back at its end: v_writelane takes its lane from m0 when its value is an SGPR -- one scalar operand per vector instruction on gfx9 -- and inline asm must not clobber m0)
         float d, e;
         asm volatile(
+            "s_mov_b32 %[ln], m0\n"
             "1:\n\t"
             "s_ff1_i32_b64 m0, %[todo]\n\t"
             "s_bitset0_b64 %[todo], m0\n\t"
@@ -117,11 +118,12 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
             "s_add_u32 %[sc], %[sc], %[L]\n\t"
             "s_cmp_lg_u64 %[todo], 0\n\t"
             "v_writelane_b32 %[cnt], %[sc], m0\n\t"
-            "s_cbranch_scc1 1b"
-            : [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [sr] "=&s"(or2), [sc] "=&s"(ocnt), [d] "=&v"(d), [e] "=&v"(e),
+            "s_cbranch_scc1 1b\n\t"
+            "s_mov_b32 m0, %[ln]"
+            : [ln] "=&s"(which), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [sr] "=&s"(or2), [sc] "=&s"(ocnt), [d] "=&v"(d), [e] "=&v"(e),
               [cnt] "+v"(cnt), [todo] "+s"(todo)
             : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [r2] "v"(r2), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz)
-            : "m0", "vcc", "scc");
+            : "vcc", "scc");
     };
     // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
     WalkerT<true, sparse_leaves> wk;

@@ -222,6 +222,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_setup(const u32* __rest
             const int lg = c > 1 ? 32 - __builtin_clz(c - 1u) : 0;
             int need = (lg + margin_bits + 7) / 8;
             need = need < 2 ? 2 : need > low ? low : need;
+            // (the last bucket is where the words of points outside the voxel grid go -- all ones above their index bits --, and
+            //  the index counts on every inside word sorting before them: that bucket is always sorted on all of its digits)
+            if (threadIdx.x == RADIX - 1) need = low;
             first = static_cast<u32>(low + 1 - need);
         }
         seg->first_pass[threadIdx.x] = first;
@@ -251,6 +254,7 @@ struct SortPayloadArgs {
     const float* xyz;  // n x 3, element order of the pass's input
     float4* rec;       // out: {x, y, z, bits of the element's index} at the word's new position
     u64 low_mask;      // the word's low bits that hold the element's index (in) / the record's position (out)
+    const float4* rec_in;  // instead of xyz: the elements' records, moved as they are
 };
 
 // One tile's place in the pass.  SEG = false: tile t covers [t * TILE, ...) of the whole array.  SEG = true: the tiles
@@ -460,16 +464,29 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
                 e[u] = k[u] & pl.low_mask;
                 dst[u] = gdelta[digit_of(k[u], shift)] + (j < in_tile ? j : j0);
             }
+            float id[U];
+            if (pl.rec_in) {  // (block-uniform)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                x[u] = pl.xyz[3 * e[u]];
-                y[u] = pl.xyz[3 * e[u] + 1];
-                z[u] = pl.xyz[3 * e[u] + 2];
+                for (int u = 0; u < U; ++u) {
+                    const float4 r = pl.rec_in[e[u]];
+                    x[u] = r.x;
+                    y[u] = r.y;
+                    z[u] = r.z;
+                    id[u] = r.w;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    x[u] = pl.xyz[3 * e[u]];
+                    y[u] = pl.xyz[3 * e[u] + 1];
+                    z[u] = pl.xyz[3 * e[u] + 2];
+                    id[u] = __uint_as_float(static_cast<u32>(e[u]));
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (j0 + u * SORT_BLOCK < in_tile) {
-                    pl.rec[dst[u]] = make_float4(x[u], y[u], z[u], __uint_as_float(static_cast<u32>(e[u])));
+                    pl.rec[dst[u]] = make_float4(x[u], y[u], z[u], id[u]);
                     (godd[digit_of(k[u], shift)] ? kout_odd : kout)[dst[u]] = (k[u] & ~pl.low_mask) | dst[u];
                 }
             }
@@ -637,11 +654,12 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     const u32 grid_seg = static_cast<u32>(L.ntiles_max < resident ? L.ntiles_max : resident);
     // ping-pong between tmp and out so that the LAST pass writes out
     auto dst_of = [&](int j) { return ((passes - 1 - j) & 1) == 0 ? kout : kt; };
-    SortPayloadArgs pl{nullptr, nullptr, 0};
+    SortPayloadArgs pl{nullptr, nullptr, 0, nullptr};
     u64* kdst = dst_of(0);
     u64* kodd = dst_of(1);  // (a bucket whose first bucketed pass is pass q is read there from dst_of(q - 1))
-    if (payload && payload->xyz) {
+    if (payload && (payload->xyz || payload->rec_in)) {
         pl.xyz = payload->xyz;
+        pl.rec_in = payload->rec_in;
         pl.rec = payload->rec;
         pl.low_mask = (1ull << payload->idx_bits) - 1ull;
         k_sort_pass<false, true><<<grid_top, SORT_BLOCK, 0, s>>>(kin, kdst, kodd, n32, static_cast<u32>(ntiles), TOP_SHIFT, 0, nullptr, tile_hist, seg, status, ctl, failed, pl);

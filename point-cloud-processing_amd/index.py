@@ -59,24 +59,29 @@ def estimate_normal(points, device=0):
 class Index:
     """Owns a pcpx_index handle: the device-resident curve-sorted implicit AABB tree."""
 
-    def __init__(self, xyz, voxel_grid=None, device=0, coarse_order=False):
+    def __init__(self, xyz, voxel_grid=None, device=0, coarse_order=False, shard=None, k_hint=0):
         self._lib = _capi.load()
         self._h = C.c_void_p(None)
         self.device = device
         xyz = _f32(xyz, 3)
         self.n_in = len(xyz)
-        p = self._params(voxel_grid, coarse_order)
+        p = self._params(voxel_grid, coarse_order, shard, k_hint)
         check(self._lib.pcpx_index_create(_vp(xyz), len(xyz), p, device, C.byref(self._h)))
 
     @staticmethod
-    def _params(voxel_grid, coarse_order=False):
+    def _params(voxel_grid, coarse_order=False, shard=None, k_hint=0, borrow=False):
         """pcpx_build_params: voxel_grid = the explicit grid (PCPX_BUILD_USE_GRID); coarse_order = PCPX_BUILD_COARSE_ORDER (an index that
-        is rebuilt after a query pass or two: one radix pass fewer on a uniform cloud, same results)."""
-        if voxel_grid is None and not coarse_order:
+        is rebuilt after a query pass or two: one radix pass fewer on a uniform cloud, same results); shard = (rank, world):
+        PCPX_BUILD_SHARD, the rank-local index of the multi-GPU path (k_hint sizes its halo; borrow = PCPX_BUILD_BORROW_CLOUD)."""
+        if voxel_grid is None and not coarse_order and shard is None:
             return None
         p = BuildParams()
         p.struct_size = C.sizeof(BuildParams)
         p.flags = (_capi.PCPX_BUILD_USE_GRID if voxel_grid is not None else 0) | (_capi.PCPX_BUILD_COARSE_ORDER if coarse_order else 0)
+        if shard is not None:
+            p.flags |= _capi.PCPX_BUILD_SHARD | (_capi.PCPX_BUILD_BORROW_CLOUD if borrow else 0)
+            p.shard_rank, p.shard_world = int(shard[0]), int(shard[1])
+            p.shard_k_hint = int(k_hint)
         if voxel_grid is None:
             return C.pointer(p)
         g = np.asarray(voxel_grid, np.float32).reshape(6)
@@ -85,10 +90,17 @@ class Index:
             p.grid_max[a] = float(g[3 + a])
         return C.pointer(p)
 
-    def rebuild(self, xyz, voxel_grid=None, coarse_order=False):
+    def rebuild(self, xyz, voxel_grid=None, coarse_order=False, shard=None, k_hint=0):
         xyz = _f32(xyz, 3)
-        check(self._lib.pcpx_index_rebuild(self._h, _vp(xyz), len(xyz), self._params(voxel_grid, coarse_order)))
+        check(self._lib.pcpx_index_rebuild(self._h, _vp(xyz), len(xyz), self._params(voxel_grid, coarse_order, shard, k_hint)))
         self.n_in = len(xyz)
+
+    def shard_info(self):
+        """A rank-local index described (pcpx_index_shard_info)."""
+        out = (C.c_uint64 * 8)()
+        check(self._lib.pcpx_index_shard_info(self._h, out))
+        names = ["local_points", "core_first", "core_count", "shard_first", "shard_count", "halo_cells", "last_failed", "enlargements"]
+        return {k: int(out[i]) for i, k in enumerate(names)}
 
     def close(self):
         if self._h:
@@ -240,19 +252,27 @@ class Index:
 
     # ---- device-pointer forms (torch tensors / raw pointers), used by bench.py ----
     @classmethod
-    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None, coarse_order=False):
+    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None, coarse_order=False, shard=None, k_hint=0, borrow=False):
         self = cls.__new__(cls)
         self._lib = _capi.load()
         self._h = C.c_void_p(None)
         self.device = device
         self.n_in = n
-        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid, coarse_order), device,
+        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid, coarse_order, shard, k_hint, borrow), device,
                                               C.c_void_p(stream) if stream else None, C.byref(self._h)))
         return self
 
-    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None, coarse_order=False):
-        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid, coarse_order)))
+    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None, coarse_order=False, shard=None, k_hint=0, borrow=False):
+        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid, coarse_order, shard, k_hint, borrow)))
         self.n_in = n
+
+    def knn_self_curve_order_dev(self, k, eps, d_idx, d_cnt, d_d2=None, d_normals=None, first=0, count=_capi.UINT64_MAX):
+        """Rows by curve position (row p = the p-th point of the curve order = input point perm[p], perm_dev)."""
+        check(self._lib.pcpx_knn_self_curve_order_dev(self._h, k, eps, first, count, C.c_void_p(d_idx), C.c_void_p(d_cnt),
+                                                      C.c_void_p(d_d2) if d_d2 else None, C.c_void_p(d_normals) if d_normals else None))
+
+    def perm_dev(self, d_perm=None, d_position_of=None):
+        check(self._lib.pcpx_index_perm_dev(self._h, C.c_void_p(d_perm) if d_perm else None, C.c_void_p(d_position_of) if d_position_of else None))
 
     def knn_self_dev(self, k, eps, d_idx, d_cnt, d_d2=None, first=0, count=_capi.UINT64_MAX):
         check(self._lib.pcpx_knn_self_dev(self._h, k, eps, first, count, C.c_void_p(d_idx), C.c_void_p(d_cnt),

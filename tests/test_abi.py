@@ -48,7 +48,7 @@ def test_header_compiles_as_c(tmp_path):
 
 def test_abi_version_and_shard_range(lib):
     hdr = open(os.path.join(ROOT, "include", "pcpx.h")).read()
-    assert lib.pcpx_abi_version() == int(re.search(r"#define PCPX_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    assert lib.pcpx_abi_version() == int(re.search(r"#define PCPX_ABI_VERSION (\d+)", hdr).group(1)) == 4
     a, b = C.c_uint64(), C.c_uint64()
     n = 10_000_019
     total, prev_end = 0, 0
