@@ -22,8 +22,17 @@ k = 32 for every point -- the rebuild is INSIDE the step there).
 
 Multi-GPU: one process per GPU.  Every rank holds the whole cloud (120 MB; exact kNN needs all
 candidates), computes the bounding box of ITS slice of the input, the per-rank boxes are all-gathered
-with RCCL (24 B per rank, the only collective), every rank builds the same index on the union box and
-answers a contiguous 64-aligned shard of the Morton-sorted queries.  Total work is fixed => "strong".
+with RCCL (24 B per rank, the only collective), and every rank builds a RANK-LOCAL index on the union box
+(PCPX_BUILD_SHARD: curve keys for every point, sort + leaves + boxes only for the cells its contiguous
+64-aligned shard of the curve-sorted queries can reach; results are bit-identical to the whole-cloud
+index, csrc/pcpx_shard.hip) and answers that shard.  Total work is fixed => "strong".
+PCPX_BENCH_REPLICATED=1 makes every rank index the whole cloud instead (rounds 1-3).
+
+The default single-GPU run also reports BASELINE.json's other configs under extra.configs -- each
+measured in a child process of its own, so that the headline kernel's per-launch average stays that of the
+headline workload -- with, for the multi-GPU configs, one rank's share of an 8-rank step timed on this GPU
+for every rank in turn (a PROJECTION of the 8-GPU step, labelled as such), the reference's own benchmark
+shapes (single-query kNN / range latency) and one end-to-end figure through the host-pointer ABI.
 """
 import argparse
 import importlib
@@ -134,9 +143,13 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     d_box = mg.global_grid(d_box.cpu() if rehearse else d_box, dist, world, always=collective)  # the one collective: 24 B per rank over RCCL
     grid = d_box.cpu().numpy()
 
+    streaming = name in STREAMING
+    # N > 1: the rank-local index (PCPX_BUILD_SHARD); the cloud is read in place (PCPX_BUILD_BORROW_CLOUD) when it is rebuilt every step
+    local = world > 1 and os.environ.get("PCPX_BENCH_REPLICATED") != "1"
+    build_kw = dict(voxel_grid=grid, shard=(rank, world), k_hint=k, borrow=streaming) if local else dict(voxel_grid=grid)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=dev.index, stream=stream, voxel_grid=grid)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=dev.index, stream=stream, **build_kw)
     torch.cuda.synchronize()
     first_build_ms = (time.perf_counter() - t0) * 1e3
     assert ix.size() == n
@@ -146,18 +159,18 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)  # rows outside this rank's shard stay 0
     d_nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
 
-    streaming = name in STREAMING
     if streaming:
-        # configs[4]: the cloud moves between iterations (jitter U(-1e-3, 1e-3), seed 45 + it); two jittered
-        # copies alternate so every step rebuilds on coordinates that differ from the previous step's
+        # configs[4]: the cloud moves between iterations (jitter U(-1e-3, 1e-3), seed 45 + it); the cloud and a jittered
+        # copy alternate so every step rebuilds on coordinates that differ from the previous step's
         variants = [d_pts] + [torch.from_numpy(np.clip(pkg.synthetic.jitter(pts, seed + it), grid[:3], grid[3:])).to(dev)
-                              for it in (1, 2)]
+                              for it in (1,)]
         it_no = [0]
+        if not local:
+            build_kw = dict(voxel_grid=grid, coarse_order=True)  # (this index answers one query pass before the next rebuild)
 
         def step():
             it_no[0] += 1
-            # (PCPX_BUILD_COARSE_ORDER: this index answers one query pass before the next rebuild)
-            ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, voxel_grid=grid, coarse_order=True)
+            ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, **build_kw)
             ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
     else:
         def step():
@@ -192,7 +205,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         t0 = time.perf_counter()
         reb = 5
         for _ in range(reb):
-            ix.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid, coarse_order=streaming)
+            ix.rebuild_dev(d_pts.data_ptr(), n, **build_kw)
         torch.cuda.synchronize()
         rebuild_ms = (time.perf_counter() - t0) * 1e3 / reb
 
@@ -211,9 +224,148 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     res = {"n": n, "k": k, "elapsed": elapsed, "range_ms": range_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
            "mqps": n * steps / elapsed / 1e6, "first_build_ms": first_build_ms, "rebuild_ms": rebuild_ms,
            "profile": prof, "shard": (first, count), "pts": pts, "complete": complete,
-           "min_count": int(d_cnt.min().item()) if world == 1 else None}
+           "min_count": int(d_cnt.min().item()) if world == 1 else None, "grid": grid,
+           "local_index": ix.shard_info() if local else None}
     ix.close()
     return res
+
+
+def eighth_shard_projection(pkg, torch, name, pts, grid, steps=3, world=8):
+    """One rank's share of an 8-rank step on THIS GPU, for every rank in turn, with the rank-local index: the step time of the
+    8-GPU job would be the slowest rank's.  A projection (one GPU, no RCCL), labelled so wherever it is quoted."""
+    kind, n, seed, k = WORKLOADS[name]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    streaming = name in STREAMING
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_idx = torch.empty((n, k), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_nrm = None if streaming else torch.empty((n, 3), dtype=torch.float32, device=dev)
+    per_rank, builds, trees = [], [], []
+    ix = None
+    for rank in range(world):
+        kw = dict(voxel_grid=grid, shard=(rank, world), k_hint=k, borrow=streaming)
+        t0 = time.perf_counter()
+        if ix is None:
+            ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=dev.index, stream=stream, **kw)
+        else:
+            ix.rebuild_dev(d_pts.data_ptr(), n, **kw)
+        first, count = pkg.shard_range(n, rank, world)
+
+        def step():
+            if streaming:
+                ix.rebuild_dev(d_pts.data_ptr(), n, **kw)
+                ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
+            else:
+                ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        per_rank.append((time.perf_counter() - t0) * 1e3 / steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ix.rebuild_dev(d_pts.data_ptr(), n, **kw)
+        torch.cuda.synchronize()
+        builds.append((time.perf_counter() - t0) * 1e3 / steps)
+        trees.append(ix.shard_info()["local_points"])
+    ix.close()
+    return {"projection": "one rank's share of an %d-rank step, every rank in turn on this one GPU (rank-local index, no RCCL); not a "
+                          "measurement on %d GPUs" % (world, world),
+            "ms_slowest_rank": round(max(per_rank), 4), "ms_mean_rank": round(sum(per_rank) / world, 4),
+            "rank_local_build_ms_slowest": round(max(builds), 4), "rank_local_tree_points_max": max(trees),
+            "rank_local_tree_fraction_of_cloud": round(max(trees) / n, 4)}
+
+
+def config_child(pkg, name, steps, warmup):
+    """extra.configs[name]: one of BASELINE.json's other configurations, in a process of its own."""
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    res = run_workload(pkg, torch, dist, name, 0, 1, steps, warmup, want_profile=True, side=True)
+    kind, n, seed, k = WORKLOADS[name]
+    streaming = name in STREAMING
+    bytes_per_q = 12 + 4 * k + (0 if streaming else 12)
+    out = {"points": n, "k": k, "mqps": round(res["mqps"], 1), "ms_per_step": round(res["ms_per_step"], 4), "steps": steps,
+           "step": "index rebuild + kNN rows" if streaming else "kNN rows + normals",
+           "index_rebuild_ms": round(res["rebuild_ms"], 4) if res["rebuild_ms"] is not None else None}
+    prof = res["profile"]
+    if prof and prof["knn"][0] > 0:
+        avg_s = prof["knn"][1] / prof["knn"][0] / 1e3
+        out["k_knn_avg_launch_ms"] = round(avg_s * 1e3, 4)
+        out["knn_only_mqps"] = round(n / avg_s / 1e6, 1)
+        out["frac"] = round(n * bytes_per_q / avg_s / HBM_PEAK, 6)
+        out["algorithmic_bytes_per_query"] = bytes_per_q
+    if name != "uniform_1m_k15":
+        out["one_eighth_shard"] = shard_extras(pkg, torch, name, res)
+    print(json.dumps(out), flush=True)
+
+
+def shard_extras(pkg, torch, name, res, steps=3):
+    """The 8-rank projection of a one-GPU run: one rank's share with the rank-local index, and what it makes of the speed-up."""
+    shard = eighth_shard_projection(pkg, torch, name, res["pts"], res["grid"], steps=steps)
+    shard["speedup_projected_8_ranks"] = round(res["ms_per_step"] / shard["ms_slowest_rank"], 2)
+    if name in STREAMING and res["rebuild_ms"] is not None:
+        # the build is inside the step: the ceiling of the 8-rank speed-up if the queries scaled perfectly, with the whole-cloud
+        # build replicated on every rank (rounds 1-3) and with the rank-local build
+        q_ms = res["ms_per_step"] - res["rebuild_ms"]
+        shard["amdahl_ceiling_8_ranks_build_in_step"] = round(res["ms_per_step"] / (q_ms / 8.0 + shard["rank_local_build_ms_slowest"]), 2)
+        shard["amdahl_ceiling_8_ranks_replicated_build_in_step"] = round(res["ms_per_step"] / (q_ms / 8.0 + res["rebuild_ms"]), 2)
+    return shard
+
+
+def end_to_end_child(pkg, name):
+    """H2D of the cloud + index build + fused kNN + normals + D2H of rows and normals, through the
+    host-pointer ABI (what a caller of the drop-in headers pays from a cold host array to results on the host); best of 3."""
+    import ctypes as C
+    capi = importlib.import_module("point-cloud-processing_amd._capi")
+    lib = capi.load()
+    kind, n, seed, k = WORKLOADS[name]
+    pts = make_cloud(pkg, kind, n, seed)
+    nrm = np.zeros((n, 3), np.float32)
+    idx = np.zeros((n, k), np.uint32)
+    cnt = np.zeros(n, np.uint32)
+    pos = np.zeros(n, np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = {}
+    for form in ("input_order", "curve_order"):
+        best = None
+        for rep in range(4):
+            h = C.c_void_p(None)
+            t0 = time.perf_counter()
+            capi.check(lib.pcpx_index_create(vp(pts), n, None, 0, C.byref(h)))
+            t1 = time.perf_counter()
+            if form == "input_order":
+                capi.check(lib.pcpx_normals_knn_self(h, k, 1e-5, vp(nrm), vp(idx), vp(cnt)))
+            else:
+                capi.check(lib.pcpx_normals_knn_self_curve_order(h, k, 1e-5, vp(nrm), vp(idx), vp(cnt), None, vp(pos)))
+            t2 = time.perf_counter()
+            lib.pcpx_index_destroy(h)
+            t3 = time.perf_counter()
+            if rep and (best is None or t3 - t0 < best[0]):
+                best = (t3 - t0, t1 - t0, t2 - t1)
+        out[form] = {"total_ms": round(best[0] * 1e3, 3), "create_from_host_ms": round(best[1] * 1e3, 3), "query_to_host_ms": round(best[2] * 1e3, 3),
+                     "mqps": round(n / best[0] / 1e6, 1)}
+    out["workload"] = name
+    out["what"] = "pcpx_index_create(host xyz) + pcpx_normals_knn_self[_curve_order](host normals, rows, counts) + pcpx_index_destroy; pageable host memory"
+    print(json.dumps(out), flush=True)
+
+
+def latency_child():
+    """The reference's own benchmark shapes (benchmark/spatial_data_structures_benchmark.cpp:108-148, :169-213, :243-264: one
+    operation per iteration) through the drop-in C++ headers: tools/latency_bench.cpp, 2^20 points."""
+    import subprocess
+    pkg_dir = os.path.join(ROOT, "point-cloud-processing_amd")
+    exe = "/tmp/pcpx_latency_bench_%d" % os.getpid()
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "latency_bench.cpp"), "-o", exe,
+                    "-L", pkg_dir, "-lpcpx", "-Wl,-rpath," + pkg_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-pthread"], check=True, timeout=120)
+    r = subprocess.run([exe, str(1 << 20), "2000"], capture_output=True, text=True, check=True, timeout=200)
+    os.unlink(exe)
+    print(r.stdout.strip().splitlines()[-1], flush=True)
 
 
 def host_api_rates(pkg, pts, k):
@@ -276,6 +428,15 @@ def main():
                     help="skip the side measurements (rebuild, range count, host-pointer ABI rates, normal evidence): the "
                          "process then launches nothing but the timed steps, which is what the profiling scripts want")
     ap.add_argument("--host-api-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--config-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--end-to-end-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--latency-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--shard-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--base-ms", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--base-rebuild-ms", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip extra.configs (BASELINE.json's other configurations, the latency shapes and the end-to-end figure, each "
+                         "in a child process: about two minutes)")
     ap.add_argument("--with-range-consumers", action="store_true",
                     help="also run tools/filter_bench.py (bilateral filter, WLOP: extras outside the hot path) and report it under extra")
     ap.add_argument("--with-1m", action="store_true",
@@ -285,6 +446,21 @@ def main():
     args = ap.parse_args()
 
     pkg = importlib.import_module("point-cloud-processing_amd")
+    if args.config_child:
+        return config_child(pkg, args.config_child, 3 if args.config_child in STREAMING else 10, 2)
+    if args.end_to_end_child:
+        return end_to_end_child(pkg, args.workload)
+    if args.latency_child:
+        return latency_child()
+    if args.shard_child:
+        import torch
+        torch.cuda.set_device(0)
+        kind, n, seed, k = WORKLOADS[args.workload]
+        pts = make_cloud(pkg, kind, n, seed)
+        res = {"pts": pts, "grid": np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32), "ms_per_step": args.base_ms,
+               "rebuild_ms": args.base_rebuild_ms if args.workload in STREAMING else None}
+        print(json.dumps(shard_extras(pkg, torch, args.workload, res, steps=3 if args.workload in STREAMING else 5)), flush=True)
+        return
     if args.host_api_child:
         # The host-pointer ABI side measurement runs in a process of its own (started by the main run below): its k_knn
         # launches follow 2-14 ms of copy each, the GPU clocks sag in between (5.6-6.3 ms per launch against 5.2 back to
@@ -335,9 +511,11 @@ def main():
                                    "frac": round(30 * n / (reb * 1e-3) / HBM_PEAK, 5)}
         # replicated build inside the step (configs[4]): Amdahl ceiling of the 8-rank speed-up from this rank's numbers
         q_ms = main_res["ms_per_step"] - (reb if args.workload in STREAMING else 0.0)
-        extra["amdahl_ceiling_8_ranks_build_in_step"] = round((q_ms + reb) / (q_ms / 8.0 + reb), 2)
+        extra["amdahl_ceiling_8_ranks_replicated_build_in_step"] = round((q_ms + reb) / (q_ms / 8.0 + reb), 2)  # (rounds 1-3; see one_eighth_shard)
     if main_res["min_count"] is not None:
         extra["min_neighbours_found"] = main_res["min_count"]
+    if main_res["local_index"]:
+        extra["rank_local_index_of_rank0"] = main_res["local_index"]
     extra["rows_with_k_neighbours_all_ranks"] = main_res["complete"]  # = points when the shards cover the cloud exactly once
     if rehearse:
         extra["rehearsal"] = "one GPU, gloo: functional check of the N > 1 path, not a measurement"
@@ -405,6 +583,44 @@ def main():
             except Exception as e:
                 extra["range_consumers_error"] = repr(e)[:200]
 
+    if rank == 0 and world == 1 and side and not args.no_configs and args.workload == "uniform_10m_k15":
+        import subprocess
+        me = [sys.executable, os.path.abspath(__file__)]
+        configs = {}
+
+        def child(key, argv, timeout):
+            t0 = time.perf_counter()
+            try:
+                c = subprocess.run(me + argv, capture_output=True, text=True, timeout=timeout)
+                configs[key] = json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
+            except Exception as e:  # a side measurement must not take the bench line down
+                configs[key] = {"error": repr(e)[:200]}
+            configs[key]["child_wall_s"] = round(time.perf_counter() - t0, 1)
+
+        child("uniform_1m_k15", ["--config-child", "uniform_1m_k15"], 120)            # configs[1]
+        child("clustered_10m_k15", ["--config-child", "clustered_10m_k15"], 200)      # configs[3]'s cloud: one GPU + one rank's share of 8
+        child("uniform_50m_k32_stream", ["--config-child", "uniform_50m_k32_stream"], 300)  # configs[4]: one GPU + one rank's share of 8
+        child("single_operation_latency_2^20_points", ["--latency-child"], 300)
+        child("end_to_end_host_abi", ["--end-to-end-child", "--workload", args.workload], 200)
+        extra["configs"] = configs
+        e2e = configs.get("end_to_end_host_abi", {})
+        if "curve_order" in e2e:
+            extra["end_to_end_mqps"] = e2e["curve_order"]["mqps"]
+
+    if rank == 0 and world == 1 and side and args.workload != "uniform_1m_k15":
+        # one rank's share of an 8-rank step of THIS workload (a projection; the driver's SCALE run is the measurement), in a
+        # process of its own like the other side measurements (its short k_knn launches would blur this process's average)
+        import subprocess
+        try:
+            c = subprocess.run([sys.executable, os.path.abspath(__file__), "--shard-child", "--workload", args.workload, "--base-ms",
+                                repr(main_res["ms_per_step"]), "--base-rebuild-ms", repr(main_res["rebuild_ms"] or 0.0)],
+                               capture_output=True, text=True, timeout=400)
+            extra["one_eighth_shard"] = json.loads([l for l in c.stdout.splitlines() if l.startswith("{")][-1])
+            if "amdahl_ceiling_8_ranks_build_in_step" in extra["one_eighth_shard"]:
+                extra["amdahl_ceiling_8_ranks_build_in_step"] = extra["one_eighth_shard"]["amdahl_ceiling_8_ranks_build_in_step"]
+        except Exception as e:
+            extra["one_eighth_shard"] = {"error": repr(e)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(main_res["pts"], k)
@@ -419,7 +635,8 @@ def main():
                 "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": args.workload, "points": n, "queries": n, "k": k,
-                           "parallelism": "replicated index, curve-sorted query shards x%d, bbox all-gather (RCCL)" % world},
+                           "parallelism": ("replicated cloud, rank-local index, curve-sorted query shards x%d, bbox all-gather (RCCL)" if main_res["local_index"]
+                                            else "replicated index, curve-sorted query shards x%d, bbox all-gather (RCCL)") % world},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

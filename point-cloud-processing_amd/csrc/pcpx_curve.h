@@ -129,7 +129,7 @@ __device__ __forceinline__ void hilbert_table_to_lds(u32* lds_tab)
 struct CurveGrid {
     float lo[3], scale[3];
 };
-__device__ __forceinline__ CurveGrid curve_grid(float b0, float b1, float b2, float b3, float b4, float b5)
+__host__ __device__ __forceinline__ CurveGrid curve_grid(float b0, float b1, float b2, float b3, float b4, float b5)
 {
     CurveGrid g;
     const float lo[3] = {b0, b1, b2}, hi[3] = {b3, b4, b5};
@@ -141,34 +141,34 @@ __device__ __forceinline__ CurveGrid curve_grid(float b0, float b1, float b2, fl
     }
     return g;
 }
-__device__ __forceinline__ u32 curve_cell(float v, float lo, float scale)
+__host__ __device__ __forceinline__ u32 curve_cell(float v, float lo, float scale)
 {
     const float t = fminf(fmaxf((v - lo) * scale, 0.f), static_cast<float>((1 << CURVE_BITS) - 1));
     return static_cast<u32>(t);
 }
 
 // curve key (bits [25, 64)) of a point on the grid g
-__device__ __forceinline__ u64 curve_key(float x, float y, float z, const CurveGrid& g, const u32* __restrict__ lds_tab)
+__host__ __device__ __forceinline__ u64 curve_key(float x, float y, float z, const CurveGrid& g, const u32* __restrict__ lds_tab)
 {
     return hilbert_index_table(curve_cell(x, g.lo[0], g.scale[0]), curve_cell(y, g.lo[1], g.scale[1]), curve_cell(z, g.lo[2], g.scale[2]), lds_tab)
            << CURVE_FIRST_BIT;
 }
 // the same for a point the index inserts: never the all-ones pattern above the word's index bits, which marks a point
 // outside the grid
-__device__ __forceinline__ u64 curve_key_inside(float x, float y, float z, const CurveGrid& g, const u32* __restrict__ lds_tab, int idx_bits)
+__host__ __device__ __forceinline__ u64 curve_key_inside(float x, float y, float z, const CurveGrid& g, const u32* __restrict__ lds_tab, int idx_bits)
 {
     const u64 hmax = ((1ull << (3 * CURVE_BITS)) - 1ull) - (idx_bits >= CURVE_FIRST_BIT ? (1ull << (idx_bits - CURVE_FIRST_BIT)) : 0ull);
     const u64 h = hilbert_index_table(curve_cell(x, g.lo[0], g.scale[0]), curve_cell(y, g.lo[1], g.scale[1]), curve_cell(z, g.lo[2], g.scale[2]), lds_tab);
     return (h < hmax ? h : hmax) << CURVE_FIRST_BIT;
 }
 // the sort word of element `index`: its key with the low idx_bits replaced by the index
-__device__ __forceinline__ u64 sort_word(u64 key, u64 index, int idx_bits)
+__host__ __device__ __forceinline__ u64 sort_word(u64 key, u64 index, int idx_bits)
 {
     const u64 low = (1ull << idx_bits) - 1ull;
     return (key & ~low) | index;
 }
 // the word of an element outside the grid (or NaN): greater than every inserted point's word
-__device__ __forceinline__ u64 outside_word(u64 index, int idx_bits) { return (~0ull << idx_bits) | index; }
+__host__ __device__ __forceinline__ u64 outside_word(u64 index, int idx_bits) { return (~0ull << idx_bits) | index; }
 
 }  // namespace pcpx
 

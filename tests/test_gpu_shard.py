@@ -353,3 +353,23 @@ def test_config5_cloud_rank_local_indexes_bit_for_bit(pkg, oracle):
     t = torch.from_numpy(sel).to(dev)
     oi, oc, od = oracle.knn_bruteforce(pts, pts[sel], k, nthreads=16, want_d2=True)
     _assert_rows_exact(pts, pts[sel], k, sidx[t].cpu().numpy().view(np.uint32), scnt[t].cpu().numpy().view(np.uint32), sd2[t].cpu().numpy(), oi, oc, od)
+
+
+def test_the_host_build_of_the_sort_word_orders_points_like_the_device(pkg):
+    """tests/test_multirank_cpu.py cuts its shards in the order of csrc/pcpx_curve.h compiled for the host: that order is the
+    device's (pcpx_index_perm_dev), points outside the grid included."""
+    torch = _torch()
+    from test_multirank_cpu import _curve_order
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4)
+    pts = np.concatenate([pkg.synthetic.clustered_cloud(300_000, 9), rng.uniform(-0.3, 1.3, (20_000, 3)).astype(np.float32)])
+    pts = pts[rng.permutation(len(pts))]
+    grid = np.array([0, 0, 0, 1, 1, 1], np.float32)
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), len(pts), voxel_grid=grid)
+    perm = torch.empty(ix.size(), dtype=torch.int32, device=dev)
+    ix.perm_dev(perm.data_ptr(), None)
+    ix.synchronize()
+    order, words = _curve_order(pts, grid)
+    assert np.array_equal(perm.cpu().numpy().view(np.uint32), order[: ix.size()].astype(np.uint32))
+    ix.close()
