@@ -395,7 +395,18 @@ class device_index_t
         if (!r.count.empty())
             check(pcpx_normals_from_knn(h_, r.idx.data(), r.count.data(), r.count.size(), r.k, nrm.data(), nullptr),
                   "pcpx_normals_from_knn");
-        return nrm;
+        if (r.position_of.empty()) return nrm;
+        // rows in curve order (knn_self): normal i of the result belongs to input point i, like r.row(i)
+        std::vector<float> by_input(r.position_of.size() * 3, 0.f);
+        for (std::size_t i = 0; i < r.position_of.size(); ++i)
+        {
+            std::size_t const row = r.position_of[i];
+            if (row >= r.count.size()) continue;  // a point outside the voxel grid has no row
+            by_input[3 * i]     = nrm[3 * row];
+            by_input[3 * i + 1] = nrm[3 * row + 1];
+            by_input[3 * i + 2] = nrm[3 * row + 2];
+        }
+        return by_input;
     }
 
     pcpx_index* handle() const { return h_; }

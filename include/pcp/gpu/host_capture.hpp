@@ -1,0 +1,123 @@
+// pcp/gpu/host_capture.hpp -- host-side helpers of the container constructors: the coordinate buffer that feeds the device
+// index, and a chunked std::thread loop for evaluating a property map over a large element range.
+//
+// The reference's constructors walk the range once on one thread (include/pcp/octree/linked_octree.hpp:83-121,
+// include/pcp/kdtree/linked_kdtree.hpp:100-135) because they build a pointer tree while they walk.  Here the walk only
+// evaluates the property map and stores three floats per element -- the tree is built on the GPU in about a millisecond -- so
+// the walk itself was the whole construction time (round 3: 233-286 ms of a 2^24-point construction).  It is split over the
+// host's cores; property maps are pure functions of the element (the reference itself calls them from PSTL worker threads,
+// include/pcp/algorithm/estimate_normals.hpp:92).
+#ifndef PCP_GPU_HOST_CAPTURE_HPP
+#define PCP_GPU_HOST_CAPTURE_HPP
+
+#include <cstddef>
+#include <memory>
+#include <new>
+#include <thread>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace pcp {
+namespace gpu {
+
+// std::allocator whose value-less construct() default-initialises: resize() of a vector<float, ...> does not write zeros over
+// memory that the capture threads are about to fill (a 2^24-point cloud: 200 MB, first touched by the threads that fill it).
+template <class T>
+struct default_init_allocator : std::allocator<T>
+{
+    using std::allocator<T>::allocator;
+    template <class U>
+    struct rebind
+    {
+        using other = default_init_allocator<U>;
+    };
+    template <class U, class... Args>
+    void construct(U* p, Args&&... args)
+    {
+        if constexpr (sizeof...(Args) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
+
+// Element types whose copies the capture threads may construct in place, each in its own piece of the container's storage:
+// a copy cannot throw half way through the range and an element that was never constructed needs no destructor.
+template <class T>
+constexpr bool constructible_in_pieces = std::is_nothrow_copy_constructible_v<T> && std::is_trivially_destructible_v<T>;
+
+// Allocator of the containers' element storage.  For such element types the value-less construct() that resize() calls does
+// NOTHING: resize(size() + n) only claims n slots, and the caller constructs every one of them (placement new, on several
+// threads) before anything reads them.  A single thread copying a 2^24-element range into fresh memory spends most of its time
+// in page faults; the pieces are first touched by the threads that fill them instead.  For any other element type this is
+// std::allocator and the containers copy the range with vector::insert.
+template <class T>
+struct piecewise_allocator : std::allocator<T>
+{
+    using std::allocator<T>::allocator;
+    template <class U>
+    struct rebind
+    {
+        using other = piecewise_allocator<U>;
+    };
+    template <class U, class... Args>
+    void construct(U* p, Args&&... args)
+    {
+        if constexpr (sizeof...(Args) == 0 && constructible_in_pieces<U>) (void)p;
+        else ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <class T>
+using element_storage_t = std::vector<T, piecewise_allocator<T>>;
+
+// n x 3 floats, point i at [3 i, 3 i + 3): what pcpx_index_create / pcpx_index_rebuild read
+using coord_buffer_t = std::vector<float, default_init_allocator<float>>;
+
+// ranges shorter than this are walked on the calling thread
+constexpr std::size_t parallel_capture_threshold = 32768;
+
+inline unsigned capture_threads(std::size_t n)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    if (hw > 32) hw = 32;
+    std::size_t const by_size = n / (parallel_capture_threshold / 2);
+    return by_size < 2 ? 1u : (by_size < hw ? static_cast<unsigned>(by_size) : hw);
+}
+
+// f(first, last, chunk) for `chunks` contiguous pieces of [0, n), chunk 0 on the calling thread after `meanwhile()` has run
+// there (work that overlaps the others' pieces), the rest on threads of their own; returns when all are done.
+template <class F, class G>
+inline void parallel_chunks(std::size_t n, unsigned chunks, F&& f, G&& meanwhile)
+{
+    if (chunks <= 1)
+    {
+        meanwhile();
+        f(std::size_t{0}, n, 0u);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(chunks - 1);
+    auto piece = [n, chunks](unsigned c) { return static_cast<std::size_t>((static_cast<unsigned long long>(n) * c) / chunks); };
+    unsigned started = 1;  // chunks [1, started) have a thread
+    try
+    {
+        for (; started < chunks; ++started) pool.emplace_back([&f, piece, c = started] { f(piece(c), piece(c + 1), c); });
+    }
+    catch (...)  // no more threads to be had: the calling thread takes the pieces that are left
+    {
+    }
+    meanwhile();
+    f(piece(0), piece(1), 0u);
+    for (unsigned c = started; c < chunks; ++c) f(piece(c), piece(c + 1), c);
+    for (auto& t : pool) t.join();
+}
+template <class F>
+inline void parallel_chunks(std::size_t n, unsigned chunks, F&& f)
+{
+    parallel_chunks(n, chunks, std::forward<F>(f), [] {});
+}
+
+} // namespace gpu
+} // namespace pcp
+
+#endif

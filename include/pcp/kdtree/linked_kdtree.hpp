@@ -16,10 +16,14 @@
 #include "pcp/common/axis_aligned_bounding_box.hpp"
 #include "pcp/common/sphere.hpp"
 #include "pcp/gpu/device_index.hpp"
+#include "pcp/gpu/host_capture.hpp"
 
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <iterator>
+#include <limits>
+#include <new>
 #include <memory>
 #include <mutex>
 #include <type_traits>
@@ -57,28 +61,72 @@ class basic_linked_kdtree_t
     using coordinates_type = std::invoke_result_t<CoordinateMap, Element>;
     using coordinate_type  = typename coordinates_type::value_type;
     using aabb_type        = kd_axis_aligned_bounding_box_t<coordinate_type, K>;
-    using iterator         = typename std::vector<element_type>::iterator;
-    using const_iterator   = typename std::vector<element_type>::const_iterator;
+    using iterator         = typename gpu::element_storage_t<element_type>::iterator;
+    using const_iterator   = typename gpu::element_storage_t<element_type>::const_iterator;
     using value_type       = element_type;
     using reference        = value_type&;
     using const_reference  = value_type const&;
-    using size_type        = typename std::vector<element_type>::size_type;
+    using size_type        = typename gpu::element_storage_t<element_type>::size_type;
 
     template <class ForwardIter>
     basic_linked_kdtree_t(ForwardIter begin, ForwardIter end, CoordinateMap coordinate_map = CoordinateMap{},
                           kdtree::construction_params_t params = kdtree::construction_params_t{})
-        : storage_(begin, end), coordinate_map_(coordinate_map), params_(params)
+        : coordinate_map_(coordinate_map), params_(params)
     {
-        xyz_.reserve(storage_.size() * 3);
-        for (auto const& e : storage_)
+        // One walk gives the stored copies of the elements, the device's coordinates and the bounding box (kd_bounding_box's
+        // box: +-max to start with, strict comparisons -- the box of the pieces' boxes is the same box), on several threads
+        // when the range is large (pcp/gpu/host_capture.hpp).
+        constexpr bool random_access =
+            std::is_base_of_v<std::random_access_iterator_tag, typename std::iterator_traits<ForwardIter>::iterator_category>;
+        bool copied = false;
+        if constexpr (random_access && gpu::constructible_in_pieces<element_type>)
         {
-            auto const c = coordinate_map_(e);
-            xyz_.push_back(axis(c, 0));
-            xyz_.push_back(axis(c, 1));
-            xyz_.push_back(axis(c, 2));
+            std::size_t const count = static_cast<std::size_t>(end - begin);
+            if (count >= gpu::parallel_capture_threshold)
+            {
+                storage_.resize(count);  // claims the slots; the pieces below construct every one
+                using diff_t = typename std::iterator_traits<ForwardIter>::difference_type;
+                gpu::parallel_chunks(count, gpu::capture_threads(count), [&](std::size_t first, std::size_t last, unsigned) {
+                    ForwardIter it = begin + static_cast<diff_t>(first);
+                    for (std::size_t i = first; i < last; ++i, ++it) ::new (static_cast<void*>(storage_.data() + i)) element_type(*it);
+                });
+                copied = true;
+            }
         }
-        aabb_ = kd_bounding_box<coordinate_type, K, CoordinateMap, const_iterator>(storage_.cbegin(), storage_.cend(),
-                                                                                  coordinate_map_);
+        if (!copied) storage_.assign(begin, end);
+        std::size_t const n = storage_.size();
+        xyz_.resize(3 * n);
+        unsigned const pieces = n >= gpu::parallel_capture_threshold ? gpu::capture_threads(n) : 1u;
+        aabb_type none;
+        for (std::size_t a = 0; a < K; ++a)
+        {
+            none.min[a] = std::numeric_limits<coordinate_type>::max();
+            none.max[a] = std::numeric_limits<coordinate_type>::lowest();
+        }
+        std::vector<aabb_type> part(pieces, none);
+        gpu::parallel_chunks(n, pieces, [&](std::size_t first, std::size_t last, unsigned piece) {
+            aabb_type b = none;
+            for (std::size_t i = first; i < last; ++i)
+            {
+                auto const c   = coordinate_map_(storage_[i]);
+                xyz_[3 * i]     = axis(c, 0);
+                xyz_[3 * i + 1] = axis(c, 1);
+                xyz_[3 * i + 2] = axis(c, 2);
+                for (std::size_t a = 0; a < K; ++a)
+                {
+                    if (c[a] < b.min[a]) b.min[a] = c[a];
+                    if (c[a] > b.max[a]) b.max[a] = c[a];
+                }
+            }
+            part[piece] = b;
+        });
+        aabb_ = none;
+        for (auto const& b : part)
+            for (std::size_t a = 0; a < K; ++a)
+            {
+                if (b.min[a] < aabb_.min[a]) aabb_.min[a] = b.min[a];
+                if (b.max[a] > aabb_.max[a]) aabb_.max[a] = b.max[a];
+            }
     }
     basic_linked_kdtree_t(self_type&&) = default;
     self_type& operator=(self_type&&) = default;
@@ -175,7 +223,7 @@ class basic_linked_kdtree_t
         if (!index_.valid()) index_.build(xyz_.data(), storage_.size());
         return index_;
     }
-    std::vector<float> const& coordinates() const { return xyz_; }
+    gpu::coord_buffer_t const& coordinates() const { return xyz_; }
     element_type const& element(std::size_t i) const { return storage_[i]; }
     CoordinateMap const& coordinate_map() const { return coordinate_map_; }
 
@@ -188,8 +236,8 @@ class basic_linked_kdtree_t
         return out;
     }
 
-    std::vector<element_type> storage_;
-    std::vector<float> xyz_;
+    gpu::element_storage_t<element_type> storage_;
+    gpu::coord_buffer_t xyz_;  // element i of storage_ at [3 i, 3 i + 3)
     CoordinateMap coordinate_map_;
     kdtree::construction_params_t params_;
     aabb_type aabb_{};

@@ -22,6 +22,7 @@
 #include "pcp/common/points/point.hpp"
 #include "pcp/common/sphere.hpp"
 #include "pcp/gpu/device_index.hpp"
+#include "pcp/gpu/host_capture.hpp"
 
 #include <array>
 #include <cassert>
@@ -58,8 +59,8 @@ class basic_linked_octree_t
     using value_type      = element_type;
     using reference       = value_type&;
     using const_reference = value_type const&;
-    using iterator        = typename std::vector<element_type>::iterator;
-    using const_iterator  = typename std::vector<element_type>::const_iterator;
+    using iterator        = typename gpu::element_storage_t<element_type>::iterator;
+    using const_iterator  = typename gpu::element_storage_t<element_type>::const_iterator;
     using self_type       = basic_linked_octree_t<element_type, params_type>;
 
     basic_linked_octree_t(self_type&&) = default;
@@ -84,17 +85,40 @@ class basic_linked_octree_t
         T const hi = std::numeric_limits<T>::max(), lo = std::numeric_limits<T>::lowest();
         params_.voxel_grid.min = aabb_point_type{hi, hi, hi};
         params_.voxel_grid.max = aabb_point_type{lo, lo, lo};
-        for (ForwardIter it = begin; it != end; ++it)
+        auto const widen = [&point_view](aabb_type& b, ForwardIter first, ForwardIter last) {
+            for (ForwardIter it = first; it != last; ++it)
+            {
+                auto const p = point_view(*it);
+                if (p.x() < b.min.x()) b.min.x(p.x());
+                if (p.y() < b.min.y()) b.min.y(p.y());
+                if (p.z() < b.min.z()) b.min.z(p.z());
+                if (p.x() > b.max.x()) b.max.x(p.x());
+                if (p.y() > b.max.y()) b.max.y(p.y());
+                if (p.z() > b.max.z()) b.max.z(p.z());
+            }
+        };
+        if constexpr (is_random_access<ForwardIter>)
         {
-            auto const p = point_view(*it);
-            auto& b      = params_.voxel_grid;
-            if (p.x() < b.min.x()) b.min.x(p.x());
-            if (p.y() < b.min.y()) b.min.y(p.y());
-            if (p.z() < b.min.z()) b.min.z(p.z());
-            if (p.x() > b.max.x()) b.max.x(p.x());
-            if (p.y() > b.max.y()) b.max.y(p.y());
-            if (p.z() > b.max.z()) b.max.z(p.z());
+            // the box of a range is the box of its pieces' boxes (min / max by strict comparison: the same box in any order)
+            std::size_t const n   = static_cast<std::size_t>(end - begin);
+            unsigned const pieces = gpu::capture_threads(n);
+            std::vector<aabb_type> part(pieces, params_.voxel_grid);
+            gpu::parallel_chunks(n, pieces, [&](std::size_t a, std::size_t b, unsigned c) {
+                using diff_t = typename std::iterator_traits<ForwardIter>::difference_type;
+                widen(part[c], begin + static_cast<diff_t>(a), begin + static_cast<diff_t>(b));
+            });
+            for (auto const& pb : part)
+            {
+                auto& b = params_.voxel_grid;
+                if (pb.min.x() < b.min.x()) b.min.x(pb.min.x());
+                if (pb.min.y() < b.min.y()) b.min.y(pb.min.y());
+                if (pb.min.z() < b.min.z()) b.min.z(pb.min.z());
+                if (pb.max.x() > b.max.x()) b.max.x(pb.max.x());
+                if (pb.max.y() > b.max.y()) b.max.y(pb.max.y());
+                if (pb.max.z() > b.max.z()) b.max.z(pb.max.z());
+            }
         }
+        else widen(params_.voxel_grid, begin, end);
         insert(begin, end, point_view);
     }
 
@@ -118,6 +142,11 @@ class basic_linked_octree_t
     template <class ForwardIter, class PointViewMap>
     std::size_t insert(ForwardIter begin, ForwardIter end, PointViewMap const& point_view)
     {
+        if constexpr (is_random_access<ForwardIter>)
+        {
+            std::size_t const n = static_cast<std::size_t>(end - begin);
+            if (n >= gpu::parallel_capture_threshold) return insert_many(begin, n, point_view);
+        }
         std::size_t inserted = 0;
         for (; begin != end; ++begin) inserted += insert(*begin, point_view) ? 1u : 0u;
         return inserted;
@@ -247,10 +276,74 @@ class basic_linked_octree_t
         }
         return index_;
     }
-    std::vector<float> const& coordinates() const { return xyz_; }
+    gpu::coord_buffer_t const& coordinates() const { return xyz_; }
     element_type const& element(std::size_t i) const { return elements_[i]; }
 
   private:
+    template <class Iter>
+    static constexpr bool is_random_access =
+        std::is_base_of_v<std::random_access_iterator_tag, typename std::iterator_traits<Iter>::iterator_category>;
+
+    // insert(begin, begin + n) for a large random-access range: the property map is evaluated and the coordinates are stored
+    // by several threads, each on a contiguous piece, while the calling thread copies the elements; the result is what the
+    // one-by-one loop gives (elements in range order, those outside the voxel grid skipped).
+    template <class RandomIter, class PointViewMap>
+    std::size_t insert_many(RandomIter begin, std::size_t n, PointViewMap const& point_view)
+    {
+        using diff_t = typename std::iterator_traits<RandomIter>::difference_type;
+        if (!point_of_)
+            point_of_ = [point_view](element_type const& el) {
+                auto const q = point_view(el);
+                return std::array<float, 3>{static_cast<float>(q.x()), static_cast<float>(q.y()), static_cast<float>(q.z())};
+            };
+        std::size_t const old = elements_.size();
+        xyz_.resize(3 * (old + n));  // (default-initialised: the pieces below are first touched by the threads that fill them)
+        constexpr bool in_pieces = gpu::constructible_in_pieces<element_type>;
+        if constexpr (in_pieces) elements_.resize(old + n);  // claims the slots; every one is constructed below
+        [[maybe_unused]] element_type* const slot = elements_.data() + old;
+        unsigned const pieces = gpu::capture_threads(n);
+        std::vector<std::vector<std::size_t>> outside(pieces);  // per piece: offsets of the points outside the grid, ascending
+        auto const& grid = params_.voxel_grid;
+        float* const dst = xyz_.data() + 3 * old;
+        gpu::parallel_chunks(
+            n, pieces,
+            [&](std::size_t a, std::size_t b, unsigned c) {
+                RandomIter it = begin + static_cast<diff_t>(a);
+                for (std::size_t i = a; i < b; ++i, ++it)
+                {
+                    if constexpr (in_pieces) ::new (static_cast<void*>(slot + i)) element_type(*it);
+                    auto const p = point_view(*it);
+                    if (!grid.contains(p)) outside[c].push_back(i);
+                    dst[3 * i]     = static_cast<float>(p.x());
+                    dst[3 * i + 1] = static_cast<float>(p.y());
+                    dst[3 * i + 2] = static_cast<float>(p.z());
+                }
+            },
+            [&] {
+                if constexpr (!in_pieces) elements_.insert(elements_.end(), begin, begin + static_cast<diff_t>(n));
+            });
+        dirty_ = true;
+        std::vector<std::size_t> drop;
+        for (auto const& o : outside) drop.insert(drop.end(), o.begin(), o.end());
+        if (drop.empty()) return n;
+        // some points lie outside the grid: close the gaps (elements and coordinates alike), in range order
+        std::size_t w = drop[0];
+        for (std::size_t d = 0; d < drop.size(); ++d)
+        {
+            std::size_t const next = d + 1 < drop.size() ? drop[d + 1] : n;
+            for (std::size_t i = drop[d] + 1; i < next; ++i, ++w)
+            {
+                elements_[old + w] = std::move(elements_[old + i]);
+                dst[3 * w]         = dst[3 * i];
+                dst[3 * w + 1]     = dst[3 * i + 1];
+                dst[3 * w + 2]     = dst[3 * i + 2];
+            }
+        }
+        elements_.erase(elements_.begin() + static_cast<std::ptrdiff_t>(old + w), elements_.end());
+        xyz_.resize(3 * (old + w));
+        return w;
+    }
+
     void check_params() const
     {
         assert(params_.node_capacity > 0u);
@@ -265,8 +358,8 @@ class basic_linked_octree_t
     }
 
     params_type params_{};
-    std::vector<element_type> elements_;
-    std::vector<float> xyz_;
+    gpu::element_storage_t<element_type> elements_;
+    gpu::coord_buffer_t xyz_;  // point i of elements_ at [3 i, 3 i + 3)
     std::function<std::array<float, 3>(element_type const&)> point_of_;
     mutable gpu::device_index_t index_;
     mutable bool dirty_ = true;

@@ -167,6 +167,12 @@ int pcpx_range_count_self(pcpx_index* idx, float radius, uint32_t* out_count);
 int pcpx_range_count_batch(pcpx_index* idx, const float* q_xyz, uint64_t nq, float radius, uint32_t* out_count);
 int pcpx_range_count_self_dev(pcpx_index* idx, float radius, uint64_t sorted_first, uint64_t sorted_count,
                               uint32_t* d_out_count);
+/* The same with the count of the p-th point of the curve order at d_out_count[p] (positions of the whole cloud's order; rows of
+ * a slice are one contiguous piece, written 256 bytes per query group; pcpx_index_perm_dev gives the order).  Additive: the
+ * reference returns results per element (include/pcp/octree/linked_octree.hpp:264-276); a consumer that reduces the counts
+ * (examples/filter_point_cloud_noise_by_density.cpp:81-90 thresholds them) does not care about their order. */
+int pcpx_range_count_self_curve_order_dev(pcpx_index* idx, float radius, uint64_t sorted_first, uint64_t sorted_count,
+                                          uint32_t* d_out_count);
 /* Lists, CSR: out_offsets has nq+1 entries; out_idx receives offsets[nq] indices.  If idx_capacity is
  * too small (or out_idx is NULL) the offsets are still filled and PCPX_ERR_CAPACITY is returned, so
  * the caller can allocate offsets[nq] entries and call again. */

@@ -797,6 +797,29 @@ int pcpx_range_count_self_dev(pcpx_index* h, float radius, uint64_t sorted_first
     return launch_range_count(*ix, qv, true, gf, gc, radius, nullptr, d_out_count);
 }
 
+// The same with the count of sorted position p at d_out_count[p]: a query group's 64 counts are one 256-byte store (the
+// input-order form scatters 4-byte stores over the whole array: eight times the bytes at the memory side).
+int pcpx_range_count_self_curve_order_dev(pcpx_index* h, float radius, uint64_t sorted_first, uint64_t sorted_count,
+                                          uint32_t* d_out_count)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    if (!d_out_count) return PCPX_ERR_INVALID;
+    if (sorted_first % GROUP != 0) {
+        set_error("pcpx_range_count_self_curve_order_dev: sorted_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
+    }
+    if (ix->shard.on) return shard_range_count_self(*ix, radius, sorted_first, sorted_count, d_out_count, true);
+    u64 gf, gc;
+    slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    qv.by_position = 1;
+    return launch_range_count(*ix, qv, true, gf, gc, radius, nullptr, d_out_count);
+}
+
 int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
@@ -1137,6 +1160,17 @@ int pcpx_normals_knn_self_curve_order(pcpx_index* h, uint32_t k, float eps, floa
                 if (e[i]) (void)hipEventDestroy(e[i]);
         }
     } guard{done};
+    // Whatever way this function is left -- an error half way through included -- both streams are drained first: queued
+    // kernels and copies write the caller's arrays and read buffers that go back to the pool (declared last: destroyed first,
+    // before the events and the buffers above).
+    struct Drain {
+        Index* ix;
+        ~Drain()
+        {
+            (void)hipStreamSynchronize(ix->copy_stream);
+            (void)hipStreamSynchronize(ix->stream);
+        }
+    } drain{ix};
     // all the kernels first (enqueueing does not block) ...
     u64 g_first[MAX_SLICES + 1];
     for (int s = 0; s <= slices; ++s) g_first[s] = groups * static_cast<u64>(s) / static_cast<u64>(slices);

@@ -108,6 +108,8 @@ struct QueryView {
     const u32* seed;  // first leaf of the seed range of group g
     u32 nq;
     u32 pos_lo = 0, pos_hi = 0xFFFFFFFFu;  // k_range, self ranges: only sorted positions [pos_lo, pos_hi) are answered
+    u32 by_position = 0, pos_bias = 0;     // k_range, self counts: 1 = the count of sorted position p goes to [p + pos_bias] (one
+                                           // contiguous 256-B store per query group) instead of to the point's input index
 };
 
 // Device allocations that outlive a call: the host-pointer entry points stage through device buffers, and a
@@ -275,7 +277,7 @@ void free_shard(Index& ix);
 int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
 // self queries of a rank-local index: translate the global slice, run, check coverage, enlarge and re-run what failed
 int shard_knn_self(Index& ix, u64 sorted_first, u64 sorted_count, u32 k, float eps, KnnOutputs o);
-int shard_range_count_self(Index& ix, float radius, u64 sorted_first, u64 sorted_count, u32* d_out_cnt);
+int shard_range_count_self(Index& ix, float radius, u64 sorted_first, u64 sorted_count, u32* d_out_cnt, bool by_position = false);
 int shard_unsupported(const Index& ix, const char* what);
 int shard_perm(Index& ix, u32* d_out_perm, u32* d_out_pos);
 int device_bbox(const float* d_xyz, u64 n, hipStream_t s, u32* d_enc6, float* d_out6);

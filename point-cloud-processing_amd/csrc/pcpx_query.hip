@@ -160,6 +160,16 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_SPARSE_LEAVES
 #define PCPX_SPARSE_LEAVES 3
 #endif
+#ifndef PCPX_PACKED_LEAVES
+#define PCPX_PACKED_LEAVES 24  // a walk leaf that 2 ... this many lanes need is looked at eight needing lanes x eight points at a time (0: off)
+#endif
+#ifndef PCPX_PACKED_FREE
+#define PCPX_PACKED_FREE 3  // free rows every needing lane has when a packed leaf starts (a key that finds none waits for a fold)
+#endif
+#ifndef PCPX_KNN_WPB16
+#define PCPX_KNN_WPB16 4  // waves per workgroup of the k <= 16 kernel: its 11 rows x 512 B per wave fill the LDS allocation granule
+                          // (1280 B) only in fours -- 7 waves per SIMD need <= 5851 B per wave
+#endif
 #ifndef PCPX_COMPACT_TIER4
 #define PCPX_COMPACT_TIER4 8  // largest KCAP whose compaction has a four-key tier (k <= 8: +2 %; k <= 16: the branch costs the kernel
                               // scratch at 7 waves per SIMD and nothing at 6; k <= 32: no difference)
@@ -170,10 +180,20 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 // rows of LDS per wave: the C++ accept path (multi-pass kernels only) stores rejected keys to a trash row, row BUF;
 // the exec-masked path stores nothing for a rejected candidate
 // (single-pass kernels: at least kcap / 2 rows -- after the search the column holds the row's kcap sorted positions, two per row)
+// The packed leaf form (knn_group: packed_leaf) publishes the needing lanes' queries in rows of their own behind the buffer: 20 B per
+// needing lane.  The kernels that have it: single-pass, k <= 16 and k <= 32 (the k <= 8 kernel has no LDS to spare at 8 waves per SIMD).
+__host__ __device__ constexpr int pack_rows(bool multi, int kcap)
+{
+    return (PCPX_PACKED_LEAVES > 0 && PCPX_ASM_ACCEPT && !multi && kcap >= 16) ? (PCPX_PACKED_LEAVES * 20 + 511) / 512 : 0;
+}
 __host__ __device__ constexpr int lds_rows(int buf, bool multi, int kcap = 0)
 {
-    return (buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0)) > kcap / 2 ? (buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0)) : kcap / 2;
+    return (buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0) + pack_rows(multi, kcap)) > kcap / 2
+               ? (buf + ((multi || !PCPX_ASM_ACCEPT) ? 1 : 0) + pack_rows(multi, kcap))
+               : kcap / 2;
 }
+// waves per workgroup (every wave works alone; the workgroup only shares an LDS allocation)
+__host__ __device__ constexpr int knn_wpb(int kcap, bool multi) { return (!multi && kcap == 16 && pack_rows(multi, kcap) > 0) ? PCPX_KNN_WPB16 : WAVES_PER_BLOCK; }
 __host__ __device__ constexpr int buf_rows(int kcap) { return kcap <= 8 ? PCPX_BUF8 : kcap <= 16 ? PCPX_BUF16 : PCPX_BUF32; }
 
 // Fold this lane's buffered keys (cnt <= BUF <= 16) into its sorted best-list.  All LDS traffic is
@@ -221,6 +241,7 @@ __device__ __forceinline__ void static_for(F&& f)
 #ifndef PCPX_DEFER_EPS
 #define PCPX_DEFER_EPS 1
 #endif
+static_assert(!PCPX_DEFER_EPS || (PCPX_COMPACT_BY8 && PCPX_BY8_K32), "the deferred eps-box test lives in the chunk-of-8 compaction: compact() has none");
 struct EpsFilter {
     bool on;
     float thr, eps, qx, qy, qz;
@@ -506,7 +527,7 @@ struct MultiPass {
 template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH, int NZ>
 __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k_arg, const float eps,
                                           const float eps_thr, const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
-                                          u64* __restrict__ col, const u32 lane)
+                                          u64* __restrict__ col, float* __restrict__ pub, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
     // k is made opaque per group: everything derived from it alone -- the initial best-list (slots below KCAP - k hold 0, the
@@ -572,6 +593,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // wa with a wave-uniform bound: no per-lane threshold register
     const u32 lds_row0 = __builtin_amdgcn_readfirstlane(col_addr) - 8u * __builtin_amdgcn_readfirstlane(lane);
     const u32 wa_full = lds_row0 + (static_cast<u32>(BUF - LEAF + 1) << 9);  // wa >= this: a leaf might not fit any more
+    const u32 wa_end = lds_row0 + (static_cast<u32>(BUF) << 9);               // a key address >= this: beyond the column's last row
+    const u32 wa_packed_full = lds_row0 + (static_cast<u32>(BUF - PCPX_PACKED_FREE + 1) << 9);  // packed_leaf: fewer than PCPX_PACKED_FREE free rows
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
     // single-pass kernels: the eps-box test waits for the compaction, unless the launcher picked the EPS_EACH form (launch_knn_t)
@@ -751,7 +774,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     tau = active ? fminf(tau, cap) : -1.f;
 
     // ---- walk rounds ----
-    constexpr bool sparse_leaves = PCPX_SPARSE_LEAVES > 0 && fast && !EPS_EACH;
+    constexpr bool sparse_leaves = (PCPX_SPARSE_LEAVES > 0 || pack_rows(MULTI, KCAP) > 0) && fast && !EPS_EACH;  // the leaf forms that want the need masks
     WalkerT<(KCAP > 8), sparse_leaves> wk;
     // A leaf that at most PCPX_SPARSE_LEAVES lanes need (a third of the walk's leaves are needed by <= 3 of the 64) is looked at
     // the other way round: lane j < 8 holds point j of the leaf, and for each needing lane in turn the eight distances to ITS
@@ -805,8 +828,69 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [tau] "v"(tau), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [pos] "v"(posj)
             : "vcc", "scc", "memory");
     };
+    // A leaf that more lanes than that but at most PCPX_PACKED_LEAVES need (half of the walk's leaves: the lane-per-query form
+    // computes 512 distances there of which 32 ... 128 matter) is looked at EIGHT NEEDING LANES x EIGHT POINTS at a time: the
+    // needing lanes publish {query, tau} and their write address in LDS in the order of their rank (v_mbcnt of the need mask);
+    // lane 8 i + j then forms the distance from the i-th published query to point j of the leaf, and a lane whose point is
+    // within that query's tau takes the next row of the query's column with a returning LDS add on the published address and
+    // writes the key there; at the end each needing lane reads its address back.  ~10 vector instructions per eight needing
+    // lanes (+ ~8 per leaf) against 91 per leaf.  Same keys, same arithmetic (d = p - q, three roundings), same tau as the
+    // other forms; the order of a column's new keys is whatever order the adds were served in, which no result depends on
+    // (keys are distinct and the selection network sorts them).
+    constexpr bool packed_leaves = pack_rows(MULTI, KCAP) > 0 && fast && !EPS_EACH;
+    // The buffer is filled OPTIMISTICALLY here: a leaf is started as soon as every needing lane has PCPX_PACKED_FREE free rows
+    // (the other forms want LEAF = 8: any lane may take every point), and a key whose add comes back with an address beyond the
+    // column's last row is not written -- the step reports those lanes, the caller folds the buffers and calls again from that
+    // step for those lanes only.  In the walk a lane takes one key of a leaf it needs, rarely three: waiting for eight free rows
+    // of ten meant a fold (the whole selection network, for all 64 lanes) per 19 keys of the WAVE.
+    // Returns 0 when the leaf is done, else the lanes of step `s` whose keys are still to be written.
+    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many, u32& s, u64 only) -> u64 {
+        float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
+        u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
+        u32 lane_here = lane;
+        asm volatile("" : "+v"(lane_here));  // (or everything below that depends on the lane alone sits in registers from group to group)
+        const u32 j = lane_here & 7u, i = lane_here >> 3;
+        const float* rec = reinterpret_cast<const float*>(t.leaves + leaf);
+        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        const u32 posj = leaf * LEAF + j;
+        const u32 r = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(who >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(who), 0u));
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(who);
+        if (mine) {
+            pub_q[r] = make_float4(qx, qy, qz, tau);
+            pub_wa[r] = wa;
+        }
+        __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
+        u64 unwritten = 0;  // (wave-uniform, like everything that steers this loop: the ballot is taken where every lane is active)
+        for (; s < how_many; s += 8u) {
+            const u32 left = how_many - s;                                           // queries of this step: lanes 0 .. 8 * left - 1
+            const u64 in_step = left >= 8u ? ~0ull : ((1ull << (8u * left)) - 1ull);
+            const float4 q = pub_q[s + i];  // (lanes beyond the step's queries: stale bytes of the row, masked by in_step)
+            const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
+            const float d2 = sq3(dx, dy, dz);
+            const u64 within = __builtin_amdgcn_ballot_w64(d2 <= q.w) & in_step & only;  // NaN padding points fail d2 <= tau
+            only = ~0ull;
+            bool no_room = false;
+            if (__builtin_amdgcn_inverse_ballot_w64(within)) {
+                u32 one_row = 512u;
+                asm volatile("" : "+v"(one_row));  // (a v_mov here, not a register held from group to group)
+                const u32 at = atomicAdd(pub_wa + s + i, one_row);
+                no_room = at >= wa_end;  // (a lane's column starts below lds_row0 + 512: "row >= BUF" is a comparison with a wave-uniform bound)
+                if (!no_room) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(at), "v"(posj), "v"(d2) : "memory");
+            }
+            unwritten = __builtin_amdgcn_ballot_w64(no_room);
+            if (unwritten != 0) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mine) {
+            const u32 now = pub_wa[r];
+            wa = now < col_addr + (static_cast<u32>(BUF) << 9) ? now : col_addr + (static_cast<u32>(BUF) << 9);  // (adds that did not fit moved it on too)
+        }
+        __builtin_amdgcn_wave_barrier();
+        return unwritten;
+    };
     const u32 seed_count = s1 - s0;
     u32 sparse_limit = PCPX_SPARSE_LEAVES;  // 0 in the shell rounds (they also want lo_d2 < d2; a visited leaf has a lane that needs it)
+    u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;
     for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
@@ -838,10 +922,27 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                             : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
                             : "scc");
                         // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
-                        // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
-                        if (PCPX_FOLD_FOR_NEEDERS ? (__builtin_amdgcn_ballot_w64(wa >= wa_full) & who) != 0 : any_lane(wa >= wa_full)) fold(false);
-                        if (how_many <= sparse_limit) {
-                            const u32 wa_was = wa;
+                        // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more
+                        // (packed_leaf: PCPX_PACKED_FREE more -- and again whenever it comes back with keys that found no room).
+                        const bool packed_form = packed_leaves && how_many <= packed_limit && how_many > sparse_limit;
+                        const u32 wa_was = wa;
+                        u32 step = 0;
+                        u64 only = ~0ull;
+                        for (bool again = false;; again = true) {
+                            const u32 full = packed_form ? wa_packed_full : wa_full;
+                            if (again || (PCPX_FOLD_FOR_NEEDERS ? (__builtin_amdgcn_ballot_w64(wa >= full) & who) != 0 : any_lane(wa >= full))) fold(false);
+                            if (!packed_form) break;
+                            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
+                            only = packed_leaf(loc, who, how_many, step, only);
+                            if (STATS) {
+                                asm volatile("" ::"v"(wa));
+                                tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
+                            }
+                            if (only == 0) break;
+                        }
+                        if (packed_form) {
+                            if (STATS) ++st_leaves, st_app += (wa - wa_was) >> 9;  // (a fold in between: not counted exactly)
+                        } else if (how_many <= sparse_limit) {
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                             sparse_leaf(loc, who);
                             if (STATS) {
@@ -875,6 +976,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         const float grown = cap * PCPX_CAP_GROW;
         ++rounds;
         sparse_limit = 0;
+        packed_limit = 0;
         cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
         active = failed;
         tau = active ? fminf(kth, cap) : -1.f;
@@ -1076,7 +1178,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
 template <int KCAP, bool SELF, bool STATS, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS, int NZ = 0>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
+__global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
     TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, float eps_thr, KnnOutputs o, MultiPass mp,
     u32* __restrict__ queue, unsigned long long* __restrict__ stats)
 {
@@ -1084,7 +1186,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
     extern __shared__ u64 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = wave_in_block();
-    u64* col = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI, MULTI ? 0 : KCAP) * 64 + lane;
+    u64* const rows = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI, MULTI ? 0 : KCAP) * 64;  // this wave's rows
+    u64* col = rows + lane;
+    float* pub = reinterpret_cast<float*>(rows + BUF * 64);  // packed_leaf's rows (pack_rows), behind the buffer's
     if (PCPX_COMPACT_BY8 && !MULTI && (KCAP <= 16 || PCPX_BY8_K32)) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
         const u64 pad = pad_key_here();
 #pragma unroll
@@ -1110,7 +1214,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
                 tg = __builtin_amdgcn_s_memrealtime();
                 tcg = __builtin_amdgcn_s_memtime();
             }
-            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, qv, group_first + qbeg + gi, k, eps, eps_thr, o, mp, stats, col, lane);
+            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, qv, group_first + qbeg + gi, k, eps, eps_thr, o, mp, stats, col, pub, lane);
             if (STATS) {
                 if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
                 ++n_done;
@@ -1132,14 +1236,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, KCAP <= 8 ? PCPX_MINW8 : KCAP
 }
 
 // number of workgroups that are resident at once (occupancy API x CUs), never more than there is work
-u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups)
+u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups, int wpb)
 {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds) != hipSuccess || per_cu < 1) per_cu = 8;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix.device) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
     u64 want = static_cast<u64>(per_cu) * cus;
-    u64 need = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    u64 need = (groups + wpb - 1) / wpb;
     // (tried for short launches -- one rank's eighth of the queries is 2.7 groups per resident wave and ends with a tail:
     //  fewer waves so that each gets >= 3 / 4 / 6 groups: 0.776 -> 0.795 / 0.862 / 0.925 ms per 1.25 M queries; the full
     //  resident grid stays)
@@ -1185,14 +1289,15 @@ template <int KCAP, bool SELF, bool EPS_EACH, int NZ>
 static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcount, u32 k, float eps, float thr, const KnnOutputs& o)
 {
     constexpr int BUF = buf_rows(KCAP);
-    const size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
+    constexpr int WPB = knn_wpb(KCAP, false);
+    const size_t lds = static_cast<size_t>(WPB) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
     const u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
     auto* fn = k_knn<KCAP, SELF, false, false, EPS_EACH, NZ>;
-    const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WAVES_PER_BLOCK, lds, gcount);
+    const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WPB, lds, gcount, WPB);
     ProfileScope prof(ix, PCPX_K_KNN);
-    fn<<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr);
+    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr);
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
@@ -1288,7 +1393,7 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
     const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false, true>)
                           : reinterpret_cast<const void*>(k_knn<KCAP, false, false, true>);
-    u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount);
+    u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount, WAVES_PER_BLOCK);
     ProfileScope prof(ix, PCPX_K_KNN);
     for (u32 pass = 0; pass < npass; ++pass) {
         MultiPass mp;
@@ -1348,13 +1453,18 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     constexpr int KCAP = 16, BUF = buf_rows(KCAP);
     u64 groups = (ix.n + GROUP - 1) / GROUP;
     if (groups == 0) return PCPX_OK;
-    size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
+    constexpr int WPB = knn_wpb(KCAP, false);
+    size_t lds = static_cast<size_t>(WPB) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
-    u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WAVES_PER_BLOCK, lds, groups);
-    k_knn<KCAP, true, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), eps_box_threshold(ix, sanitize_eps(eps)),
+    u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WPB, lds, groups, WPB);
+    // (this instantiation is the deferred-eps form whatever the threshold says: a negative one -- "test every candidate" -- becomes
+    //  +inf here, so that every buffered key takes the exact test in the compaction)
+    float thr = eps_box_threshold(ix, sanitize_eps(eps));
+    if (thr < 0.f) thr = std::numeric_limits<float>::infinity();
+    k_knn<KCAP, true, true><<<pgrid, 64 * WPB, lds, ix.stream>>>(
+        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), thr,
         KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats);
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }

@@ -8,6 +8,9 @@
 #ifndef PCPX_RANGE_DIRECT_LEAVES
 #define PCPX_RANGE_DIRECT_LEAVES 1
 #endif
+#ifndef PCPX_RANGE_PACKED_LEAVES
+#define PCPX_RANGE_PACKED_LEAVES 32  // count form: a leaf that at most this many lanes need is counted eight needing lanes x eight points at a time (0: off; <= 32: one 512-B row of LDS per wave)
+#endif
 
 namespace pcpx {
 
@@ -26,7 +29,8 @@ namespace {
 template <bool SELF, bool FILL>
 __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& qv, const u32 g, const float radius,
                                             const float* __restrict__ radii, u32* __restrict__ out_cnt,
-                                            const u64* __restrict__ offsets, u32* __restrict__ out_idx, const u32 lane)
+                                            const u64* __restrict__ offsets, u32* __restrict__ out_idx, float4* __restrict__ pub,
+                                            const u32 lane)
 {
     const u32 p = g * GROUP + lane;
     const u32 nq = SELF ? t.n : qv.nq;
@@ -125,8 +129,36 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
             : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [r2] "v"(r2), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz)
             : "vcc", "scc");
     };
+    // A leaf that more lanes than that but at most PCPX_RANGE_PACKED_LEAVES need is counted EIGHT NEEDING LANES x EIGHT POINTS at a
+    // time (k_knn's packed_leaf, pcpx_query.hip): the needing lanes publish {centre, r^2} in LDS in the order of their rank among
+    // the needing lanes, lane 8 i + j forms the distance from the i-th published centre to point j, and a needing lane adds the
+    // number of set bits of its own byte of the step's ballot -- ~13 vector instructions per eight needing lanes (+ 8 per leaf)
+    // against 88 per leaf in the lane-per-range form.  Same arithmetic (d = p - c, three roundings; sphere.hpp:27-35).
+    constexpr bool packed_leaves = PCPX_RANGE_PACKED_LEAVES > 0 && !FILL;
+    static_assert(PCPX_RANGE_PACKED_LEAVES <= 32, "one row of LDS per wave");
+    auto packed_leaf = [&](const Leaf* record, const u64 who, const u32 how_many) {
+        u32 lane_here = lane;
+        asm volatile("" : "+v"(lane_here));  // (or what depends on the lane alone is kept in registers for the whole walk)
+        const u32 j = lane_here & 7u, i = lane_here >> 3;
+        const float* rec = reinterpret_cast<const float*>(record);
+        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        const u32 rank = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(who >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(who), 0u));
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(who);
+        if (mine) pub[rank] = make_float4(qx, qy, qz, r2);
+        __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
+        const u32 my_byte = (rank & 7u) << 3;
+        for (u32 s = 0; s < how_many; s += 8u) {
+            const u32 left = how_many - s;
+            const u64 in_step = left >= 8u ? ~0ull : ((1ull << (8u * left)) - 1ull);  // lanes 0 .. 8 * left - 1 hold a published centre
+            const float4 q = pub[s + i];
+            const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
+            const u64 inside = __builtin_amdgcn_ballot_w64(sq3(dx, dy, dz) <= q.w) & in_step;  // (a NaN padding point fails)
+            if (mine && rank - s < 8u) cnt += static_cast<u32>(__builtin_popcount(static_cast<u32>(inside >> my_byte) & 0xFFu));
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
-    WalkerT<true, sparse_leaves> wk;
+    WalkerT<true, (sparse_leaves || packed_leaves)> wk;
     u32 nexp = 0;
     if (wk.start(t, need, nexp)) leaf_points(0u);  // the root is the only leaf
     // A last-level node looks at its needed leaves itself (WalkerT::leaves_of) instead of pushing and popping them: the four
@@ -144,8 +176,9 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
             for (int c = 0; c < W; ++c) {
                 if ((needed >> c) & 1u) {
                     u32 how_many = GROUP;
-                    if (sparse_leaves) asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
+                    if (sparse_leaves || packed_leaves) asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
                     if (sparse_leaves && how_many <= static_cast<u32>(PCPX_RANGE_SPARSE_LEAVES)) sparse_leaf(records + c, wk.leaf_need[c]);
+                    else if (packed_leaves && how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c, wk.leaf_need[c], how_many);
                     else leaf_record_points(load_const(records + c));
                 }
             }
@@ -154,7 +187,7 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
             leaf_points(loc);
         }
     }
-    if (valid && !FILL) out_cnt[row] = cnt;
+    if (valid && !FILL) out_cnt[(SELF && qv.by_position) ? p + qv.pos_bias : row] = cnt;
 }
 
 // One single-wave workgroup per group, XCD-aware block order (pcpx_device.h: virtual_block).  (Tried: a persistent grid
@@ -165,10 +198,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, Quer
                                                                const float* __restrict__ radii, u32* __restrict__ out_cnt,
                                                                const u64* __restrict__ offsets, u32* __restrict__ out_idx)
 {
+    __shared__ float4 published[WAVES_PER_BLOCK][FILL ? 1 : 32];  // packed_leaf's row, one per wave
     const u32 lane = threadIdx.x & 63u;
     const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
     if (g >= group_end) return;
-    range_group<SELF, FILL>(t, qv, g, radius, radii, out_cnt, offsets, out_idx, lane);
+    range_group<SELF, FILL>(t, qv, g, radius, radii, out_cnt, offsets, out_idx, published[wave_in_block()], lane);
 }
 
 // AABB ranges: one wave per 64 boxes, no spatial coherence assumed (boxes are few in practice:

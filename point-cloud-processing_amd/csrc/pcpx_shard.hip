@@ -748,7 +748,7 @@ int shard_knn_self(Index& ix, u64 sorted_first, u64 sorted_count, u32 k, float e
 
 // Radius counts around the shard's own points: the halo must reach `radius` from every core cell; if it does not yet, the
 // selection is dilated by what is missing first.
-int shard_range_count_self(Index& ix, float radius, u64 sorted_first, u64 sorted_count, u32* d_out_cnt)
+int shard_range_count_self(Index& ix, float radius, u64 sorted_first, u64 sorted_count, u32* d_out_cnt, bool by_position)
 {
     Index::Shard& sh = ix.shard;
     hipStream_t s = ix.stream;
@@ -792,6 +792,8 @@ int shard_range_count_self(Index& ix, float radius, u64 sorted_first, u64 sorted
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
     qv.pos_lo = a;
     qv.pos_hi = b;
+    qv.by_position = by_position ? 1u : 0u;
+    qv.pos_bias = bias;  // local position + bias = position in the whole cloud's order
     return launch_range_count(ix, qv, true, gf, ge - gf, radius, nullptr, d_out_cnt);
 }
 

@@ -290,6 +290,10 @@ class Index:
     def range_count_self_dev(self, radius, d_cnt, first=0, count=_capi.UINT64_MAX):
         check(self._lib.pcpx_range_count_self_dev(self._h, radius, first, count, C.c_void_p(d_cnt)))
 
+    def range_count_self_curve_order_dev(self, radius, d_cnt, first=0, count=_capi.UINT64_MAX):
+        """Counts at curve positions (d_cnt[p] = count around the p-th point of the index's order; perm_dev gives the order)."""
+        check(self._lib.pcpx_range_count_self_curve_order_dev(self._h, radius, first, count, C.c_void_p(d_cnt)))
+
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 

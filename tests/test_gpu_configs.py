@@ -262,3 +262,68 @@ def test_latency_path_equals_the_general_path(pkg, oracle):
         gi, gc, gd = ix.knn(base[:200], 8, eps=eps, want_d2=True)
         oi, oc, od = oracle.knn_bruteforce(pts, base[:200], 8, eps=eps, nthreads=16, want_d2=True)
         _assert_rows_exact(pts, base[:200], 8, gi, gc, gd, oi, oc, od)
+
+
+@pytest.mark.parametrize("cloud", ["uniform_10m_seed43", "clustered_10m_seed44"])
+def test_contiguous_curve_block_against_the_restated_octree(pkg, oracle, cloud):
+    """BASELINE configs[2] / [3] at full size: ONE CONTIGUOUS block of a million rows of the curve order (what a rank's shard
+    is), not scattered samples, against the oracle's restatement of basic_linked_octree_t (capacity 32, depth 21, auto
+    bounding box; test/octree/octree_knn.cpp:184-254 is the reference's own shape of this check): k = 15 rows row for row,
+    r = 0.01 counts count for count; and every one of the 10 M normals is finite and of unit length
+    (test/algorithm/estimate_normals.cpp:48-64 checks exactly that)."""
+    torch = pytest.importorskip("torch")
+    n, k, block = 10_000_000, 15, 1_000_000
+    dev = torch.device("cuda", 0)
+    pts = pkg.synthetic.uniform_cloud(n, 43) if cloud.startswith("uniform") else pkg.synthetic.clustered_cloud(n, 44)
+    d_pts = torch.from_numpy(pts).to(dev)
+    torch.cuda.synchronize()
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n)
+    d_idx = torch.empty((n, k), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_d2 = torch.empty((n, k), dtype=torch.float32, device=dev)
+    d_nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_rc = torch.empty(n, dtype=torch.int32, device=dev)
+    d_perm = torch.empty(n, dtype=torch.int32, device=dev)
+    ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), d_d2.data_ptr())
+    ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr())
+    ix.range_count_self_dev(0.01, d_rc.data_ptr())
+    ix.perm_dev(d_perm.data_ptr())
+    d_rc_pos = torch.empty(n, dtype=torch.int32, device=dev)
+    ix.range_count_self_curve_order_dev(0.01, d_rc_pos.data_ptr())
+    ix.synchronize()
+    assert torch.equal(d_rc_pos, d_rc[d_perm.long()])  # the counts at curve positions are the same counts
+    del d_rc_pos
+    # every normal: finite, unit length
+    assert bool(torch.isfinite(d_nrm).all())
+    assert float(((d_nrm * d_nrm).sum(1) - 1.0).abs().max()) <= 1e-5
+    # the block: positions [first, first + block) of the curve order, deliberately not aligned to a query group
+    first = 3_333_337
+    ids = d_perm[first:first + block].long()
+    assert int(ids.min()) >= 0 and int(ids.max()) < n and int(torch.unique(ids).numel()) == block
+    gi = d_idx[ids].cpu().numpy().view(np.uint32)
+    gc = d_cnt[ids].cpu().numpy().view(np.uint32)
+    gd = d_d2[ids].cpu().numpy()
+    grc = d_rc[ids].cpu().numpy().view(np.uint32)
+    ids = ids.cpu().numpy()
+    q = pts[ids]
+    tree = oracle.Octree(pts)  # reference defaults
+    assert tree.size() == n
+    oi, oc, od = tree.knn(q, k, nthreads=16, want_d2=True)
+    # counts and distance lists bit for bit; indices equal except inside runs of EXACTLY equal distance, whose order the
+    # reference leaves to its heap (linked_octree_node.hpp:479-489): there the index sets of the run are equal, or -- at the
+    # k-th distance, where the run may be cut -- the returned point really is at that distance
+    assert np.array_equal(gc, oc) and int(oc.min()) == k
+    assert np.array_equal(gd, od)
+    differ = np.nonzero((gi != oi).any(1))[0]
+    assert len(differ) < block // 100
+    for r in differ:
+        for d in np.unique(gd[r][gi[r] != oi[r]]):
+            run = gd[r] == d
+            if d != gd[r, -1]:
+                assert set(gi[r][run].tolist()) == set(oi[r][run].tolist()), "row %d: different points at distance %r" % (r, d)
+            else:
+                e = pts[gi[r][run].astype(np.int64)] - q[r][None, :]
+                assert np.all(((e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2]).astype(np.float32) == d)
+                assert len(set(gi[r].tolist())) == k
+    assert np.array_equal(grc, tree.range_count(q, 0.01, nthreads=16))
+    ix.close()

@@ -181,10 +181,18 @@ def test_rank_local_radius_counts(pkg, oracle):
     grid = np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32)
     d_pts = torch.from_numpy(pts).to(dev)
     ix = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid)
+    d_perm = torch.empty(n, dtype=torch.int32, device=dev)
+    ix.perm_dev(d_perm.data_ptr())
     for radius in (0.004, 0.03, 0.11):  # the last one is far wider than the first halo
         want = torch.zeros(n, dtype=torch.int32, device=dev)
         ix.range_count_self_dev(radius, want.data_ptr())
+        # counts at curve positions (pcpx_range_count_self_curve_order_dev): the same counts, found through the order
+        by_pos = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ix.range_count_self_curve_order_dev(radius, by_pos.data_ptr())
+        ix.synchronize()
+        assert torch.equal(by_pos, want[d_perm.long()])
         got = torch.zeros(n, dtype=torch.int32, device=dev)
+        got_pos = torch.full((n,), -1, dtype=torch.int32, device=dev)
         sx = None
         for rank in range(world):
             kw = dict(voxel_grid=grid, shard=(rank, world), k_hint=8)
@@ -194,10 +202,11 @@ def test_rank_local_radius_counts(pkg, oracle):
                 sx.rebuild_dev(d_pts.data_ptr(), n, **kw)
             first, count = pkg.shard_range(n, rank, world)
             sx.range_count_self_dev(radius, got.data_ptr(), first, count)
+            sx.range_count_self_curve_order_dev(radius, got_pos.data_ptr(), first, count)  # a rank's piece of the whole order
             sx.synchronize()
         sx.close()
         ix.synchronize()
-        assert torch.equal(got, want)
+        assert torch.equal(got, want) and torch.equal(got_pos, by_pos)
         sel = np.random.default_rng(2).integers(0, n, 200)
         assert np.array_equal(got.cpu().numpy().view(np.uint32)[sel], oracle.range_count_bruteforce(pts, pts[sel], radius, nthreads=16))
     ix.close()
