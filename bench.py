@@ -125,7 +125,8 @@ def _reduce(torch, dist, value, op, dev, rehearse):
     return float(t.item())
 
 
-def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profile, rehearse=False, side=True, collective=False):
+def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profile, rehearse=False, side=True, collective=False,
+                 at_curve_positions=False):
     kind, n, seed, k = WORKLOADS[name]
     dev = torch.device("cuda", torch.cuda.current_device())
     pts = make_cloud(pkg, kind, n, seed)
@@ -172,6 +173,9 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
             it_no[0] += 1
             ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, **build_kw)
             ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
+    elif at_curve_positions:  # (--rows-at-curve-positions: the same launch with rows and normals at curve positions; for the counter passes)
+        def step():
+            ix.knn_self_curve_order_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, d_nrm.data_ptr(), first, count)
     else:
         def step():
             ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
@@ -210,7 +214,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         rebuild_ms = (time.perf_counter() - t0) * 1e3 / reb
 
     # config 3 shape on the same cloud: radius count r = 0.01 around every point (device resident)
-    range_ms = None
+    range_ms = range_pos_ms = None
     if side and name == "uniform_10m_k15" and world == 1:
         d_rc = torch.empty(n, dtype=torch.int32, device=dev)
         ix.range_count_self_dev(0.01, d_rc.data_ptr())
@@ -220,8 +224,27 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
             ix.range_count_self_dev(0.01, d_rc.data_ptr())
         torch.cuda.synchronize()
         range_ms = (time.perf_counter() - t0) * 1e3 / 3
+        # the same counts written at curve positions (pcpx_range_count_self_curve_order_dev: one 256-B store per query group)
+        ix.range_count_self_curve_order_dev(0.01, d_rc.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ix.range_count_self_curve_order_dev(0.01, d_rc.data_ptr())
+        torch.cuda.synchronize()
+        range_pos_ms = (time.perf_counter() - t0) * 1e3 / 3
 
-    res = {"n": n, "k": k, "elapsed": elapsed, "range_ms": range_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
+    # the step with rows and normals written at curve positions (pcpx_knn_self_curve_order_dev) instead of input indices
+    rows_pos_ms = None
+    if side and not streaming and world == 1:
+        ix.knn_self_curve_order_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, d_nrm.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ix.knn_self_curve_order_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, d_nrm.data_ptr())
+        torch.cuda.synchronize()
+        rows_pos_ms = (time.perf_counter() - t0) * 1e3 / 5
+
+    res = {"n": n, "k": k, "elapsed": elapsed, "range_ms": range_ms, "range_pos_ms": range_pos_ms, "rows_pos_ms": rows_pos_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
            "mqps": n * steps / elapsed / 1e6, "first_build_ms": first_build_ms, "rebuild_ms": rebuild_ms,
            "profile": prof, "shard": (first, count), "pts": pts, "complete": complete,
            "min_count": int(d_cnt.min().item()) if world == 1 else None, "grid": grid,
@@ -424,6 +447,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="uniform_10m_k15", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows-at-curve-positions", action="store_true",
+                    help="the step writes rows and normals at curve positions (pcpx_knn_self_curve_order_dev) instead of input indices: "
+                         "for counter passes of that form; the default line is the input-order form")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the side measurements (rebuild, range count, host-pointer ABI rates, normal evidence): the "
                          "process then launches nothing but the timed steps, which is what the profiling scripts want")
@@ -497,7 +523,7 @@ def main():
 
     side = not args.no_extra
     main_res = run_workload(pkg, torch, dist, args.workload, rank, world, args.steps, args.warmup, want_profile=True,
-                            rehearse=rehearse, side=side, collective=collective)
+                            rehearse=rehearse, side=side, collective=collective, at_curve_positions=args.rows_at_curve_positions)
     n, k = main_res["n"], main_res["k"]
 
     extra = {"index_build_ms_first": round(main_res["first_build_ms"], 3), "shard_of_rank0": list(main_res["shard"])}
@@ -524,6 +550,11 @@ def main():
     if main_res.get("range_ms"):
         extra["config3_range_count_r0.01_ms"] = round(main_res["range_ms"], 3)
         extra["config3_range_count_r0.01_mqps"] = round(n / main_res["range_ms"] / 1e3, 1)
+    if main_res.get("range_pos_ms"):
+        extra["config3_range_count_r0.01_curve_order_ms"] = round(main_res["range_pos_ms"], 3)
+    if main_res.get("rows_pos_ms"):
+        extra["step_rows_at_curve_positions_ms"] = round(main_res["rows_pos_ms"], 4)
+        extra["step_rows_at_curve_positions_mqps"] = round(n / main_res["rows_pos_ms"] / 1e3, 1)
 
     roofline = None
     prof = main_res["profile"]

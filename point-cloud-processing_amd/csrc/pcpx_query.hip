@@ -157,14 +157,8 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_FOLD_FOR_NEEDERS
 #define PCPX_FOLD_FOR_NEEDERS 1
 #endif
-#ifndef PCPX_SPARSE_LEAVES
-#define PCPX_SPARSE_LEAVES 3
-#endif
 #ifndef PCPX_PACKED_LEAVES
 #define PCPX_PACKED_LEAVES 24  // a walk leaf that 2 ... this many lanes need is looked at eight needing lanes x eight points at a time (0: off)
-#endif
-#ifndef PCPX_PACKED_FREE
-#define PCPX_PACKED_FREE 3  // free rows every needing lane has when a packed leaf starts (a key that finds none waits for a fold)
 #endif
 #ifndef PCPX_KNN_WPB16
 #define PCPX_KNN_WPB16 4  // waves per workgroup of the k <= 16 kernel: its 11 rows x 512 B per wave fill the LDS allocation granule
@@ -593,8 +587,6 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // wa with a wave-uniform bound: no per-lane threshold register
     const u32 lds_row0 = __builtin_amdgcn_readfirstlane(col_addr) - 8u * __builtin_amdgcn_readfirstlane(lane);
     const u32 wa_full = lds_row0 + (static_cast<u32>(BUF - LEAF + 1) << 9);  // wa >= this: a leaf might not fit any more
-    const u32 wa_end = lds_row0 + (static_cast<u32>(BUF) << 9);               // a key address >= this: beyond the column's last row
-    const u32 wa_packed_full = lds_row0 + (static_cast<u32>(BUF - PCPX_PACKED_FREE + 1) << 9);  // packed_leaf: fewer than PCPX_PACKED_FREE free rows
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
     // single-pass kernels: the eps-box test waits for the compaction, unless the launcher picked the EPS_EACH form (launch_knn_t)
@@ -774,62 +766,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     tau = active ? fminf(tau, cap) : -1.f;
 
     // ---- walk rounds ----
-    constexpr bool sparse_leaves = (PCPX_SPARSE_LEAVES > 0 || pack_rows(MULTI, KCAP) > 0) && fast && !EPS_EACH;  // the leaf forms that want the need masks
-    WalkerT<(KCAP > 8), sparse_leaves> wk;
-    // A leaf that at most PCPX_SPARSE_LEAVES lanes need (a third of the walk's leaves are needed by <= 3 of the 64) is looked at
-    // the other way round: lane j < 8 holds point j of the leaf, and for each needing lane in turn the eight distances to ITS
-    // query are formed at once, compared with its tau and appended to its column -- ~18 vector instructions per needing lane
-    // against 91 for the leaf in the lane-per-query form.  (Which lanes: the ballots of the parent's box tests, taken under a
-    // tau that can only have shrunk since.)
-    auto sparse_leaf = [&](const u32 leaf, u64 todo) {
-        const u32 j = lane & 7u;
-        const float* rec = reinterpret_cast<const float*>(t.leaves + leaf);
-        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
-        const u32 posj = leaf * LEAF + j;
-        // (one statement: v_cmpx .. v_writelane keeps the >= 4 instructions the hardware wants between a vector write of EXEC and a
-        //  lane write; nothing here depends on a compiler-inserted wait state)
-        u64 saved;
-        u32 ox, oy, oz, otau, owa, owner, which;  // (`which`: m0 as the statement found it, put back at its end: v_writelane takes its lane from m0 when its value is an SGPR -- one scalar operand per vector instruction on gfx9 -- and inline asm must not clobber m0)
-        float d, e;
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b32 %[ln], m0\n"
-            "1:\n\t"
-            "s_ff1_i32_b64 m0, %[todo]\n\t"
-            "s_bitset0_b64 %[todo], m0\n\t"
-            "v_readlane_b32 %[sx], %[qx], m0\n\t"
-            "v_readlane_b32 %[sy], %[qy], m0\n\t"
-            "v_readlane_b32 %[sz], %[qz], m0\n\t"
-            "v_readlane_b32 %[st], %[tau], m0\n\t"
-            "v_readlane_b32 %[sw], %[wa], m0\n\t"
-            "s_mov_b64 exec, 0xff\n\t"
-            "v_subrev_f32_e32 %[d], %[sx], %[cx]\n\t"
-            "v_subrev_f32_e32 %[e], %[sy], %[cy]\n\t"
-            "v_mul_f32_e32 %[d], %[d], %[d]\n\t"
-            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
-            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
-            "v_subrev_f32_e32 %[e], %[sz], %[cz]\n\t"
-            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
-            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
-            "v_cmpx_ge_f32_e32 %[st], %[d]\n\t"
-            "s_bcnt1_i32_b64 %[L], exec\n\t"
-            "v_mbcnt_lo_u32_b32 %[e], exec_lo, 0\n\t"
-            "v_lshl_add_u32 %[e], %[e], 9, %[sw]\n\t"
-            "ds_write2_b32 %[e], %[pos], %[d] offset1:1\n\t"
-            "s_lshl_b32 %[L], %[L], 9\n\t"
-            "s_add_u32 %[sw], %[sw], %[L]\n\t"
-            "s_cmp_lg_u64 %[todo], 0\n\t"
-            "v_writelane_b32 %[wa], %[sw], m0\n\t"
-            "s_cbranch_scc1 1b\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_mov_b32 m0, %[ln]"
-            : [ln] "=&s"(which), [sv] "=&s"(saved), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [st] "=&s"(otau), [sw] "=&s"(owa),
-              [d] "=&v"(d), [e] "=&v"(e), [wa] "+v"(wa), [todo] "+s"(todo)
-            : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [tau] "v"(tau), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [pos] "v"(posj)
-            : "vcc", "scc", "memory");
-    };
-    // A leaf that more lanes than that but at most PCPX_PACKED_LEAVES need (half of the walk's leaves: the lane-per-query form
-    // computes 512 distances there of which 32 ... 128 matter) is looked at EIGHT NEEDING LANES x EIGHT POINTS at a time: the
+    constexpr bool packed_leaves = pack_rows(MULTI, KCAP) > 0 && fast && !EPS_EACH;  // (wants the lanes that need each leaf: WalkerT's KEEP)
+    WalkerT<(KCAP > 8), packed_leaves> wk;
+    // A leaf of the walk that at most PCPX_PACKED_LEAVES lanes need (three quarters of the walk's leaves: the lane-per-query form
+    // computes 512 distances there of which 8 ... 192 matter) is looked at EIGHT NEEDING LANES x EIGHT POINTS at a time: the
     // needing lanes publish {query, tau} and their write address in LDS in the order of their rank (v_mbcnt of the need mask);
     // lane 8 i + j then forms the distance from the i-th published query to point j of the leaf, and a lane whose point is
     // within that query's tau takes the next row of the query's column with a returning LDS add on the published address and
@@ -837,14 +777,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // lanes (+ ~8 per leaf) against 91 per leaf.  Same keys, same arithmetic (d = p - q, three roundings), same tau as the
     // other forms; the order of a column's new keys is whatever order the adds were served in, which no result depends on
     // (keys are distinct and the selection network sorts them).
-    constexpr bool packed_leaves = pack_rows(MULTI, KCAP) > 0 && fast && !EPS_EACH;
-    // The buffer is filled OPTIMISTICALLY here: a leaf is started as soon as every needing lane has PCPX_PACKED_FREE free rows
-    // (the other forms want LEAF = 8: any lane may take every point), and a key whose add comes back with an address beyond the
-    // column's last row is not written -- the step reports those lanes, the caller folds the buffers and calls again from that
-    // step for those lanes only.  In the walk a lane takes one key of a leaf it needs, rarely three: waiting for eight free rows
-    // of ten meant a fold (the whole selection network, for all 64 lanes) per 19 keys of the WAVE.
-    // Returns 0 when the leaf is done, else the lanes of step `s` whose keys are still to be written.
-    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many, u32& s, u64 only) -> u64 {
+    // Slots that hold no query hold tau = -1 (k_knn sets them so, a needing lane sets its slot back when the leaf is done): the
+    // lanes of a step beyond the leaf's needing lanes compare against that and take nothing -- no lane mask per step, and the
+    // scalar unit is as loaded as the vector units here (profiles/experiments/README.md, round 4).
+    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) {
         float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
         u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
         u32 lane_here = lane;
@@ -860,37 +796,26 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             pub_wa[r] = wa;
         }
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
-        u64 unwritten = 0;  // (wave-uniform, like everything that steers this loop: the ballot is taken where every lane is active)
-        for (; s < how_many; s += 8u) {
-            const u32 left = how_many - s;                                           // queries of this step: lanes 0 .. 8 * left - 1
-            const u64 in_step = left >= 8u ? ~0ull : ((1ull << (8u * left)) - 1ull);
-            const float4 q = pub_q[s + i];  // (lanes beyond the step's queries: stale bytes of the row, masked by in_step)
+        for (u32 s = 0; s < how_many; s += 8u) {
+            const float4 q = pub_q[s + i];
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
             const float d2 = sq3(dx, dy, dz);
-            const u64 within = __builtin_amdgcn_ballot_w64(d2 <= q.w) & in_step & only;  // NaN padding points fail d2 <= tau
-            only = ~0ull;
-            bool no_room = false;
-            if (__builtin_amdgcn_inverse_ballot_w64(within)) {
+            if (d2 <= q.w) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
                 u32 one_row = 512u;
                 asm volatile("" : "+v"(one_row));  // (a v_mov here, not a register held from group to group)
                 const u32 at = atomicAdd(pub_wa + s + i, one_row);
-                no_room = at >= wa_end;  // (a lane's column starts below lds_row0 + 512: "row >= BUF" is a comparison with a wave-uniform bound)
-                if (!no_room) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(at), "v"(posj), "v"(d2) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(at), "v"(posj), "v"(d2) : "memory");
             }
-            unwritten = __builtin_amdgcn_ballot_w64(no_room);
-            if (unwritten != 0) break;
         }
         __builtin_amdgcn_wave_barrier();
         if (mine) {
-            const u32 now = pub_wa[r];
-            wa = now < col_addr + (static_cast<u32>(BUF) << 9) ? now : col_addr + (static_cast<u32>(BUF) << 9);  // (adds that did not fit moved it on too)
+            wa = pub_wa[r];
+            reinterpret_cast<float*>(pub_q + r)[3] = -1.f;
         }
         __builtin_amdgcn_wave_barrier();
-        return unwritten;
     };
     const u32 seed_count = s1 - s0;
-    u32 sparse_limit = PCPX_SPARSE_LEAVES;  // 0 in the shell rounds (they also want lo_d2 < d2; a visited leaf has a lane that needs it)
-    u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;
+    u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;  // 0 in the shell rounds (they also want lo_d2 < d2)
     for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
@@ -907,7 +832,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                 wk.at_leaf(loc);
                 if (loc - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
-                    if (!sparse_leaves) {
+                    if (!packed_leaves) {
                         fold_if_needed(true, false);
                         candidates(loc, rounds != 0u);
                     } else {
@@ -922,31 +847,14 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                             : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
                             : "scc");
                         // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
-                        // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more
-                        // (packed_leaf: PCPX_PACKED_FREE more -- and again whenever it comes back with keys that found no room).
-                        const bool packed_form = packed_leaves && how_many <= packed_limit && how_many > sparse_limit;
-                        const u32 wa_was = wa;
-                        u32 step = 0;
-                        u64 only = ~0ull;
-                        for (bool again = false;; again = true) {
-                            const u32 full = packed_form ? wa_packed_full : wa_full;
-                            if (again || (PCPX_FOLD_FOR_NEEDERS ? (__builtin_amdgcn_ballot_w64(wa >= full) & who) != 0 : any_lane(wa >= full))) fold(false);
-                            if (!packed_form) break;
+                        // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
+                        if (PCPX_FOLD_FOR_NEEDERS ? (__builtin_amdgcn_ballot_w64(wa >= wa_full) & who) != 0 : any_lane(wa >= wa_full)) fold(false);
+                        if (how_many <= packed_limit) {
+                            const u32 wa_was = wa;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            only = packed_leaf(loc, who, how_many, step, only);
+                            packed_leaf(loc, who, how_many);
                             if (STATS) {
-                                asm volatile("" ::"v"(wa));
-                                tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
-                            }
-                            if (only == 0) break;
-                        }
-                        if (packed_form) {
-                            if (STATS) ++st_leaves, st_app += (wa - wa_was) >> 9;  // (a fold in between: not counted exactly)
-                        } else if (how_many <= sparse_limit) {
-                            if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            sparse_leaf(loc, who);
-                            if (STATS) {
-                                ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;
+                                ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;  // ([14], [15]: the packed leaves and their needing lanes)
                                 tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
                             }
                         } else {
@@ -975,7 +883,6 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         // after 12 rounds
         const float grown = cap * PCPX_CAP_GROW;
         ++rounds;
-        sparse_limit = 0;
         packed_limit = 0;
         cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
         active = failed;
@@ -1189,6 +1096,7 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
     u64* const rows = lds + static_cast<size_t>(wib) * lds_rows(BUF, MULTI, MULTI ? 0 : KCAP) * 64;  // this wave's rows
     u64* col = rows + lane;
     float* pub = reinterpret_cast<float*>(rows + BUF * 64);  // packed_leaf's rows (pack_rows), behind the buffer's
+    if (pack_rows(MULTI, KCAP) > 0 && lane < static_cast<u32>(PCPX_PACKED_LEAVES)) pub[4u * lane + 3u] = -1.f;  // its invariant: a slot that holds no query holds tau = -1
     if (PCPX_COMPACT_BY8 && !MULTI && (KCAP <= 16 || PCPX_BY8_K32)) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
         const u64 pad = pad_key_here();
 #pragma unroll

@@ -2,14 +2,11 @@
 // walk as the kNN kernel (pcpx_device.h), one lane = one range, count or CSR fill.
 #include "pcpx_device.h"
 
-#ifndef PCPX_RANGE_SPARSE_LEAVES
-#define PCPX_RANGE_SPARSE_LEAVES 3
-#endif
 #ifndef PCPX_RANGE_DIRECT_LEAVES
 #define PCPX_RANGE_DIRECT_LEAVES 1
 #endif
 #ifndef PCPX_RANGE_PACKED_LEAVES
-#define PCPX_RANGE_PACKED_LEAVES 32  // count form: a leaf that at most this many lanes need is counted eight needing lanes x eight points at a time (0: off; <= 32: one 512-B row of LDS per wave)
+#define PCPX_RANGE_PACKED_LEAVES 16  // count form: a leaf that at most this many lanes need is counted eight needing lanes x eight points at a time (0: off; <= 32: one 512-B row of LDS per wave)
 #endif
 
 namespace pcpx {
@@ -24,8 +21,9 @@ namespace {
 // broadcast from SGPRs, the count kept per lane (compare + add-with-carry: 2 VALU per candidate on top of the 8 of the
 // distance -- an exec-masked form would not be shorter).  The kernel sits on both issue pipes, so what pays is what takes
 // instructions off both: a last-level node looks at its own leaves (no push and pop), and a leaf that few lanes need is
-// counted point-per-lane for those lanes only (count form; the fill form keeps the lane-per-range leaf).  Measured one at
-// a time each gave nothing, together 2.56 -> 2.40 ms per 10 M counts at r = 0.01 (profiles/experiments/README.md).
+// counted eight needing lanes x eight points at a time (count form: packed_leaf below; the fill form keeps the lane-per-range
+// leaf).  10 M counts at r = 0.01: 2.56 ms (round 3 start) -> 2.40 (direct leaves + round 3's point-per-lane form) -> 2.21
+// (round 4: the packed form instead; profiles/experiments/README.md).
 template <bool SELF, bool FILL>
 __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& qv, const u32 g, const float radius,
                                             const float* __restrict__ radii, u32* __restrict__ out_cnt,
@@ -89,51 +87,13 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
         }
     };
     auto leaf_points = [&](const u32 leaf) { leaf_record_points(load_const(t.leaves + leaf)); };
-    // A leaf that at most PCPX_RANGE_SPARSE_LEAVES lanes need is counted point-per-lane, once per needing lane (k_knn's
-    // sparse_leaf, pcpx_query.hip): lane j holds point j & 7, the needing lane's centre comes through v_readlane.
-    constexpr bool sparse_leaves = PCPX_RANGE_SPARSE_LEAVES > 0 && !FILL;
-    auto sparse_leaf = [&](const Leaf* record, u64 todo) {
-        const u32 j = lane & 7u;
-        const float* rec = reinterpret_cast<const float*>(record);
-        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
-        u32 ox, oy, oz, or2, ocnt, owner, which;  // (`which`: m0 as the statement found it, put back at its end: v_writelane takes its lane from m0 when its value is an SGPR -- one scalar operand per vector instruction on gfx9 -- and inline asm must not clobber m0)
-        float d, e;
-        asm volatile(
-            "s_mov_b32 %[ln], m0\n"
-            "1:\n\t"
-            "s_ff1_i32_b64 m0, %[todo]\n\t"
-            "s_bitset0_b64 %[todo], m0\n\t"
-            "v_readlane_b32 %[sx], %[qx], m0\n\t"
-            "v_readlane_b32 %[sy], %[qy], m0\n\t"
-            "v_readlane_b32 %[sz], %[qz], m0\n\t"
-            "v_readlane_b32 %[sr], %[r2], m0\n\t"
-            "v_readlane_b32 %[sc], %[cnt], m0\n\t"
-            "v_subrev_f32_e32 %[d], %[sx], %[cx]\n\t"
-            "v_subrev_f32_e32 %[e], %[sy], %[cy]\n\t"
-            "v_mul_f32_e32 %[d], %[d], %[d]\n\t"
-            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
-            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
-            "v_subrev_f32_e32 %[e], %[sz], %[cz]\n\t"
-            "v_mul_f32_e32 %[e], %[e], %[e]\n\t"
-            "v_add_f32_e32 %[d], %[d], %[e]\n\t"
-            "v_cmp_ge_f32_e32 vcc, %[sr], %[d]\n\t"  // (a NaN padding point fails)
-            "s_and_b32 %[L], vcc_lo, 0xff\n\t"
-            "s_bcnt1_i32_b32 %[L], %[L]\n\t"
-            "s_add_u32 %[sc], %[sc], %[L]\n\t"
-            "s_cmp_lg_u64 %[todo], 0\n\t"
-            "v_writelane_b32 %[cnt], %[sc], m0\n\t"
-            "s_cbranch_scc1 1b\n\t"
-            "s_mov_b32 m0, %[ln]"
-            : [ln] "=&s"(which), [L] "=&s"(owner), [sx] "=&s"(ox), [sy] "=&s"(oy), [sz] "=&s"(oz), [sr] "=&s"(or2), [sc] "=&s"(ocnt), [d] "=&v"(d), [e] "=&v"(e),
-              [cnt] "+v"(cnt), [todo] "+s"(todo)
-            : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [r2] "v"(r2), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz)
-            : "vcc", "scc");
-    };
-    // A leaf that more lanes than that but at most PCPX_RANGE_PACKED_LEAVES need is counted EIGHT NEEDING LANES x EIGHT POINTS at a
-    // time (k_knn's packed_leaf, pcpx_query.hip): the needing lanes publish {centre, r^2} in LDS in the order of their rank among
-    // the needing lanes, lane 8 i + j forms the distance from the i-th published centre to point j, and a needing lane adds the
-    // number of set bits of its own byte of the step's ballot -- ~13 vector instructions per eight needing lanes (+ 8 per leaf)
-    // against 88 per leaf in the lane-per-range form.  Same arithmetic (d = p - c, three roundings; sphere.hpp:27-35).
+    // A leaf that at most PCPX_RANGE_PACKED_LEAVES lanes need is counted EIGHT NEEDING LANES x EIGHT POINTS at a time (k_knn's
+    // packed_leaf, pcpx_query.hip): the needing lanes publish {centre, r^2} in LDS in the order of their rank among the needing
+    // lanes, lane 8 i + j forms the distance from the i-th published centre to point j, and a needing lane adds the number of set
+    // bits of its own byte of the step's ballot -- ~12 vector instructions per eight needing lanes (+ 8 per leaf) against 88 per
+    // leaf in the lane-per-range form.  Same arithmetic (d = p - c, three roundings; sphere.hpp:27-35).  A slot that holds no
+    // centre holds r^2 = -1 (k_range sets the row so, a needing lane sets its slot back): the lanes of a step beyond the leaf's
+    // needing lanes count nothing, without a lane mask per step (the scalar unit is as loaded as the vector units here).
     constexpr bool packed_leaves = PCPX_RANGE_PACKED_LEAVES > 0 && !FILL;
     static_assert(PCPX_RANGE_PACKED_LEAVES <= 32, "one row of LDS per wave");
     auto packed_leaf = [&](const Leaf* record, const u64 who, const u32 how_many) {
@@ -148,17 +108,17 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
         const u32 my_byte = (rank & 7u) << 3;
         for (u32 s = 0; s < how_many; s += 8u) {
-            const u32 left = how_many - s;
-            const u64 in_step = left >= 8u ? ~0ull : ((1ull << (8u * left)) - 1ull);  // lanes 0 .. 8 * left - 1 hold a published centre
             const float4 q = pub[s + i];
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
-            const u64 inside = __builtin_amdgcn_ballot_w64(sq3(dx, dy, dz) <= q.w) & in_step;  // (a NaN padding point fails)
+            const u64 inside = __builtin_amdgcn_ballot_w64(sq3(dx, dy, dz) <= q.w);  // (a NaN padding point fails; so does every point against an empty slot)
             if (mine && rank - s < 8u) cnt += static_cast<u32>(__builtin_popcount(static_cast<u32>(inside >> my_byte) & 0xFFu));
         }
         __builtin_amdgcn_wave_barrier();
+        if (mine) reinterpret_cast<float*>(pub + rank)[3] = -1.f;
+        __builtin_amdgcn_wave_barrier();
     };
     // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
-    WalkerT<true, (sparse_leaves || packed_leaves)> wk;
+    WalkerT<true, packed_leaves> wk;
     u32 nexp = 0;
     if (wk.start(t, need, nexp)) leaf_points(0u);  // the root is the only leaf
     // A last-level node looks at its needed leaves itself (WalkerT::leaves_of) instead of pushing and popping them: the four
@@ -176,9 +136,8 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
             for (int c = 0; c < W; ++c) {
                 if ((needed >> c) & 1u) {
                     u32 how_many = GROUP;
-                    if (sparse_leaves || packed_leaves) asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
-                    if (sparse_leaves && how_many <= static_cast<u32>(PCPX_RANGE_SPARSE_LEAVES)) sparse_leaf(records + c, wk.leaf_need[c]);
-                    else if (packed_leaves && how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c, wk.leaf_need[c], how_many);
+                    if (packed_leaves) asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
+                    if (packed_leaves && how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c, wk.leaf_need[c], how_many);
                     else leaf_record_points(load_const(records + c));
                 }
             }
@@ -202,6 +161,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, Quer
     const u32 lane = threadIdx.x & 63u;
     const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
     if (g >= group_end) return;
+    if (!FILL && lane < 32u) published[wave_in_block()][lane].w = -1.f;  // packed_leaf's invariant: a slot that holds no centre holds r^2 = -1
     range_group<SELF, FILL>(t, qv, g, radius, radii, out_cnt, offsets, out_idx, published[wave_in_block()], lane);
 }
 
