@@ -212,8 +212,7 @@ __global__ __launch_bounds__(CODES_BLOCK) void k_codes(const float* __restrict__
 __device__ __forceinline__ NodeBox padding_node()
 {
     NodeBox nb;
-    nb.lo[0] = nb.lo[1] = nb.lo[2] = 0.f;
-    nb.hi[0] = nb.hi[1] = nb.hi[2] = 0.f;
+    nb.set(0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
     nb.poison = __builtin_nanf("");
     nb.pad = 0.f;
     return nb;
@@ -246,17 +245,16 @@ __device__ __forceinline__ NodeBox union_of_children(const NodeBox* __restrict__
         NodeBox cb = child4[c];
         if (cb.poison == 0.f) {
             any = true;
-            b[0] = fminf(b[0], cb.lo[0]);
-            b[1] = fminf(b[1], cb.lo[1]);
-            b[2] = fminf(b[2], cb.lo[2]);
-            b[3] = fmaxf(b[3], cb.hi[0]);
-            b[4] = fmaxf(b[4], cb.hi[1]);
-            b[5] = fmaxf(b[5], cb.hi[2]);
+            b[0] = fminf(b[0], cb.lo(0));
+            b[1] = fminf(b[1], cb.lo(1));
+            b[2] = fminf(b[2], cb.lo(2));
+            b[3] = fmaxf(b[3], cb.hi(0));
+            b[4] = fmaxf(b[4], cb.hi(1));
+            b[5] = fmaxf(b[5], cb.hi(2));
         }
     }
     NodeBox nb;
-    nb.lo[0] = any ? b[0] : 0.f; nb.lo[1] = any ? b[1] : 0.f; nb.lo[2] = any ? b[2] : 0.f;
-    nb.hi[0] = any ? b[3] : 0.f; nb.hi[1] = any ? b[4] : 0.f; nb.hi[2] = any ? b[5] : 0.f;
+    nb.set(any ? b[0] : 0.f, any ? b[1] : 0.f, any ? b[2] : 0.f, any ? b[3] : 0.f, any ? b[4] : 0.f, any ? b[5] : 0.f);
     nb.poison = any ? 0.f : __builtin_nanf("");
     nb.pad = 0.f;
     return nb;
@@ -354,8 +352,7 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_fill_leaves(const float4* __rest
         if ((p % LEAF) == 0) {
             NodeBox nb = padding_node();
             if (p / LEAF < ts.nleaves) {
-                nb.lo[0] = lx; nb.lo[1] = ly; nb.lo[2] = lz;
-                nb.hi[0] = hx; nb.hi[1] = hy; nb.hi[2] = hz;
+                nb.set(lx, ly, lz, hx, hy, hz);
                 nb.poison = 0.f;
             }
             lvl0[(threadIdx.x + u * FILL_BLOCK) / LEAF] = nb;

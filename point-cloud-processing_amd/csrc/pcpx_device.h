@@ -35,12 +35,15 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx *
 // squared distance from q to the box (+ poison): equals d2(q, clamp(q, box)) of
 // include/pcp/common/axis_aligned_bounding_box.hpp:138-148 and is a lower bound, in float arithmetic,
 // of sq3(p - q) for every p inside the box; NaN for a padding node.
+typedef float float_pair __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float box_d2(const NodeBox& b, float qx, float qy, float qz)
 {
-    // (v_med3_f32(q, lo, hi) takes two SGPR operands, which gfx9 VALU encodings do not allow: no cheaper)
-    float dx = fmaxf(fmaxf(b.lo[0] - qx, qx - b.hi[0]), 0.f);
-    float dy = fmaxf(fmaxf(b.lo[1] - qy, qy - b.hi[1]), 0.f);
-    float dz = fmaxf(fmaxf(b.lo[2] - qz, qz - b.hi[2]), 0.f);
+    // (v_med3_f32(q, lo, hi) takes two SGPR operands, which gfx9 VALU encodings do not allow: no cheaper.  Two axes per
+    //  packed-float instruction -- v_pk_add_f32 / v_pk_mul_f32 on register pairs, 12 instead of 16 instructions per box -- was
+    //  measured in round 4: k_knn the same, k_range 8 % slower; profiles/experiments/README.md)
+    float dx = fmaxf(fmaxf(b.lo(0) - qx, qx - b.hi(0)), 0.f);
+    float dy = fmaxf(fmaxf(b.lo(1) - qy, qy - b.hi(1)), 0.f);
+    float dz = fmaxf(fmaxf(b.lo(2) - qz, qz - b.hi(2)), 0.f);
     return sq3(dx, dy, dz) + b.poison;
 }
 
@@ -132,7 +135,8 @@ struct WalkerT {
 #pragma unroll
         for (int c = W - 1; c >= 0; --c) {
             const u64 lanes = __builtin_amdgcn_ballot_w64(need(cb.c[c]));
-            if (KEEP) leaf_need[c] = lanes;
+            if (KEEP) leaf_need[c] = lanes;  // (kept at every expansion, though only a last-level node's are read: keeping them only there
+                                             //  measured 2 % SLOWER -- hipcc then moves the masks about at the loop's edges)
             asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(m) : "s"(lanes) : "scc");
         }
         return m;

@@ -63,10 +63,16 @@ static_assert(sizeof(Leaf) == 16 * LEAF, "leaf record must be dense");
 // scalar load.  `poison` is +0 for a real node and NaN for a padding node (no points below it): it is
 // added to the box distance, so a padding node can never pass a `distance <= bound` test.
 struct NodeBox {
-    float lo[3];
-    float hi[3];
+    float lo3[3];
+    float hi3[3];
     float poison;
     float pad;
+    __host__ __device__ float lo(int a) const { return lo3[a]; }
+    __host__ __device__ float hi(int a) const { return hi3[a]; }
+    __host__ __device__ void set(float lx, float ly, float lz, float hx, float hy, float hz)
+    {
+        lo3[0] = lx, lo3[1] = ly, lo3[2] = lz, hi3[0] = hx, hi3[1] = hy, hi3[2] = hz;
+    }
 };
 static_assert(sizeof(NodeBox) == 32, "node box must be 32 bytes");
 

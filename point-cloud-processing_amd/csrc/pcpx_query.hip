@@ -154,11 +154,11 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_SEED_DIRECT
 #define PCPX_SEED_DIRECT 8  // largest KCAP whose seed leaves skip the append buffer (k <= 16 / 32: scratch in the seed phase)
 #endif
-#ifndef PCPX_FOLD_FOR_NEEDERS
-#define PCPX_FOLD_FOR_NEEDERS 1
-#endif
 #ifndef PCPX_PACKED_LEAVES
 #define PCPX_PACKED_LEAVES 24  // a walk leaf that 2 ... this many lanes need is looked at eight needing lanes x eight points at a time (0: off)
+#endif
+#ifndef PCPX_PACKED_FREE
+#define PCPX_PACKED_FREE 3  // k <= 16 kernel: free rows every needing lane has when a packed leaf starts (0: LEAF of them, like the other forms -- no key can then find its column full).  The k <= 32 kernel always waits for LEAF rows: its fold is twice the network, and what the optimistic fill loses there it does not win back (measured)
 #endif
 #ifndef PCPX_KNN_WPB16
 #define PCPX_KNN_WPB16 4  // waves per workgroup of the k <= 16 kernel: its 11 rows x 512 B per wave fill the LDS allocation granule
@@ -587,6 +587,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // wa with a wave-uniform bound: no per-lane threshold register
     const u32 lds_row0 = __builtin_amdgcn_readfirstlane(col_addr) - 8u * __builtin_amdgcn_readfirstlane(lane);
     const u32 wa_full = lds_row0 + (static_cast<u32>(BUF - LEAF + 1) << 9);  // wa >= this: a leaf might not fit any more
+    const u32 wa_end = lds_row0 + (static_cast<u32>(BUF) << 9);               // a key address >= this: beyond the column's last row
+    constexpr int packed_free = KCAP <= 16 ? PCPX_PACKED_FREE : 0;  // (see PCPX_PACKED_FREE)
+    const u32 wa_packed_full = packed_free > 0 ? lds_row0 + (static_cast<u32>(BUF - packed_free + 1) << 9) : wa_full;
 
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= tau; };
     // single-pass kernels: the eps-box test waits for the compaction, unless the launcher picked the EPS_EACH form (launch_knn_t)
@@ -663,6 +666,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             u32 posv = posbase;
             const u64 saved = save_exec();
             static_assert(LEAF == 8, "two statements of four candidates");
+            // (two candidates at a time with packed-float arithmetic -- 18 instead of 26 instructions per pair -- measured in round 4: the
+            //  same rate; profiles/experiments/README.md)
             append4_if_within(lf.x, lf.y, lf.z, qx, qy, qz, tau, posv, wa, saved);
             append4_if_within(lf.x + 4, lf.y + 4, lf.z + 4, qx, qy, qz, tau, posv, wa, saved);
         } else if (fast && eps_filter.on && !shell) {
@@ -780,7 +785,14 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // Slots that hold no query hold tau = -1 (k_knn sets them so, a needing lane sets its slot back when the leaf is done): the
     // lanes of a step beyond the leaf's needing lanes compare against that and take nothing -- no lane mask per step, and the
     // scalar unit is as loaded as the vector units here (profiles/experiments/README.md, round 4).
-    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) {
+    // PCPX_PACKED_FREE > 0: the buffer is filled OPTIMISTICALLY -- a leaf is started as soon as every needing lane has that many
+    // free rows (the other forms want LEAF = 8: any lane may take every point; in the walk a lane takes one key of a leaf it
+    // needs, rarely three, and waiting for eight free rows of ten meant a fold -- the whole selection network, for all 64
+    // lanes -- per 19 keys of the WAVE).  A key whose add comes back with an address beyond the column goes to a spare word of
+    // the publish row instead; the needing lane sees from the address it reads back that keys were lost, takes its column back
+    // to where it was before the leaf (the rows written since hold PAD_KEY again), and the leaf is looked at once more for
+    // those lanes after a fold.  Returns the lanes that want that (0: done).
+    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) -> u64 {
         float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
         u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
         u32 lane_here = lane;
@@ -803,33 +815,70 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             if (d2 <= q.w) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
                 u32 one_row = 512u;
                 asm volatile("" : "+v"(one_row));  // (a v_mov here, not a register held from group to group)
-                const u32 at = atomicAdd(pub_wa + s + i, one_row);
+                u32 at = atomicAdd(pub_wa + s + i, one_row);
+                if (packed_free > 0) at = at < wa_end ? at : wa_end + 480u;  // (the publish row's last 32 bytes are nobody's)
                 asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(at), "v"(posj), "v"(d2) : "memory");
             }
         }
         __builtin_amdgcn_wave_barrier();
+        u32 now = wa;
         if (mine) {
-            wa = pub_wa[r];
+            now = pub_wa[r];
             reinterpret_cast<float*>(pub_q + r)[3] = -1.f;
         }
         __builtin_amdgcn_wave_barrier();
+        if (packed_free == 0) {
+            wa = now;
+            return 0ull;
+        }
+        const u32 column_end = col_addr + (static_cast<u32>(BUF) << 9);
+        const bool lost_keys = now > column_end;  // (a lane that does not need the leaf: now = wa <= column_end)
+        const u64 lost = __builtin_amdgcn_ballot_w64(lost_keys);
+        if (lost != 0) {  // rare
+            if (lost_keys) {
+                const u64 pad = pad_key_here();
+                for (u32 a = wa; a < column_end; a += 512u) asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(pad) : "memory");
+            }
+        }
+        if (!lost_keys) wa = now;
+        return lost;
     };
     const u32 seed_count = s1 - s0;
     u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;  // 0 in the shell rounds (they also want lo_d2 < d2)
     for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
-        // one pop per trip: a node is expanded, a leaf outside the seed range (a seed leaf was seen under a larger tau than any
-        // later one) is looked at -- "is there another leaf" is the loop's own control flow (see WalkerT::pop)
+        // A trip of the outer loop pops one node: a node above the last level is expanded; a LAST-LEVEL node hands its needed
+        // leaves to the inner loop directly (WalkerT::leaves_of: no trip through the pending bits for them -- a dozen scalar
+        // instructions per leaf, and the scalar side of this kernel is what it is short of); `direct` = its children still to look
+        // at, as leaves direct_first + c.  A leaf inside the seed range was seen under a larger tau than any later one: skipped.
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-        while (!wk.done()) {
-            u32 loc;
-            const int h = wk.pop(loc);
-            if (h != 0) {
+        u32 direct = 0, direct_first = 0;
+        for (;;) {
+            if (direct == 0) {
+                if (wk.done()) break;
+                u32 node;
+                const int h = wk.pop(node);
                 ++st_expand;
-                wk.expand(t, h, loc, need);
-            } else {
-                wk.at_leaf(loc);
+                if (h > 1) {
+                    wk.expand(t, h, node, need);
+                } else if (h == 1) {
+                    direct = wk.leaves_of(t, node, need);
+                    direct_first = node << LOGW;
+                } else {  // (a leaf is popped only when the root's own children are leaves; as a block before the loop -- `if (t.depth == 1)
+                          //  direct = the root's child mask` -- this cost every k_knn kernel 50 ... 300 B of scratch: hipcc 7.2)
+                    wk.at_leaf(node);
+                    direct = 1u << (node & (W - 1u));
+                    direct_first = node & ~(W - 1u);
+                }
+            }
+            while (direct != 0) {
+                u32 loc;
+                {
+                    u32 child;
+                    asm("s_ff1_i32_b32 %0, %1\n\ts_bitset0_b32 %1, %0" : "=&s"(child), "+s"(direct));
+                    loc = direct_first + child;
+                }
                 if (loc - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
                     if (!packed_leaves) {
@@ -848,15 +897,23 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
                             : "scc");
                         // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
                         // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
-                        if (PCPX_FOLD_FOR_NEEDERS ? (__builtin_amdgcn_ballot_w64(wa >= wa_full) & who) != 0 : any_lane(wa >= wa_full)) fold(false);
-                        if (how_many <= packed_limit) {
-                            const u32 wa_was = wa;
+                        const bool packed_form = how_many <= packed_limit;
+                        const u32 wa_was = wa;
+                        u64 todo = who;  // (the lanes the leaf is still to be looked at for)
+                        for (bool again = false;; again = true) {  // (one call site of the fold: one copy of the selection network)
+                            if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false);
+                            if (!packed_form) break;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            packed_leaf(loc, who, how_many);
+                            todo = packed_leaf(loc, todo, how_many);
                             if (STATS) {
-                                ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;  // ([14], [15]: the packed leaves and their needing lanes)
+                                asm volatile("" ::"v"(wa));
                                 tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
                             }
+                            if (todo == 0) break;  // (else, PCPX_PACKED_FREE > 0 only and rare: columns ran full -- fold, and once more for their lanes)
+                            how_many = static_cast<u32>(__builtin_popcountll(todo));
+                        }
+                        if (packed_form) {
+                            if (STATS) ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;  // ([14], [15]: the packed leaves and their needing lanes)
                         } else {
                             candidates(loc, rounds != 0u);
                         }
@@ -876,7 +933,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         if (STATS) ++st_round2;
         lo_d2 = cap;
         const NodeBox root = load_const(t.nodes);
-        const float ex = root.hi[0] - root.lo[0], ey = root.hi[1] - root.lo[1], ez = root.hi[2] - root.lo[2];
+        const float ex = root.hi(0) - root.lo(0), ey = root.hi(1) - root.lo(1), ez = root.hi(2) - root.lo(2);
         const float diag2 = sq3(ex, ey, ez);
         // next radius^2; the last round is uncapped: when the cap covers the whole cloud from any query inside 2x its box, when
         // it cannot grow (a cap of 0: more than half of the sampled lanes sit on >= k coincident points and eps is 0), or

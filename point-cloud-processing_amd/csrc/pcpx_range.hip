@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
     u32 cnt = 0;
     u64 wpos = (FILL && valid) ? offsets[p] : 0;
     auto need = [&](const NodeBox& n) {
-        bool o = (n.hi[0] >= b0) & (n.hi[1] >= b1) & (n.hi[2] >= b2) & (n.lo[0] <= b3) & (n.lo[1] <= b4) & (n.lo[2] <= b5);
+        const float lx = n.lo(0), ly = n.lo(1), lz = n.lo(2), hx = n.hi(0), hy = n.hi(1), hz = n.hi(2);
+        bool o = (hx >= b0) & (hy >= b1) & (hz >= b2) & (lx <= b3) & (ly <= b4) & (lz <= b5);
         return o & (n.poison == 0.f) & valid;
     };
     auto leaf_points = [&](const u32 leaf) {
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(64) void k_range_one(TreeView t, float a0, float a1
     const u32 lane = threadIdx.x;
     const float r2 = a3 * a3;  // sphere.hpp:34 radius * radius in float
     auto need = [&](const NodeBox& b) -> bool {
-        if (AABB) return (b.hi[0] >= a0) & (b.hi[1] >= a1) & (b.hi[2] >= a2) & (b.lo[0] <= a3) & (b.lo[1] <= a4) & (b.lo[2] <= a5) & (b.poison == 0.f);
+        const float lx = b.lo(0), ly = b.lo(1), lz = b.lo(2), hx = b.hi(0), hy = b.hi(1), hz = b.hi(2);
+        if (AABB) return (hx >= a0) & (hy >= a1) & (hz >= a2) & (lx <= a3) & (ly <= a4) & (lz <= a5) & (b.poison == 0.f);
         return box_d2(b, a0, a1, a2) <= r2;  // (NaN for a padding node)
     };
     auto level_base = [](int d) { return d == 0 ? 0u : (0x55555555u >> (32 - 2 * d)); };
