@@ -566,21 +566,21 @@ def main():
         # write + 12 B normal write per query (84 B at k = 15); the fused k_knn launch does exactly that
         bytes_per_q = 12 + 4 * k + (0 if args.workload in STREAMING else 12)
         achieved = q_per_launch * bytes_per_q / avg_s
-        roofline = {"bound": "hbm", "limiter": "instruction issue, vector and scalar pipes (profiles/r03_valu_issue_model.json: ~93 % and ~72 % of the SIMD cycles)", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
+        roofline = {"bound": "hbm", "limiter": "instructions issued per wave, the scalar ones first: ~33 000 per 64 queries at 7 waves per SIMD (profiles/r04_pmc_summary.json, profiles/experiments/README.md round 4)", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_query": bytes_per_q, "queries_per_launch": q_per_launch,
-                    "note": "fused kNN+normals kernel: a tree search, bounded by instruction issue (vector and scalar pipes), not by HBM (DESIGN.md "
+                    "note": "fused kNN+normals kernel: a tree search, bounded by instruction issue (per wave; the scalar side first), not by HBM (DESIGN.md "
                             "'Roofline'); achieved = algorithmic bytes / HIP-event time of the launch on its stream, measured in this "
                             "run; traffic = PMC HBM bytes per launch from the committed rocprofv3 --pmc passes of this command "
-                            "(profiles/r03_hbm_traffic.json), null when that file is not for this workload"}
-        traffic_file = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+                            "(profiles/r04_hbm_traffic.json), null when that file is not for this workload"}
+        traffic_file = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
                 if tr.get("workload") == args.workload and world == 1:
                     roofline["traffic"] = tr.get("k_knn_hbm_bytes_per_launch")
-                    roofline["traffic_source"] = "profiles/r03_hbm_traffic.json (separate --pmc passes, not this run)"
+                    roofline["traffic_source"] = "profiles/r04_hbm_traffic.json (separate --pmc passes, not this run)"
                     roofline["hbm_measured_GBps"] = round(roofline["traffic"] / avg_s / 1e9, 1)
                     roofline["hbm_measured_frac"] = round(roofline["traffic"] / avg_s / HBM_PEAK, 5)
             except Exception:

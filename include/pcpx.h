@@ -299,6 +299,10 @@ int pcpx_device_malloc(uint64_t bytes, int device, void** out_ptr);
 void pcpx_device_free(void* d_ptr, int device);
 int pcpx_device_upload(void* d_dst, const void* src, uint64_t bytes, int device, void* stream);   /* synchronous */
 int pcpx_device_download(void* dst, const void* d_src, uint64_t bytes, int device, void* stream); /* synchronous */
+/* Destroying an index keeps its device blocks for the next index of the same device (a drop-in caller constructs containers in a
+ * loop, benchmark/spatial_data_structures_benchmark.cpp:108-148, and hipMalloc / hipFree cost more than a small build): at most
+ * PCPX_DEVICE_CACHE_MB (environment; default 2048, 0 = keep nothing) of idle blocks per device.  This gives them all back. */
+int pcpx_device_trim(int device);
 
 /* ---- multi-GPU: one process per GPU ------------------------------------------------------------ */
 /* Contiguous, 64-aligned shard of the curve-sorted query order for `rank` of `world`. */

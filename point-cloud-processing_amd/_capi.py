@@ -107,6 +107,7 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p]),
     "pcpx_device_malloc": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "pcpx_device_free": (None, [C.c_void_p, C.c_int]),
+    "pcpx_device_trim": (C.c_int, [C.c_int]),
     "pcpx_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "pcpx_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "pcpx_comm_unique_id": (C.c_int, [C.c_char_p]),

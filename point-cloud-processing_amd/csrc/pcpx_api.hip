@@ -3,6 +3,10 @@
 // enqueue on the index's stream.  No CPU fallback exists: every compute call needs a HIP device.
 #include "pcpx_internal.h"
 
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
@@ -87,15 +91,6 @@ void DevPool::release(void* p)
         blocks.erase(blocks.begin() + largest);
     }
 }
-void DevPool::discard(void* p)
-{
-    for (size_t i = 0; i < blocks.size(); ++i)
-        if (blocks[i].p == p) {
-            (void)hipFree(p);
-            blocks.erase(blocks.begin() + static_cast<long>(i));
-            return;
-        }
-}
 void DevPool::trim()
 {
     size_t keep = 0;
@@ -115,6 +110,105 @@ DevPool::~DevPool()
 {
     for (auto& b : blocks) (void)hipFree(b.p);
 }
+// ---- device blocks of indexes, cached per device (pcpx_internal.h) ----------------------------------------------------------
+namespace {
+struct IndexBlocks {
+    std::mutex mu;
+    struct Idle {
+        void* p;
+        size_t bytes;
+        int device;
+    };
+    std::vector<Idle> idle;
+    std::unordered_map<void*, size_t> handed_out;  // block -> its real size
+    size_t cap_bytes()
+    {
+        static const size_t cap = [] {
+            const char* e = std::getenv("PCPX_DEVICE_CACHE_MB");
+            const long long mb = e ? std::atoll(e) : 2048;
+            return static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
+        }();
+        return cap;
+    }
+};
+IndexBlocks& index_blocks()
+{
+    static IndexBlocks* b = new IndexBlocks();  // (never destroyed: the HIP runtime may be gone by the time statics are)
+    return *b;
+}
+}  // namespace
+
+hipError_t index_block_alloc(void** p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    IndexBlocks& c = index_blocks();
+    std::lock_guard<std::mutex> lock(c.mu);
+    int best = -1;
+    for (size_t i = 0; i < c.idle.size(); ++i)
+        if (c.idle[i].device == dev && c.idle[i].bytes >= bytes && c.idle[i].bytes <= bytes + bytes / 4 + (size_t(64) << 10) &&
+            (best < 0 || c.idle[i].bytes < c.idle[static_cast<size_t>(best)].bytes))
+            best = static_cast<int>(i);
+    if (best >= 0) {
+        *p = c.idle[static_cast<size_t>(best)].p;
+        c.handed_out[*p] = c.idle[static_cast<size_t>(best)].bytes;
+        c.idle.erase(c.idle.begin() + best);
+        return hipSuccess;
+    }
+    const size_t rounded = (bytes + 4095) / 4096 * 4096;
+    hipError_t e = hipMalloc(p, rounded);
+    if (e == hipErrorOutOfMemory) {  // what sits idle here may be what is missing
+        (void)hipGetLastError();
+        size_t keep = 0;
+        for (size_t i = 0; i < c.idle.size(); ++i) {
+            if (c.idle[i].device == dev) (void)hipFree(c.idle[i].p);
+            else c.idle[keep++] = c.idle[i];
+        }
+        c.idle.resize(keep);
+        e = hipMalloc(p, rounded);
+    }
+    if (e == hipSuccess) c.handed_out[*p] = rounded;
+    else *p = nullptr;
+    return e;
+}
+
+void index_block_free(void* p)
+{
+    if (!p) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    IndexBlocks& c = index_blocks();
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.handed_out.find(p);
+    if (it == c.handed_out.end()) {  // not one of ours (cannot happen; be safe)
+        (void)hipFree(p);
+        return;
+    }
+    const size_t bytes = it->second;
+    c.handed_out.erase(it);
+    size_t idle_here = 0;
+    for (auto const& b : c.idle)
+        if (b.device == dev) idle_here += b.bytes;
+    if (idle_here + bytes <= c.cap_bytes()) c.idle.push_back(IndexBlocks::Idle{p, bytes, dev});
+    else (void)hipFree(p);
+}
+
+void index_blocks_trim()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    IndexBlocks& c = index_blocks();
+    std::lock_guard<std::mutex> lock(c.mu);
+    size_t keep = 0;
+    for (size_t i = 0; i < c.idle.size(); ++i) {
+        if (c.idle[i].device == dev) (void)hipFree(c.idle[i].p);
+        else c.idle[keep++] = c.idle[i];
+    }
+    c.idle.resize(keep);
+}
+
 int PinnedStage::ensure(size_t need)
 {
     if (need <= bytes) return PCPX_OK;
@@ -144,8 +238,9 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     DevPool* pool = nullptr;
-    bool one_off = false;  // true: the block goes back to the driver, not into the pool's cache (the n x 12-byte staging copy
-                           // of a build from host memory would otherwise stay cached for the handle's lifetime)
+    bool one_off = false;  // true: not a block of the handle's pool (the n x 12-byte staging copy of a build from host memory
+                           // would stay cached for the handle's lifetime) but one of the device's index blocks: it serves the
+                           // next index built on this device, or goes back to the driver (index_block_alloc, pcpx_internal.h)
     explicit DevBuf(DevPool& owner, bool one_off_ = false) : pool(&owner), one_off(one_off_) {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -153,13 +248,22 @@ struct DevBuf {
     void reset()
     {
         if (!p) return;
-        if (one_off) pool->discard(p);
+        if (one_off) index_block_free(p);
         else pool->release(p);
         p = nullptr;
     }
     int alloc(size_t bytes)
     {
-        p = pool->acquire(bytes);
+        if (one_off) {
+            const hipError_t e = index_block_alloc(&p, bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+                p = nullptr;
+            }
+        } else {
+            p = pool->acquire(bytes);
+        }
         return p ? PCPX_OK : PCPX_ERR_ALLOC;
     }
     template <class T>
@@ -306,15 +410,16 @@ void free_index(Index* ix)
         (void)hipEventDestroy(iv.a);
         (void)hipEventDestroy(iv.b);
     }
-    (void)hipFree(ix->d_xyz);
-    for (int b = 0; b < 2; ++b) (void)hipFree(ix->d_codes[b]);
-    (void)hipFree(ix->d_perm);
-    (void)hipFree(ix->d_rec);
-    (void)hipFree(ix->d_sort_tmp);
-    (void)hipFree(ix->d_leaves);
-    (void)hipFree(ix->d_nodes);
-    (void)hipFree(ix->d_scalars);
-    (void)hipFree(ix->d_scratch);
+    // (the stream is drained: the blocks may serve the next index of this device -- index_block_free)
+    index_block_free(ix->d_xyz);
+    for (int b = 0; b < 2; ++b) index_block_free(ix->d_codes[b]);
+    index_block_free(ix->d_perm);
+    index_block_free(ix->d_rec);
+    index_block_free(ix->d_sort_tmp);
+    index_block_free(ix->d_leaves);
+    index_block_free(ix->d_nodes);
+    index_block_free(ix->d_scalars);
+    index_block_free(ix->d_scratch);
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
     free_shard(*ix);
@@ -1581,6 +1686,15 @@ int pcpx_device_malloc(uint64_t bytes, int device, void** out_ptr)
     }
     return PCPX_OK;
 }
+int pcpx_device_trim(int device)
+{
+    DeviceScope dscope;
+    int st = dscope.select(device);
+    if (st != PCPX_OK) return st;
+    index_blocks_trim();
+    return PCPX_OK;
+}
+
 void pcpx_device_free(void* d_ptr, int device)
 {
     if (!d_ptr) return;

@@ -426,11 +426,11 @@ int dev_alloc(T*& p, size_t count, DevPool* pool)
 {
     p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    hipError_t e = index_block_alloc(reinterpret_cast<void**>(&p), count * sizeof(T));  // (a block of an earlier index of this device, or hipMalloc)
     if (e == hipErrorOutOfMemory && pool && pool->cached_bytes() > 0) {
         (void)hipGetLastError();
         pool->trim();
-        e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        e = index_block_alloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     }
     if (e != hipSuccess) {
         p = nullptr;
@@ -465,15 +465,15 @@ int ensure_scratch(Index& ix, size_t bytes)
     if (bytes <= ix.scratch_bytes) return PCPX_OK;
     if (ix.d_scratch) {
         PCPX_HIP(hipStreamSynchronize(ix.stream));
-        (void)hipFree(ix.d_scratch);
+        index_block_free(ix.d_scratch);
         ix.d_scratch = nullptr;
         ix.scratch_bytes = 0;
     }
-    hipError_t e = hipMalloc(&ix.d_scratch, bytes);
+    hipError_t e = index_block_alloc(&ix.d_scratch, bytes);
     if (e == hipErrorOutOfMemory && ix.pool.cached_bytes() > 0) {
         (void)hipGetLastError();
         ix.pool.trim();
-        e = hipMalloc(&ix.d_scratch, bytes);
+        e = index_block_alloc(&ix.d_scratch, bytes);
     }
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu bytes) for query scratch failed: %s", bytes, hipGetErrorString(e));
@@ -507,11 +507,11 @@ static int grow_arrays(Index& ix, u64 need_cloud, u64 need_tree, bool want_xyz)
         ~Fresh()
         {
             if (keep) return;
-            (void)hipFree(xyz);
-            (void)hipFree(codes[0]); (void)hipFree(codes[1]);
-            (void)hipFree(perm);
-            (void)hipFree(rec);
-            (void)hipFree(leaves); (void)hipFree(nodes); (void)hipFree(sort_tmp);
+            index_block_free(xyz);
+            index_block_free(codes[0]); index_block_free(codes[1]);
+            index_block_free(perm);
+            index_block_free(rec);
+            index_block_free(leaves); index_block_free(nodes); index_block_free(sort_tmp);
         }
     } nw;
     int st;
@@ -536,23 +536,23 @@ static int grow_arrays(Index& ix, u64 need_cloud, u64 need_tree, bool want_xyz)
         nw.sort_tmp = tmp;
     }
     if (grow_cloud) {
-        (void)hipFree(ix.d_xyz);
+        index_block_free(ix.d_xyz);
         ix.d_xyz = nw.xyz;
         ix.cap_xyz = want_xyz ? ccap : 0;
-        (void)hipFree(ix.d_codes[0]);
+        index_block_free(ix.d_codes[0]);
         ix.d_codes[0] = nw.codes[0];
         ix.cap = ccap;
     }
     if (grow_tree) {
-        (void)hipFree(ix.d_codes[1]);
+        index_block_free(ix.d_codes[1]);
         ix.d_codes[1] = nw.codes[1];
-        (void)hipFree(ix.d_perm);
+        index_block_free(ix.d_perm);
         ix.d_perm = nw.perm;
-        (void)hipFree(ix.d_rec);
+        index_block_free(ix.d_rec);
         ix.d_rec = nw.rec;
-        (void)hipFree(ix.d_leaves);
-        (void)hipFree(ix.d_nodes);
-        (void)hipFree(ix.d_sort_tmp);
+        index_block_free(ix.d_leaves);
+        index_block_free(ix.d_nodes);
+        index_block_free(ix.d_sort_tmp);
         ix.d_leaves = nw.leaves;
         ix.d_nodes = nw.nodes;
         ix.d_sort_tmp = nw.sort_tmp;

@@ -131,11 +131,21 @@ struct DevPool {
     std::vector<Block> blocks;
     void* acquire(size_t bytes);  // nullptr (and the thread's error text set) when the device is out of memory
     void release(void* p);
-    void discard(void* p);        // returns a handed-out block to the driver instead of caching it
     void trim();                  // frees every block that is not handed out
     size_t cached_bytes() const;
     ~DevPool();
 };
+
+// Device blocks of INDEXES (cloud copy, sort words, leaves, nodes, sort workspace ...), cached per device across handles:
+// hipMalloc / hipFree cost 0.3 ... 1 ms each and hipFree synchronises the device, and a drop-in caller builds containers in
+// a loop (benchmark/spatial_data_structures_benchmark.cpp:108-148 constructs one per iteration) -- at 2^20 points a dozen
+// allocations and frees were most of the 25 ms of a construction.  index_block_free keeps a block for the next
+// index_block_alloc of the CURRENT device that it fits (at most a quarter larger than asked), up to PCPX_DEVICE_CACHE_MB
+// (environment, default 2048; 0: no caching) of idle blocks per device; what does not fit goes back to the driver, and an
+// allocation that fails empties the cache and tries again.  The caller has finished with the block (its stream is drained).
+hipError_t index_block_alloc(void** p, size_t bytes);
+void index_block_free(void* p);
+void index_blocks_trim();  // every idle block of the current device back to the driver
 
 // pinned host memory of a handle: staging for small transfers (a query point in, one row out) that the device reads and
 // writes in place, so a single-query call issues no copy at all

@@ -4,7 +4,7 @@ usage: tools/collect_profiles.py r01"""
 import glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -25,6 +25,7 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("rebuild_10m_clustered.json", "rebuild_10m_clustered.json"), ("rebuild_10m_coarse.json", "rebuild_10m_coarse_order.json"),
                   ("rebuild_50m_coarse.json", "rebuild_50m_coarse_order.json"),
                   ("pmc_range/range_kernel_stats.txt", "range_kernel_stats.txt"), ("pmc_range/range_under_prof.json", "range_count_10m.json"),
+                  ("pmc_range_pos/range_under_prof.json", "range_count_10m_curve_positions.json"),
                   ("valu_issue_rates.txt", "valu_issue_rates.txt"), ("pmc_latency/latency_kernel_stats.txt", "latency_kernel_stats.txt"),
                   ("pmc_latency/latency_under_prof.json", "latency_under_rocprofv3.json"), ("filter_bench.json", "filter_bench.json"),
                   ("fuzz_filters.json", "fuzz_filters.json")):
@@ -48,7 +49,7 @@ if r50:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), r50[0]], capture_output=True, text=True).stdout
     open(os.path.join(dst, tag + "_rebuild_50m_kernel_stats.txt"), "w").write(
         "rocprofv3 --kernel-trace --stats -- python3 tools/rebuild_loop.py 5e7 5   (7 rebuilds of 50 M points, auto bounding box)\n" + txt)
-for sub, name in (("pmc_rebuild", "pmc_rebuild"), ("pmc_range", "pmc_range"), ("pmc_latency", "pmc_latency")):
+for sub, name in (("pmc_rebuild", "pmc_rebuild"), ("pmc_range", "pmc_range"), ("pmc_range_pos", "pmc_range_curve_positions"), ("pmc_latency", "pmc_latency")):
     f = os.path.join(src, sub, "pmc_summary.json")
     if os.path.exists(f):
         d = json.load(open(f))
@@ -83,5 +84,16 @@ if os.path.exists(pmc):
             "k_knn_hbm_bytes_per_launch": int((2 * f + w) * 1024),
             "k_knn_hbm_bytes_per_launch_uncorrected": int((f + w) * 1024),
             "algorithmic_bytes_per_launch": 84 * 10_000_000}, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
+pos = os.path.join(src, "pmc_pos", "pmc_summary.json")
+if os.path.exists(pos):
+    allk = json.load(open(pos))
+    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,false,false") or k == "k_knn"), {})
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        f, w = d["FETCH_SIZE"]["avg_per_dispatch"], d["WRITE_SIZE"]["avg_per_dispatch"]
+        json.dump({"workload": "uniform_10m_k15, rows and normals at curve positions (pcpx_knn_self_curve_order_dev)",
+                   "command": "tools/pmc_passes.sh ... -- python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --rows-at-curve-positions",
+                   "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "WRITE_bytes_per_launch": int(w * 1024),
+                   "payload_bytes_per_launch": 76 * 10_000_000,
+                   "counters": {c: round(v["avg_per_dispatch"], 1) for c, v in d.items()}}, open(os.path.join(dst, tag + "_pmc_rows_at_curve_positions.json"), "w"), indent=1)
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_issue_model.py"), tag], check=False)
 print("copied into", dst)

@@ -1,17 +1,20 @@
 #!/bin/bash
 # Collects every measurement DESIGN.md quotes, on the GPU box, into gpurun_out/<tag>/ :
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r03 [part]'      part: all (default) | knn | build | host
-# then, back in the container:  python3 tools/collect_profiles.py r03   (copies the summaries into profiles/)
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04 [part]'      part: all (default) | knn (= knn1 + knn2) | knn1 | knn2 | build | host
+#   (all of it does not fit one 20-minute call: knn1, knn2, host, build are four)
+# then, back in the container:  python3 tools/collect_profiles.py r04   (copies the summaries into profiles/)
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 part=${2:-all}
 out=gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-if [ "$part" = all ] || [ "$part" = knn ]; then
+if [ "$part" = all ] || [ "$part" = knn ] || [ "$part" = knn1 ]; then
 # 1. PMC passes of the bench command (separate runs per counter group, --kernel-trace only)
 bash tools/pmc_passes.sh "$out/pmc" --steps 3 --warmup 1 > "$out/pmc.txt" 2>&1 || { echo "pmc failed"; tail -5 "$out/pmc.txt"; }
 echo "pmc done"
+# 1b. the same launch with rows and normals written at curve positions (pcpx_knn_self_curve_order_dev): its memory-side bytes
+PMC_PASSES=5 bash tools/pmc_passes.sh "$out/pmc_pos" --steps 3 --warmup 1 --rows-at-curve-positions > "$out/pmc_pos.txt" 2>&1 || { echo "pmc (curve positions) failed"; tail -5 "$out/pmc_pos.txt"; }
 # (the HBM traffic file bench.py quotes under roofline.traffic is made from these passes before the bench line is taken)
 python3 tools/collect_profiles.py "$tag" > /dev/null 2>&1
 # 2. the bench line (default workload, CPU baseline included; --with-1m adds the configs[1] side figure)
@@ -24,6 +27,8 @@ echo "trace done"
 timeout -k 10 200 python3 tools/knn_stats.py 1e7 uniform 15 > "$out/stats_uniform.json" 2>> "$out/stats.err" &&
 timeout -k 10 200 python3 tools/knn_stats.py 1e7 clustered 15 > "$out/stats_clustered.json" 2>> "$out/stats.err" || echo "stats failed"
 echo "stats done"
+fi
+if [ "$part" = all ] || [ "$part" = knn ] || [ "$part" = knn2 ]; then
 # 5. other workloads: configs[3]'s cloud on one GPU, configs[4] streaming
 timeout -k 10 300 python3 bench.py --workload clustered_10m_k15 --no-cpu-baseline > "$out/bench_clustered_10m_k15.json" 2>> "$out/bench.err" || echo "clustered failed"
 timeout -k 10 300 python3 bench.py --workload uniform_10m_k8 --no-cpu-baseline --no-extra > "$out/bench_uniform_10m_k8.json" 2>> "$out/bench.err" || echo "k8 failed"
@@ -35,6 +40,7 @@ timeout -k 10 400 python3 tools/shard_rate.py uniform 5e7 32 stream > "$out/shar
 timeout -k 10 300 python3 tools/batch_query_rate.py > "$out/batch_query_rate.json" 2>> "$out/bench.err" || echo "batch failed"
 # configs[2]'s kernel: per-kernel time and counters
 bash tools/pmc_range.sh "$out/pmc_range" > "$out/pmc_range.txt" 2>&1 || echo "pmc range failed"
+RANGE_FORM=curve bash tools/pmc_range.sh "$out/pmc_range_pos" > "$out/pmc_range_pos.txt" 2>&1 || echo "pmc range (curve positions) failed"
 echo "range done"
 fi
 if [ "$part" = all ] || [ "$part" = host ]; then

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """configs[2]'s kernel alone (for rocprofv3 --kernel-trace --stats / --pmc): radius counts r = 0.01 around every point of the
-10 M uniform cloud, device resident.  usage: python tools/range_loop.py [n] [reps] [radius]"""
+10 M uniform cloud, device resident.  usage: python tools/range_loop.py [n] [reps] [radius]
+RANGE_FORM=curve in the environment: the counts are written at curve positions (pcpx_range_count_self_curve_order_dev)."""
 import importlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,12 +13,14 @@ pts = pkg.synthetic.uniform_cloud(n, 43)
 d = torch.from_numpy(pts).cuda()
 ix = pkg.Index.from_device(d.data_ptr(), n)
 cnt = torch.empty(n, dtype=torch.int32, device="cuda")
-ix.range_count_self_dev(r, cnt.data_ptr())
+curve = os.environ.get("RANGE_FORM") == "curve"
+call = ix.range_count_self_curve_order_dev if curve else ix.range_count_self_dev
+call(r, cnt.data_ptr())
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    ix.range_count_self_dev(r, cnt.data_ptr())
+    call(r, cnt.data_ptr())
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / reps
-print(json.dumps({"n": n, "radius": r, "range_count_ms": round(ms, 4), "mqps": round(n / ms / 1e3, 1), "mean_count": float(cnt.float().mean().item()),
+print(json.dumps({"n": n, "radius": r, "counts_at": "curve positions" if curve else "input indices", "range_count_ms": round(ms, 4), "mqps": round(n / ms / 1e3, 1), "mean_count": float(cnt.float().mean().item()),
                   "algorithmic_GBps": round(16 * n / ms / 1e6, 1)}))

@@ -52,5 +52,20 @@ try:
     out["scalar_pipe_frac"] = round(scalar / groups * SCALAR / available, 3)
 except Exception as e:  # counters not collected yet
     out["scalar_pipe_note"] = "no counters: %r" % (e,)
+if tag >= "r04":
+    # Round 4: the kernel no longer fits a one-pipe model (profiles/experiments/README.md, round 4: 19 % fewer vector instructions bought
+    # 3 %, the same count of scalar ones taken away bought 5 %, packed-float instructions nothing).  What is reported from round 4 on is
+    # the instruction mix per group from the counters and the cycles a SIMD has per group; the per-class vector model above is kept
+    # for rounds 1-3 only (its "point-per-lane leaf" class no longer exists: statistics [14] / [15] count the packed leaves now).
+    for k in ("valu_issue_cycles_per_group", "valu_issue_cycles_per_group_total", "valu_issue_frac", "note", "scalar_pipe_cycles_per_group", "scalar_pipe_frac"):
+        out.pop(k, None)
+    out["assumptions"].pop("short_compaction_share", None)
+    if "counters_per_group" in out:
+        out["instructions_per_group"] = sum(out["counters_per_group"].values())
+        out["simd_cycles_per_instruction_at_7_waves"] = round(available / out["instructions_per_group"], 2)
+    out["events_per_group"] = {k: st[k] for k in ("leaves", "expansions", "compactions", "seed_leaves", "seed_compactions", "sparse_leaves", "sparse_leaf_lanes") if k in st}
+    out["events_note"] = "diagnostic build (tools/knn_stats.py); sparse_leaves / sparse_leaf_lanes = the leaves looked at in the packed form and the lanes that needed them"
+    out["reading"] = ("a wave issues an instruction every ~4 cycles whatever its kind and its stream is largely dependent; with seven waves per SIMD the "
+                      "kernel's time follows the instructions per group, the scalar ones first (they wait on each other through SCC and the scalar registers)")
 json.dump(out, open(P("valu_issue_model.json"), "w"), indent=1)
 print(json.dumps(out))
