@@ -3,6 +3,8 @@
 // enqueue on the index's stream.  No CPU fallback exists: every compute call needs a HIP device.
 #include "pcpx_internal.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -209,6 +211,59 @@ void index_blocks_trim()
     c.idle.resize(keep);
 }
 
+namespace {
+struct IdleStreams {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;  // (device, stream)
+};
+IdleStreams& idle_streams()
+{
+    static IdleStreams* s = new IdleStreams();  // (never destroyed: the HIP runtime may be gone by the time statics are)
+    return *s;
+}
+}  // namespace
+
+hipError_t pooled_stream_get(hipStream_t* out)
+{
+    static const bool no_pool = std::getenv("PCPX_NO_STREAM_POOL") != nullptr;  // (diagnostic)
+    if (no_pool) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        IdleStreams& p = idle_streams();
+        std::lock_guard<std::mutex> lock(p.mu);
+        for (size_t i = 0; i < p.idle.size(); ++i)
+            if (p.idle[i].first == dev) {
+                *out = p.idle[i].second;
+                p.idle.erase(p.idle.begin() + static_cast<long>(i));
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void pooled_stream_put(hipStream_t s)
+{
+    if (!s) return;
+    if (std::getenv("PCPX_NO_STREAM_POOL") != nullptr) {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        IdleStreams& p = idle_streams();
+        std::lock_guard<std::mutex> lock(p.mu);
+        size_t here = 0;
+        for (auto const& e : p.idle) here += e.first == dev ? 1u : 0u;
+        if (here < 8) {
+            p.idle.emplace_back(dev, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 int PinnedStage::ensure(size_t need)
 {
     if (need <= bytes) return PCPX_OK;
@@ -286,6 +341,64 @@ DeviceShared& shared_of(int device)
     if (static_cast<size_t>(device) >= table.size()) table.resize(static_cast<size_t>(device) + 1, nullptr);
     if (!table[static_cast<size_t>(device)]) table[static_cast<size_t>(device)] = new DeviceShared();
     return *table[static_cast<size_t>(device)];
+}
+
+// Pageable host memory -> device on `stream`; the source may be reused when this returns (64 KB and more: the bytes have arrived).  hipMemcpy from a pageable buffer it has not seen before took 12-24 ms for 12 MB on this stack (0.5-1 GB/s: the 2^20-point
+// cloud of a construction; 200 MB take 4-7 ms), against 0.46 ms for a host memcpy of 12 MB plus 0.29 ms for the same copy from pinned
+// memory (tools/h2d_probe.hip, PCPX_TRACE_CREATE).  So copies of up to 64 MB go through a per-device ring of two pinned 4-MB blocks --
+// the host fills one while the other is on its way -- and larger ones are left to the runtime.
+namespace {
+struct Uploader {
+    std::mutex mu;
+    void* pin = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr size_t CHUNK = size_t(4) << 20;
+};
+Uploader& uploader_of(int device)
+{
+    static std::mutex table_mu;
+    static std::vector<Uploader*> table;  // never freed: the HIP runtime may be gone at exit
+    std::lock_guard<std::mutex> lock(table_mu);
+    if (static_cast<size_t>(device) >= table.size()) table.resize(static_cast<size_t>(device) + 1, nullptr);
+    if (!table[static_cast<size_t>(device)]) table[static_cast<size_t>(device)] = new Uploader();
+    return *table[static_cast<size_t>(device)];
+}
+}  // namespace
+
+int upload_pageable(void* d_dst, const void* src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return PCPX_OK;
+    if (bytes < (size_t(64) << 10)) {  // (a query or a few hundred: the runtime has taken its copy of a pageable source when this returns)
+        PCPX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return PCPX_OK;
+    }
+    static const bool no_ring = std::getenv("PCPX_NO_UPLOAD_RING") != nullptr;  // (diagnostic: leave every copy to the runtime)
+    if (no_ring || bytes > (size_t(64) << 20)) {
+        PCPX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return check_hip(hipStreamSynchronize(stream), "upload", __FILE__, __LINE__);
+    }
+    int dev = 0;
+    PCPX_HIP(hipGetDevice(&dev));
+    Uploader& u = uploader_of(dev);
+    std::lock_guard<std::mutex> lock(u.mu);
+    if (!u.pin) {
+        PCPX_HIP(hipHostMalloc(&u.pin, 2 * Uploader::CHUNK, hipHostMallocDefault));
+        PCPX_HIP(hipEventCreateWithFlags(&u.ev[0], hipEventDisableTiming));
+        PCPX_HIP(hipEventCreateWithFlags(&u.ev[1], hipEventDisableTiming));
+    }
+    const char* from = static_cast<const char*>(src);
+    char* to = static_cast<char*>(d_dst);
+    size_t piece = 0;
+    for (size_t off = 0; off < bytes; off += Uploader::CHUNK, ++piece) {
+        const size_t len = bytes - off < Uploader::CHUNK ? bytes - off : Uploader::CHUNK;
+        const int b = static_cast<int>(piece & 1);
+        char* stage = static_cast<char*>(u.pin) + static_cast<size_t>(b) * Uploader::CHUNK;
+        if (piece >= 2) PCPX_HIP(hipEventSynchronize(u.ev[b]));  // the copy that last read this block has finished
+        std::memcpy(stage, from + off, len);
+        PCPX_HIP(hipMemcpyAsync(to + off, stage, len, hipMemcpyHostToDevice, stream));
+        PCPX_HIP(hipEventRecord(u.ev[b], stream));
+    }
+    return check_hip(hipStreamSynchronize(stream), "upload", __FILE__, __LINE__);  // (before the ring is anyone else's)
 }
 
 int select_device(int device)
@@ -423,8 +536,11 @@ void free_index(Index* ix)
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
     free_shard(*ix);
-    if (ix->copy_stream) (void)hipStreamDestroy(ix->copy_stream);
-    if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
+    if (ix->copy_stream) {
+        (void)hipStreamSynchronize(ix->copy_stream);
+        pooled_stream_put(ix->copy_stream);
+    }
+    if (ix->own_stream && ix->stream) pooled_stream_put(ix->stream);  // (synchronised above)
     delete ix;  // (the pool and the pinned stage free their memory in their destructors, while the device is still current)
 }
 
@@ -476,16 +592,21 @@ static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_bui
     DeviceScope dscope;
     st = dscope.select(device);
     if (st != PCPX_OK) return st;
+    // PCPX_TRACE_CREATE=1 in the environment: the phases of a creation from host memory on stderr (where a construction's time goes)
+    static const bool trace = std::getenv("PCPX_TRACE_CREATE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     Index* ix = new (std::nothrow) Index();
     if (!ix) return PCPX_ERR_ALLOC;
     ix->device = device;
+    const double t_new = since();
     if (on_device) {
         // device-pointer form: work is enqueued on the CALLER's stream; NULL is the legacy default stream, which is
         // ordered against the caller's other default-stream work (a private stream would not be)
         ix->stream = static_cast<hipStream_t>(stream);
     } else {
         // host-pointer form: synchronous calls, so a private stream (no ordering against the caller's streams needed)
-        hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+        hipError_t e = pooled_stream_get(&ix->stream);
         if (e != hipSuccess) {
             delete ix;
             return check_hip(e, "hipStreamCreate", __FILE__, __LINE__);
@@ -496,15 +617,23 @@ static int create_common(const float* xyz, bool on_device, u64 n, const pcpx_bui
         // (inner scope: the staging block belongs to the handle's pool and must be gone before a failure path deletes the handle)
         DevBuf staged(ix->pool, true);
         const float* d_src = xyz;
+        const double t_stream = since();
+        double t_alloc = t_stream, t_copy = t_stream;
         if (!on_device && n > 0) {
             st = staged.alloc(n * 3 * sizeof(float));
-            if (st == PCPX_OK) st = check_hip(hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice), "H2D copy of points", __FILE__, __LINE__);
+            t_alloc = since();
+            if (st == PCPX_OK) st = upload_pageable(staged.p, xyz, n * 3 * sizeof(float), ix->stream);
+            t_copy = since();
             d_src = staged.as<float>();
         }
         if (st == PCPX_OK) st = build_index(*ix, d_src, n, params);
+        const double t_build = since();
         const std::string why = g_err;
         // (also on failure: work of a partial build may still be reading the staging block)
         const int sync = check_hip(hipStreamSynchronize(ix->stream), "build sync", __FILE__, __LINE__);
+        if (trace)
+            std::fprintf(stderr, "pcpx_index_create n=%llu: handle %.3f ms, stream %.3f, staging block %.3f, H2D %.3f, build enqueue (+ its allocations) %.3f, sync %.3f\n",
+                         static_cast<unsigned long long>(n), t_new, t_stream - t_new, t_alloc - t_stream, t_copy - t_alloc, t_build - t_copy, since() - t_build);
         if (st == PCPX_OK) st = sync;
         else g_err = why;
     }
@@ -541,7 +670,7 @@ int pcpx_index_rebuild(pcpx_index* h, const float* xyz, uint64_t n, const pcpx_b
     DevBuf staged(ix->pool, true);
     if (n > 0) {
         if ((st = staged.alloc(n * 3 * sizeof(float))) != PCPX_OK) return st;
-        PCPX_HIP(hipMemcpy(staged.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+        if ((st = upload_pageable(staged.p, xyz, n * 3 * sizeof(float), ix->stream)) != PCPX_OK) return st;
     }
     st = build_index(*ix, staged.as<float>(), n, params);
     const std::string why = g_err;
@@ -871,7 +1000,7 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
     if ((st = di.alloc(nq * k * sizeof(u32))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
     if (out_d2 && (st = dd.alloc(nq * k * sizeof(float))) != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    if ((st = upload_pageable(dq.p, q_xyz, nq * 3 * sizeof(float), ix->stream)) != PCPX_OK) return st;
     st = pcpx_knn_batch_dev(h, dq.as<float>(), nq, k, eps, di.as<u32>(), dc.as<u32>(), out_d2 ? dd.as<float>() : nullptr);
     if (st != PCPX_OK) return st;
     PCPX_HIP(hipMemcpyAsync(out_idx, di.p, nq * k * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
@@ -957,7 +1086,7 @@ int pcpx_range_count_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, float
     DevBuf dq(ix->pool), dc(ix->pool);
     if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    if ((st = upload_pageable(dq.p, q_xyz, nq * 3 * sizeof(float), ix->stream)) != PCPX_OK) return st;
     QueryView qv;
     if ((st = prepare_queries(*ix, dq.as<float>(), nq, qv)) != PCPX_OK) return st;
     if ((st = launch_range_count(*ix, qv, false, 0, (nq + GROUP - 1) / GROUP, radius, nullptr, dc.as<u32>())) != PCPX_OK)
@@ -1024,7 +1153,7 @@ int pcpx_range_sphere_batch(pcpx_index* h, const float* q_xyz, const float* radi
     DevBuf dq(ix->pool), dr(ix->pool), dc(ix->pool), doff(ix->pool), dout(ix->pool);
     if ((st = dq.alloc(nq * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = dc.alloc(nq * sizeof(u32))) != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(dq.p, q_xyz, nq * 3 * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    if ((st = upload_pageable(dq.p, q_xyz, nq * 3 * sizeof(float), ix->stream)) != PCPX_OK) return st;
     if (radii) {
         if ((st = dr.alloc(nq * sizeof(float))) != PCPX_OK) return st;
         PCPX_HIP(hipMemcpyAsync(dr.p, radii, nq * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -1242,7 +1371,7 @@ int pcpx_normals_knn_self_curve_order(pcpx_index* h, uint32_t k, float eps, floa
     const u64 rows = ix->n;  // inserted points only: a point outside the voxel grid has no position on the curve
     if (opt_out_position_of && ix->n != ix->n_in) std::memset(opt_out_position_of, 0xFF, ix->n_in * sizeof(u32));
     if (rows == 0) return PCPX_OK;
-    if (!ix->copy_stream) PCPX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+    if (!ix->copy_stream) PCPX_HIP(pooled_stream_get(&ix->copy_stream));
     DevBuf dn(ix->pool), di(ix->pool), dc(ix->pool), dinv(ix->pool);
     if (opt_out_normals && (st = dn.alloc(rows * 3 * sizeof(float))) != PCPX_OK) return st;
     if ((st = di.alloc(rows * k * sizeof(u32))) != PCPX_OK || (st = dc.alloc(rows * sizeof(u32))) != PCPX_OK) return st;
@@ -1709,7 +1838,7 @@ int pcpx_device_upload(void* d_dst, const void* src, uint64_t bytes, int device,
     DeviceScope dscope;
     int st = dscope.select(device);
     if (st != PCPX_OK) return st;
-    PCPX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    if ((st = upload_pageable(d_dst, src, bytes, static_cast<hipStream_t>(stream))) != PCPX_OK) return st;
     PCPX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return PCPX_OK;
 }

@@ -147,6 +147,12 @@ hipError_t index_block_alloc(void** p, size_t bytes);
 void index_block_free(void* p);
 void index_blocks_trim();  // every idle block of the current device back to the driver
 
+// Streams of handles, kept per device across handles: hipStreamCreate costs 8 ms on this stack and hipStreamDestroy 2 (measured:
+// tools/h2d_probe.hip) -- more than a 2^20-point index build with its upload.  A handle's private streams come from here and go
+// back drained (at most 8 idle per device; the rest are destroyed).
+hipError_t pooled_stream_get(hipStream_t* s);
+void pooled_stream_put(hipStream_t s);  // the caller has synchronised it
+
 // pinned host memory of a handle: staging for small transfers (a query point in, one row out) that the device reads and
 // writes in place, so a single-query call issues no copy at all
 struct PinnedStage {

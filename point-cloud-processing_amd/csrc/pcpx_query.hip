@@ -42,6 +42,7 @@ namespace pcpx {
 
 namespace {
 
+constexpr size_t STATS_EXTRA = 16 + 5 * 65536 - 8;  // diagnostic build: counters added in round 4 sit behind the per-wave records
 constexpr u64 PAD_KEY = 0x7F800000FFFFFFFFull;  // (+inf, INVALID): larger than every real key, a finite double
 
 // PAD_KEY in a fresh register pair: for the stores that refill buffer rows.  (As a plain constant hipcc hoists the pair out of
@@ -537,7 +538,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0, st_sparse = 0, st_owners = 0;
     // [7] shader cycles in the walker (pop + node expansions), [8] in compactions, [9] in leaf candidates,
     // [10] in the whole search loop, [11] whole group incl. the epilogue (id gather, tie repair, stores, fused normal)
-    unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0;
+    unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0, tc_later_mark = 0;
+    u32 st_later_lanes = 0;
     if (STATS) tc0 = __builtin_amdgcn_s_memtime();
 
     // ---- my query ----
@@ -756,6 +758,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         bitonic_merge<KCAP, NZ, LEAF>(best);
         tau = active ? fminf(__uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32)), cap) : -1.f;
     };
+    // (the seed leaves from the middle of the range outwards instead of in curve order -- the middle of the group's own chunk is near
+    //  most of its lanes -- was measured in round 4: no gain; profiles/experiments/README.md)
     for (u32 leaf = s0;; ++leaf) {
         const bool more = leaf < s1;
         if (direct_seeds && more && leaf + 1u != t.nleaves) {
@@ -930,7 +934,11 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
         const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         const bool failed = active && !(kth <= cap);
         if (!any_lane(failed)) break;
-        if (STATS) ++st_round2;
+        if (STATS) {
+            ++st_round2;
+            if (tc_later_mark == 0) tc_later_mark = __builtin_amdgcn_s_memtime();  // the group's later rounds start here
+            st_later_lanes += static_cast<u32>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(failed)));
+        }
         lo_d2 = cap;
         const NodeBox root = load_const(t.nodes);
         const float ex = root.hi(0) - root.lo(0), ey = root.hi(1) - root.lo(1), ez = root.hi(2) - root.lo(2);
@@ -971,6 +979,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             atomicAdd(&stats[8], tc_compact);
             atomicAdd(&stats[9], tc_leaf);
             atomicAdd(&stats[10], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tc0);  // search loop
+            // (behind the per-wave records: [STATS_EXTRA] cycles of the groups' walk rounds after the first, [+1] the lanes those rounds ran for)
+            if (tc_later_mark != 0) atomicAdd(&stats[STATS_EXTRA], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tc_later_mark);
+            atomicAdd(&stats[STATS_EXTRA + 1], static_cast<unsigned long long>(st_later_lanes));
         }
     }
 

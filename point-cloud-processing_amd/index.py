@@ -310,8 +310,10 @@ class Index:
                  "cycles_walk", "cycles_compact", "cycles_leaf", "cycles_search_loop", "cycles_group",
                  "seed_compactions", "seed_appended", "sparse_leaves", "sparse_leaf_lanes"]
         d = {n: int(out[i]) for i, n in enumerate(names)}
+        d["cycles_later_rounds"] = int(out[cap - 8])   # walk rounds after a group's first (lanes whose k-th distance lay beyond the cap)
+        d["lanes_in_later_rounds"] = int(out[cap - 7])
         if want_waves:
-            w = np.frombuffer(out, dtype=np.uint64)[16:].reshape(-1, 5)
+            w = np.frombuffer(out, dtype=np.uint64)[16:16 + 5 * 65534].reshape(-1, 5)  # (the last two records' words hold the round-4 counters)
             d["wave_times"] = w[w[:, 1] > 0].copy()
         return d
 

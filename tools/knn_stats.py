@@ -14,6 +14,7 @@ w = st["waves"]
 tot = max(1, st["cycles_group"])
 phases = {a[7:]: round(st[a] / tot, 4) for a in st if a.startswith("cycles_") and a != "cycles_group"}
 phases["epilogue"] = round(1.0 - st["cycles_search_loop"] / tot, 4)
+phases["later_rounds (part of the phases above)"] = round(st.get("cycles_later_rounds", 0) / tot, 4)
 phases["seed_cap_control"] = round((st["cycles_search_loop"] - st["cycles_walk"] - st["cycles_compact"] - st["cycles_leaf"]) / tot, 4)
 print(json.dumps({"n": n, "kind": kind, "k": k, "floor_mode": floor, **st, "per_group": {a: round(st[a] / w, 2) for a in st if a != "waves"},
                   "appended_per_query": round(st["appended"] / n, 2),
