@@ -517,14 +517,57 @@ struct MultiPass {
     u32 slot0 = 0;            // query slot of the first group of the launch
 };
 
+// The arguments of k_knn, one struct: the kernel's only parameter, so the struct IS the kernarg segment.  The tree, the group
+// range, eps and the queue are used all through a group and live in scalar registers; everything else -- the query arrays, k, where
+// the rows go, the multi-pass bookkeeping: ~50 dwords -- is needed for a few instructions at a group's start and in its epilogue.
+// Taken as ordinary parameters hipcc loads all of it at kernel entry, finds no registers for it across the persistent loop and parks
+// it in lanes of a VGPR (42-58 "SGPR spills" per kernel, ~100 v_readlane per group).  knn_group reads those fields through the
+// kernarg pointer instead (constant address space: scalar loads), made opaque where a group starts and where its epilogue starts so
+// that nothing read through it lives across the search.
+struct KnnArgs {
+    TreeView t;
+    QueryView qv;
+    u32 group_first, group_end, k;
+    float eps, eps_thr;
+    KnnOutputs o;
+    MultiPass mp;
+    u32* queue;
+    unsigned long long* stats;
+};
+typedef const __attribute__((address_space(4))) KnnArgs* knn_args_ptr;
+__device__ __forceinline__ knn_args_ptr knn_args_here()
+{
+    u64 a = reinterpret_cast<u64>(__builtin_amdgcn_kernarg_segment_ptr());
+    u32 lo = static_cast<u32>(a), hi = static_cast<u32>(a >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));  // (opaque: what is loaded through it from here on is loaded here, not at kernel entry)
+    return reinterpret_cast<knn_args_ptr>((static_cast<u64>(hi) << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T cold(const __attribute__((address_space(4))) T* field)
+{
+    static_assert(sizeof(T) % 4 == 0, "dwords");
+    T out;
+    u32* o = reinterpret_cast<u32*>(&out);
+    const __attribute__((address_space(4))) u32* c = reinterpret_cast<const __attribute__((address_space(4))) u32*>(field);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = c[i];
+    return out;
+}
+
 // One query group (64 curve-consecutive queries, one per lane) from start to finish.
 // NZ: the caller guarantees k <= KCAP - NZ (NZ sentinel slots at the bottom of the best-list hold 0 throughout)
 template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH, int NZ>
-__device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv, const u32 g, const u32 k_arg, const float eps,
-                                          const float eps_thr, const KnnOutputs& o, const MultiPass& mp, unsigned long long* __restrict__ stats,
-                                          u64* __restrict__ col, float* __restrict__ pub, const u32 lane)
+__device__ __forceinline__ void knn_group(const TreeView& t, const u32 g, const float eps, const float eps_thr,
+                                          unsigned long long* __restrict__ stats, u64* __restrict__ col, float* __restrict__ pub, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
+    // the cold arguments (KnnArgs), as this group's start sees them: dead before the search begins
+    const knn_args_ptr ka = knn_args_here();
+    const u32 k_arg = ka->k;
+    const u32 pos_lo = ka->o.pos_lo, pos_hi = ka->o.pos_hi;
+    MultiPass mp;
+    if (MULTI) mp = cold(&ka->mp);
+    const float* const known_d2 = STATS ? cold(&ka->o.d2) : nullptr;
     // k is made opaque per group: everything derived from it alone -- the initial best-list (slots below KCAP - k hold 0, the
     // others PAD_KEY) and the epilogue's per-slot predicates -- is otherwise a loop invariant of the persistent kernel and is
     // held in 4 x KCAP SGPRs from the first group to the last; the walk's own scalars then spill into VGPR lanes, and those
@@ -546,9 +589,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     u32 p_here = g * GROUP + lane;
     asm volatile("" : "+v"(p_here));  // (opaque: or the lane-only pieces of every address formed from p stay pinned in VGPR pairs across groups)
     const u32 p = p_here;
-    const u32 nq = SELF ? t.n : qv.nq;
+    const u32 nq = SELF ? t.n : ka->qv.nq;
     // (self queries: only the positions [pos_lo, pos_hi) the caller asked for -- a slice that starts or ends inside a group)
-    const bool valid = p < nq && (!SELF || p - o.pos_lo < o.pos_hi - o.pos_lo);
+    const bool valid = p < nq && (!SELF || p - pos_lo < pos_hi - pos_lo);
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (valid) {
         if (SELF) {
@@ -557,9 +600,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
             qy = lf.y[p % LEAF];
             qz = lf.z[p % LEAF];
         } else {
-            qx = qv.qx[p];
-            qy = qv.qy[p];
-            qz = qv.qz[p];
+            qx = cold(&ka->qv.qx)[p];
+            qy = cold(&ka->qv.qy)[p];
+            qz = cold(&ka->qv.qz)[p];
         }
     }
     // (the query's coordinates are waited for here, once: left pending, hipcc puts three s_waitcnt vmcnt in front of their first
@@ -580,7 +623,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // diagnostic build only: o.d2 holds the FINAL rows of an earlier run; starting from the true k-th distance
     // measures how much of the walk is spent before tau has tightened (the floor any visiting order can reach)
     float tau_known = inf;
-    if (STATS && o.d2 && valid && SELF) tau_known = o.d2[static_cast<u64>(t.leaves[p / LEAF].id[p % LEAF]) * k + (k - 1)];
+    if (STATS && known_d2 && valid && SELF) tau_known = known_d2[static_cast<u64>(t.leaves[p / LEAF].id[p % LEAF]) * k + (k - 1)];
     bool active = valid;             // lanes still searching (the second walk round keeps only the failed ones)
     int cnt = 0;
     const u32 col_addr = lds_address(col);  // byte address of row 0 of this lane's column
@@ -600,7 +643,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     // ---- seed range: the 64-point chunk at the group's own curve position ----
     u32 s0, s1;
     if (SELF) s0 = g * LEAVES_PER_GROUP;
-    else s0 = qv.seed[g];
+    else s0 = load_const(cold(&ka->qv.seed) + g);  // (a scalar load: through a plain pointer hipcc makes this wave-uniform read a vector load, and the seed loop with it)
     s1 = s0 + LEAVES_PER_GROUP < t.nleaves ? s0 + LEAVES_PER_GROUP : t.nleaves;
     if (s0 > s1) s0 = s1;
     // leaves before and after the group's own chunk that are also processed before the walk: they are curve neighbours the walk
@@ -986,7 +1029,10 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     }
 
     const int first_slot = KCAP - static_cast<int>(k);
+    // the cold arguments again, as the epilogue sees them (nothing read through `ka` above is alive any more)
+    const knn_args_ptr kb = knn_args_here();
     if (MULTI) {  // raw (d2, sorted position) keys of this pass; rows are built by k_assemble
+        const MultiPass mp = cold(&kb->mp);
         if (valid) {
             u64* dst = mp.keys + static_cast<u64>(p - mp.slot0) * mp.stride + mp.offset;
 #pragma unroll
@@ -1060,7 +1106,8 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const QueryView& qv
     asm volatile("" : "+s"(g_again));  // (or hipcc keeps the search's `p` for this: in scratch, in the k <= 16 kernel)
     u32 p_row = g_again * GROUP + lane;
     asm volatile("" : "+v"(p_row));
-    u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : qv.row[p_row];
+    const KnnOutputs o = cold(&kb->o);
+    u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : cold(&kb->qv.row)[p_row];
     if (SELF && o.by_position) row = p_row + o.pos_bias;
     if (SELF && o.tau) o.tau[p_row] = key_d2(best[KCAP - 1]);  // (+inf when the row holds fewer than k)
     u32 found = 0;
@@ -1154,9 +1201,14 @@ constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
 template <int KCAP, bool SELF, bool STATS, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS, int NZ = 0>
 __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
-    TreeView t, QueryView qv, u32 group_first, u32 group_end, u32 k, float eps, float eps_thr, KnnOutputs o, MultiPass mp,
-    u32* __restrict__ queue, unsigned long long* __restrict__ stats)
+    const KnnArgs a)
 {
+    // (the fields used all through a group; the others are read where they are needed: KnnArgs)
+    const TreeView t = a.t;
+    const u32 group_first = a.group_first, group_end = a.group_end;
+    const float eps = a.eps, eps_thr = a.eps_thr;
+    u32* const __restrict__ queue = a.queue;
+    unsigned long long* const __restrict__ stats = STATS ? a.stats : nullptr;
     constexpr int BUF = buf_rows(KCAP);
     extern __shared__ u64 lds[];
     const u32 lane = threadIdx.x & 63u;
@@ -1190,7 +1242,7 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
                 tg = __builtin_amdgcn_s_memrealtime();
                 tcg = __builtin_amdgcn_s_memtime();
             }
-            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, qv, group_first + qbeg + gi, k, eps, eps_thr, o, mp, stats, col, pub, lane);
+            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, group_first + qbeg + gi, eps, eps_thr, stats, col, pub, lane);
             if (STATS) {
                 if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
                 ++n_done;
@@ -1273,7 +1325,7 @@ static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcoun
     auto* fn = k_knn<KCAP, SELF, false, false, EPS_EACH, NZ>;
     const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WPB, lds, gcount, WPB);
     ProfileScope prof(ix, PCPX_K_KNN);
-    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr);
+    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr});
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
@@ -1385,8 +1437,8 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
         KnnOutputs range_only;  // (a pass writes keys, not rows; it still answers the asked positions only)
         range_only.pos_lo = o.pos_lo;
         range_only.pos_hi = o.pos_hi;
-        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr);
-        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr);
+        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr});
+        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr});
     }
     const u32 n32 = static_cast<u32>(nslots);
     if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
@@ -1440,8 +1492,8 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     float thr = eps_box_threshold(ix, sanitize_eps(eps));
     if (thr < 0.f) thr = std::numeric_limits<float>::infinity();
     k_knn<KCAP, true, true><<<pgrid, 64 * WPB, lds, ix.stream>>>(
-        ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), thr,
-        KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats);
+        KnnArgs{ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), thr,
+                KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats});
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 
