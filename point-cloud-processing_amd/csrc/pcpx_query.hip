@@ -1205,9 +1205,7 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
 {
     // (the fields used all through a group; the others are read where they are needed: KnnArgs)
     const TreeView t = a.t;
-    const u32 group_first = a.group_first, group_end = a.group_end;
     const float eps = a.eps, eps_thr = a.eps_thr;
-    u32* const __restrict__ queue = a.queue;
     unsigned long long* const __restrict__ stats = STATS ? a.stats : nullptr;
     constexpr int BUF = buf_rows(KCAP);
     extern __shared__ u64 lds[];
@@ -1222,35 +1220,42 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
 #pragma unroll
         for (int j = 0; j < BUF; ++j) col[j * 64] = pad;
     }
-    const u32 ngroups = group_end - group_first;
-    const u32 per = (ngroups + 7u) >> 3;
-    const u32 home = blockIdx.x & 7u;
     unsigned long long t_start = 0, t_max = 0, g_max = 0;
     u32 n_done = 0;
     if (STATS) t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock
-    for (u32 s = 0; s < 8u; ++s) {
-        const u32 q = (home + s) & 7u;
+    // The loop's only state is `s`, the number of queues this wave has seen run dry: the group range, the queue's address and the
+    // queue's share of the groups are read again through the kernarg pointer for every group (three scalar loads and a dozen scalar
+    // instructions per ~32 000), so that none of them sits in a spilled scalar register across the search.
+    for (u32 s = 0; s < 8u;) {
+        const knn_args_ptr ka = knn_args_here();
+        const u32 group_first = ka->group_first, group_end = ka->group_end;
+        u32* const queue = cold(&ka->queue);
+        const u32 ngroups = group_end - group_first;
+        const u32 per = (ngroups + 7u) >> 3;
+        const u32 q = (blockIdx.x + s) & 7u;
         const u32 qbeg = q * per;
         const u32 qend = qbeg + per < ngroups ? qbeg + per : ngroups;
-        for (;;) {
-            u32 gi = 0;
-            if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
-            gi = __builtin_amdgcn_readfirstlane(gi);
-            if (qbeg + gi >= qend) break;
-            unsigned long long tg = 0, tcg = 0;
-            if (STATS) {
-                tg = __builtin_amdgcn_s_memrealtime();
-                tcg = __builtin_amdgcn_s_memtime();
-            }
-            knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, group_first + qbeg + gi, eps, eps_thr, stats, col, pub, lane);
-            if (STATS) {
-                if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
-                ++n_done;
-                tg = __builtin_amdgcn_s_memrealtime() - tg;
-                if (tg > t_max) {
-                    t_max = tg;
-                    g_max = group_first + qbeg + gi;
-                }
+        u32 gi = 0;
+        if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        if (qbeg + gi >= qend) {
+            ++s;
+            continue;
+        }
+        unsigned long long tg = 0, tcg = 0;
+        if (STATS) {
+            tg = __builtin_amdgcn_s_memrealtime();
+            tcg = __builtin_amdgcn_s_memtime();
+        }
+        const u32 g = group_first + qbeg + gi;
+        knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, g, eps, eps_thr, stats, col, pub, lane);
+        if (STATS) {
+            if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
+            ++n_done;
+            tg = __builtin_amdgcn_s_memrealtime() - tg;
+            if (tg > t_max) {
+                t_max = tg;
+                g_max = g;
             }
         }
     }
