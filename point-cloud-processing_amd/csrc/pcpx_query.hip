@@ -557,10 +557,14 @@ __device__ __forceinline__ T cold(const __attribute__((address_space(4))) T* fie
 // One query group (64 curve-consecutive queries, one per lane) from start to finish.
 // NZ: the caller guarantees k <= KCAP - NZ (NZ sentinel slots at the bottom of the best-list hold 0 throughout)
 template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH, int NZ>
-__device__ __forceinline__ void knn_group(const TreeView& t, const u32 g, const float eps, const float eps_thr,
+__device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, const float eps, const float eps_thr,
                                           unsigned long long* __restrict__ stats, u64* __restrict__ col, float* __restrict__ pub, const u32 lane)
 {
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
+    // (the depth is made opaque per group, like k below: depth - 1, its multiples and the level masks are otherwise computed once
+    //  per kernel and parked in spilled scalar registers)
+    TreeView t = tree;
+    asm volatile("" : "+s"(t.depth), "+s"(t.nodes));
     // the cold arguments (KnnArgs), as this group's start sees them: dead before the search begins
     const knn_args_ptr ka = knn_args_here();
     const u32 k_arg = ka->k;
@@ -1029,10 +1033,9 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const u32 g, const 
     }
 
     const int first_slot = KCAP - static_cast<int>(k);
-    // the cold arguments again, as the epilogue sees them (nothing read through `ka` above is alive any more)
-    const knn_args_ptr kb = knn_args_here();
+    // (the cold arguments are read again where the epilogue needs them: nothing read through `ka` above is alive any more)
     if (MULTI) {  // raw (d2, sorted position) keys of this pass; rows are built by k_assemble
-        const MultiPass mp = cold(&kb->mp);
+        const MultiPass mp = cold(&knn_args_here()->mp);
         if (valid) {
             u64* dst = mp.keys + static_cast<u64>(p - mp.slot0) * mp.stride + mp.offset;
 #pragma unroll
@@ -1106,6 +1109,7 @@ __device__ __forceinline__ void knn_group(const TreeView& t, const u32 g, const 
     asm volatile("" : "+s"(g_again));  // (or hipcc keeps the search's `p` for this: in scratch, in the k <= 16 kernel)
     u32 p_row = g_again * GROUP + lane;
     asm volatile("" : "+v"(p_row));
+    const knn_args_ptr kb = knn_args_here();  // (here, not above the reordering loop: what is loaded through it is loaded where it is made)
     const KnnOutputs o = cold(&kb->o);
     u32 row = SELF ? t.leaves[p_row / LEAF].id[p_row % LEAF] : cold(&kb->qv.row)[p_row];
     if (SELF && o.by_position) row = p_row + o.pos_bias;
@@ -1235,8 +1239,9 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
         const u32 q = (blockIdx.x + s) & 7u;
         const u32 qbeg = q * per;
         const u32 qend = qbeg + per < ngroups ? qbeg + per : ngroups;
-        u32 gi = 0;
-        if (lane == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
+        u32 gi = 0, lane_here = lane;
+        asm volatile("" : "+v"(lane_here));  // (or the mask of "lane == 0" is one more pair of scalar registers held across the search)
+        if (lane_here == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
         gi = __builtin_amdgcn_readfirstlane(gi);
         if (qbeg + gi >= qend) {
             ++s;
