@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <memory>
 #include <new>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -129,18 +131,42 @@ inline void parallel_chunks(std::size_t n, unsigned chunks, F&& f, G&& meanwhile
     std::vector<std::thread> pool;
     pool.reserve(chunks - 1);
     auto piece = [n, chunks](unsigned c) { return static_cast<std::size_t>((static_cast<unsigned long long>(n) * c) / chunks); };
+    // an exception thrown by a piece (the caller's property map, an element's copy) reaches the caller as it would from the
+    // one-by-one loop: the first one caught is rethrown after every thread has been joined
+    std::exception_ptr failed;
+    std::mutex failed_mu;
+    auto guarded = [&](std::size_t first, std::size_t last, unsigned c) {
+        try
+        {
+            f(first, last, c);
+        }
+        catch (...)
+        {
+            std::lock_guard<std::mutex> lock(failed_mu);
+            if (!failed) failed = std::current_exception();
+        }
+    };
     unsigned started = 1;  // chunks [1, started) have a thread
     try
     {
-        for (; started < chunks; ++started) pool.emplace_back([&f, piece, c = started] { f(piece(c), piece(c + 1), c); });
+        for (; started < chunks; ++started) pool.emplace_back([&guarded, piece, c = started] { guarded(piece(c), piece(c + 1), c); });
     }
     catch (...)  // no more threads to be had: the calling thread takes the pieces that are left
     {
     }
-    meanwhile();
-    f(piece(0), piece(1), 0u);
-    for (unsigned c = started; c < chunks; ++c) f(piece(c), piece(c + 1), c);
+    try
+    {
+        meanwhile();
+    }
+    catch (...)
+    {
+        std::lock_guard<std::mutex> lock(failed_mu);
+        if (!failed) failed = std::current_exception();
+    }
+    guarded(piece(0), piece(1), 0u);
+    for (unsigned c = started; c < chunks; ++c) guarded(piece(c), piece(c + 1), c);
     for (auto& t : pool) t.join();
+    if (failed) std::rethrow_exception(failed);
 }
 template <class F>
 inline void parallel_chunks(std::size_t n, unsigned chunks, F&& f)

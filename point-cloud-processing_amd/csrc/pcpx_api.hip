@@ -381,24 +381,27 @@ int upload_pageable(void* d_dst, const void* src, size_t bytes, hipStream_t stre
     PCPX_HIP(hipGetDevice(&dev));
     Uploader& u = uploader_of(dev);
     std::lock_guard<std::mutex> lock(u.mu);
-    if (!u.pin) {
-        PCPX_HIP(hipHostMalloc(&u.pin, 2 * Uploader::CHUNK, hipHostMallocDefault));
-        PCPX_HIP(hipEventCreateWithFlags(&u.ev[0], hipEventDisableTiming));
+    if (!u.ev[1]) {  // (first use, or an earlier attempt that got part of the way)
+        if (!u.pin) PCPX_HIP(hipHostMalloc(&u.pin, 2 * Uploader::CHUNK, hipHostMallocDefault));
+        if (!u.ev[0]) PCPX_HIP(hipEventCreateWithFlags(&u.ev[0], hipEventDisableTiming));
         PCPX_HIP(hipEventCreateWithFlags(&u.ev[1], hipEventDisableTiming));
     }
     const char* from = static_cast<const char*>(src);
     char* to = static_cast<char*>(d_dst);
+    hipError_t e = hipSuccess;
     size_t piece = 0;
-    for (size_t off = 0; off < bytes; off += Uploader::CHUNK, ++piece) {
+    for (size_t off = 0; off < bytes && e == hipSuccess; off += Uploader::CHUNK, ++piece) {
         const size_t len = bytes - off < Uploader::CHUNK ? bytes - off : Uploader::CHUNK;
         const int b = static_cast<int>(piece & 1);
         char* stage = static_cast<char*>(u.pin) + static_cast<size_t>(b) * Uploader::CHUNK;
-        if (piece >= 2) PCPX_HIP(hipEventSynchronize(u.ev[b]));  // the copy that last read this block has finished
+        if (piece >= 2 && (e = hipEventSynchronize(u.ev[b])) != hipSuccess) break;  // the copy that last read this block has finished
         std::memcpy(stage, from + off, len);
-        PCPX_HIP(hipMemcpyAsync(to + off, stage, len, hipMemcpyHostToDevice, stream));
-        PCPX_HIP(hipEventRecord(u.ev[b], stream));
+        if ((e = hipMemcpyAsync(to + off, stage, len, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        e = hipEventRecord(u.ev[b], stream);
     }
-    return check_hip(hipStreamSynchronize(stream), "upload", __FILE__, __LINE__);  // (before the ring is anyone else's)
+    // whatever happened, the stream is drained before the ring is anyone else's (copies queued before a failure still read it)
+    const hipError_t drained = hipStreamSynchronize(stream);
+    return check_hip(e != hipSuccess ? e : drained, "upload", __FILE__, __LINE__);
 }
 
 int select_device(int device)

@@ -115,6 +115,26 @@ int main()
     CHECK(kd2.size() == n && kd2.coordinates()[3 * 777 + 2] == 0.f && kd2.coordinates()[3 * 777] == points[777].x());
     CHECK(kd2.aabb().min[0] == kd_box.min[0] && kd2.aabb().max[1] == kd_box.max[1]);
 
+    // ---- a property map that throws reaches the caller as it does from the one-by-one loop (not std::terminate from a thread) ----
+    {
+        struct refused {};
+        auto const throwing_map = [&points](std::uint64_t i) {
+            if (i == 222222u) throw refused{};
+            return points[i];
+        };
+        bool caught = false;
+        try
+        {
+            pcp::basic_linked_octree_t<std::uint64_t> never(ids.cbegin(), ids.cend(), throwing_map, params);
+            CHECK(never.size() == 0u && false);
+        }
+        catch (refused const&)
+        {
+            caught = true;
+        }
+        CHECK(caught);
+    }
+
     if (failures) return 1;
     std::printf("host capture: ok\n");
     return 0;
