@@ -305,6 +305,8 @@ class basic_linked_octree_t
         std::vector<std::vector<std::size_t>> outside(pieces);  // per piece: offsets of the points outside the grid, ascending
         auto const& grid = params_.voxel_grid;
         float* const dst = xyz_.data() + 3 * old;
+        try
+        {
         gpu::parallel_chunks(
             n, pieces,
             [&](std::size_t a, std::size_t b, unsigned c) {
@@ -322,6 +324,13 @@ class basic_linked_octree_t
             [&] {
                 if constexpr (!in_pieces) elements_.insert(elements_.end(), begin, begin + static_cast<diff_t>(n));
             });
+        }
+        catch (...)  // (a property map or an element's copy threw: the container is what it was before the call)
+        {
+            if (elements_.size() > old) elements_.erase(elements_.begin() + static_cast<std::ptrdiff_t>(old), elements_.end());
+            xyz_.resize(3 * old);
+            throw;
+        }
         dirty_ = true;
         std::vector<std::size_t> drop;
         for (auto const& o : outside) drop.insert(drop.end(), o.begin(), o.end());

@@ -133,6 +133,19 @@ int main()
             caught = true;
         }
         CHECK(caught);
+        // ... and insert() of such a range leaves the container as it was
+        pcp::basic_linked_octree_t<std::uint64_t> kept(params);
+        CHECK(kept.insert(ids[1], throwing_map));
+        caught = false;
+        try
+        {
+            kept.insert(ids.cbegin(), ids.cend(), throwing_map);
+        }
+        catch (refused const&)
+        {
+            caught = true;
+        }
+        CHECK(caught && kept.size() == 1u && kept.coordinates().size() == 3u && *kept.cbegin() == 1u);
     }
 
     if (failures) return 1;
