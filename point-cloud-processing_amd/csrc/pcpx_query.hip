@@ -236,7 +236,7 @@ __device__ __forceinline__ void static_for(F&& f)
 #ifndef PCPX_DEFER_EPS
 #define PCPX_DEFER_EPS 1
 #endif
-static_assert(!PCPX_DEFER_EPS || (PCPX_COMPACT_BY8 && PCPX_BY8_K32), "the deferred eps-box test lives in the chunk-of-8 compaction: compact() has none");
+static_assert(!PCPX_DEFER_EPS || (PCPX_COMPACT_BY8 * PCPX_BY8_K32 != 0), "the deferred eps-box test lives in the chunk-of-8 compaction: compact() has none");
 struct EpsFilter {
     bool on;
     float thr, eps, qx, qy, qz;
@@ -1296,6 +1296,8 @@ u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups
 int prepare_queue(Index& ix)
 {
     if (!ix.d_queue) PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix.d_queue), 8 * QUEUE_STRIDE * sizeof(u32)));
+    // (measured, round 4: the last wave out clearing the counters instead of this memset -- one dispatch per launch instead of two --
+    //  is SLOWER, 1.72 against 1.84 Gq/s at 1 M queries and 2.46 against 2.48 at 10 M: profiles/experiments/README.md)
     PCPX_HIP(hipMemsetAsync(ix.d_queue, 0, 8 * QUEUE_STRIDE * sizeof(u32), ix.stream));
     return PCPX_OK;
 }
