@@ -161,6 +161,24 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_PACKED_FREE
 #define PCPX_PACKED_FREE 3  // k <= 16 kernel: free rows every needing lane has when a packed leaf starts (0: LEAF of them, like the other forms -- no key can then find its column full).  The k <= 32 kernel always waits for LEAF rows: its fold is twice the network, and what the optimistic fill loses there it does not win back (measured)
 #endif
+// Wave priorities (s_setprio) by phase of a group.  A fold is ~130 vector instructions back to back that wait for nothing; the
+// walk and the leaf forms are short runs of arithmetic between loads whose round trips are what a wave's time is made of.  With the
+// fold at a LOWER priority than the rest, a SIMD's issue slots go first to the waves that are about to issue a load, and the folds
+// fill what is left: +2 % at k = 15 (uniform and clustered), +5 % at k = 32 (four waves per SIMD: fewer to hide a round trip
+// behind), +1 % at k = 8.  The other way round (fold raised) -3 ... -6 %; a lower priority for the epilogue or the dense leaves
+// as well: nothing, or -1 % at k = 8; base 3 instead of 1: the same (only the order matters).  profiles/experiments/README.md.
+#ifndef PCPX_PRIO_BASE
+#define PCPX_PRIO_BASE 1
+#endif
+#ifndef PCPX_PRIO_FOLD
+#define PCPX_PRIO_FOLD 0
+#endif
+#ifndef PCPX_PRIO_DENSE
+#define PCPX_PRIO_DENSE PCPX_PRIO_BASE
+#endif
+#ifndef PCPX_PRIO_EPI
+#define PCPX_PRIO_EPI PCPX_PRIO_BASE
+#endif
 #ifndef PCPX_KNN_WPB16
 #define PCPX_KNN_WPB16 4  // waves per workgroup of the k <= 16 kernel: its 11 rows x 512 B per wave fill the LDS allocation granule
                           // (1280 B) only in fours -- 7 waves per SIMD need <= 5851 B per wave
@@ -565,6 +583,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     //  per kernel and parked in spilled scalar registers)
     TreeView t = tree;
     asm volatile("" : "+s"(t.depth), "+s"(t.nodes));
+    if (PCPX_PRIO_BASE != PCPX_PRIO_EPI || PCPX_PRIO_BASE != PCPX_PRIO_FOLD || PCPX_PRIO_BASE != PCPX_PRIO_DENSE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
     // the cold arguments (KnnArgs), as this group's start sees them: dead before the search begins
     const knn_args_ptr ka = knn_args_here();
     const u32 k_arg = ka->k;
@@ -682,8 +701,10 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     auto fold = [&](bool in_seed_phase) {
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
         if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
+        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_FOLD);
         if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF, NZ>(best, col, cnt, eps_filter);
         else compact<KCAP, BUF>(best, col, cnt);
+        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         tau = active ? fminf(nt, cap) : -1.f;
         if (STATS) tau = fminf(tau, tau_known);
@@ -710,6 +731,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         }
         const Leaf lf = load_const(t.leaves + leaf);  // (a vector-memory fetch of the record measured the same)
         const u32 posbase = leaf * LEAF;
+        if (PCPX_PRIO_DENSE != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_DENSE);
         // copies of the candidate loop, switched per leaf (hipcc otherwise re-tests the mode per point)
         if (fast && eps_filter.on && !shell && !STATS) {
             u32 posv = posbase;
@@ -775,6 +797,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                 if (STATS) st_app += acc ? 1u : 0u;
             }
         }
+        if (PCPX_PRIO_DENSE != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         if (STATS) {
             asm volatile("" ::"v"(wa), "v"(cnt));
             tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
@@ -1033,6 +1056,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     }
 
     const int first_slot = KCAP - static_cast<int>(k);
+    if (PCPX_PRIO_EPI != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_EPI);
     // (the cold arguments are read again where the epilogue needs them: nothing read through `ka` above is alive any more)
     if (MULTI) {  // raw (d2, sorted position) keys of this pass; rows are built by k_assemble
         const MultiPass mp = cold(&knn_args_here()->mp);
