@@ -173,6 +173,9 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_PRIO_FOLD
 #define PCPX_PRIO_FOLD 0
 #endif
+#ifndef PCPX_PRIO_WALK
+#define PCPX_PRIO_WALK PCPX_PRIO_BASE
+#endif
 #ifndef PCPX_PRIO_DENSE
 #define PCPX_PRIO_DENSE PCPX_PRIO_BASE
 #endif
@@ -931,6 +934,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         for (;;) {
             if (direct == 0) {
                 if (wk.done()) break;
+                if (PCPX_PRIO_WALK != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_WALK);
                 u32 node;
                 const int h = wk.pop(node);
                 ++st_expand;
@@ -945,6 +949,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                     direct = 1u << (node & (W - 1u));
                     direct_first = node & ~(W - 1u);
                 }
+                if (PCPX_PRIO_WALK != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
             }
             while (direct != 0) {
                 u32 loc;

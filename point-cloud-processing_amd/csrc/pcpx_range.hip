@@ -9,6 +9,14 @@
 #define PCPX_RANGE_PACKED_LEAVES 16  // count form: a leaf that at most this many lanes need is counted eight needing lanes x eight points at a time (0: off; <= 32: one 512-B row of LDS per wave)
 #endif
 
+// Wave priority by phase, as in k_knn (pcpx_query.hip): the dense leaf's 88 vector instructions run at a lower priority than the walk
+// and the packed leaves (2.238 -> 2.212 ms per 10 M counts; the dense leaf raised instead: 2.25)
+#ifndef PCPX_RANGE_PRIO_BASE
+#define PCPX_RANGE_PRIO_BASE 1
+#endif
+#ifndef PCPX_RANGE_PRIO_DENSE
+#define PCPX_RANGE_PRIO_DENSE 0
+#endif
 namespace pcpx {
 
 namespace {
@@ -52,12 +60,14 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
     float r = radius;
     if (radii && valid) r = radii[row];
     const float r2 = valid ? r * r : -1.f;  // sphere.hpp:34 radius * radius in float; -1: idle lane
+    if (PCPX_RANGE_PRIO_BASE != 0) __builtin_amdgcn_s_setprio(PCPX_RANGE_PRIO_BASE);
     u32 cnt = 0;
     u64 wpos = (FILL && valid) ? offsets[row] : 0;
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
 
     auto leaf_record_points = [&](const Leaf& lf) {
         if (!FILL) {
+            if (PCPX_RANGE_PRIO_DENSE != PCPX_RANGE_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_RANGE_PRIO_DENSE);
             // count: the eight "inside" masks first (a scalar register pair each), then eight add-with-carry -- from
             // `cnt += in` hipcc pairs the points up as compare, select 0/1 under VCC, compare, add-with-carry, and the select
             // under a VCC that a compare has just written issues in 23 cycles on gfx950 (profiles/r03_valu_issue_rates.txt)
@@ -76,6 +86,7 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
                 : "+v"(cnt), "=&s"(carry_out)
                 : "s"(inside[0]), "s"(inside[1]), "s"(inside[2]), "s"(inside[3]), "s"(inside[4]), "s"(inside[5]), "s"(inside[6]),
                   "s"(inside[7]));
+            if (PCPX_RANGE_PRIO_DENSE != PCPX_RANGE_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_RANGE_PRIO_BASE);
             return;
         }
 #pragma unroll
