@@ -173,6 +173,9 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_PRIO_FOLD
 #define PCPX_PRIO_FOLD 0
 #endif
+#ifndef PCPX_PRIO_PACKED
+#define PCPX_PRIO_PACKED 2  // the packed leaf (three dependent LDS round trips on top of its loads) one step above the rest: +0.8 % (five rounds)
+#endif
 #ifndef PCPX_PRIO_WALK
 #define PCPX_PRIO_WALK PCPX_PRIO_BASE
 #endif
@@ -872,6 +875,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) -> u64 {
         float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
         u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
+        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_PACKED);
         u32 lane_here = lane;
         asm volatile("" : "+v"(lane_here));  // (or everything below that depends on the lane alone sits in registers from group to group)
         const u32 j = lane_here & 7u, i = lane_here >> 3;
@@ -904,6 +908,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             reinterpret_cast<float*>(pub_q + r)[3] = -1.f;
         }
         __builtin_amdgcn_wave_barrier();
+        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         if (packed_free == 0) {
             wa = now;
             return 0ull;
