@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define PCPX_ABI_VERSION 4
+#define PCPX_ABI_VERSION 5
 
 typedef enum pcpx_status {
     PCPX_OK = 0,
@@ -96,8 +96,13 @@ typedef struct pcpx_index pcpx_index; /* opaque: device buffers + stream */
                                       the handle is rebuilt or destroyed.  Without the flag the handle copies, like the       \
                                       reference's containers do (linked_kdtree.hpp:107).                                   */
 
+#define PCPX_BUILD_SHARD_RANGE 16u /* with PCPX_BUILD_SHARD: the shard is curve positions [shard_first, shard_first + shard_count) of the   \
+                                      whole cloud's order (shard_first a multiple of 64; clipped to the cloud) instead of                 \
+                                      pcpx_shard_range(shard_rank, shard_world) -- the cut of pcpx_shard_cuts_by_cost, which gives        \
+                                      every rank the same WORK rather than the same number of queries.                                 */
+
 typedef struct pcpx_build_params {
-    uint32_t struct_size; /* = sizeof(pcpx_build_params) (callers built against ABI 3 pass its first 32 bytes: accepted) */
+    uint32_t struct_size; /* = sizeof(pcpx_build_params) (callers built against ABI 3 / 4 pass its first 32 / 48 bytes: accepted) */
     uint32_t flags;
     float grid_min[3];
     float grid_max[3];
@@ -106,6 +111,9 @@ typedef struct pcpx_build_params {
     uint32_t shard_world;
     uint32_t shard_k_hint; /* the k the shard will be asked for: sizes the halo (0 = 32).  Only a performance hint. */
     uint32_t reserved;     /* 0 */
+    /* PCPX_BUILD_SHARD_RANGE */
+    uint64_t shard_first;
+    uint64_t shard_count;
 } pcpx_build_params;
 
 int pcpx_abi_version(void);
@@ -150,6 +158,14 @@ int pcpx_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_fi
                       uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
 int pcpx_knn_batch_dev(pcpx_index* idx, const float* d_q_xyz, uint64_t nq, uint32_t k, float eps,
                        uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
+/* pcpx_knn_self_dev with `row_stride` entries between the rows of d_out_idx / d_out_d2 (0: k; otherwise >= k, k <= 32; entries
+ * k .. row_stride of a row are 0xFFFFFFFF / +inf).  The reference returns one std::vector per query
+ * (include/pcp/octree/linked_octree.hpp:245-254), so the row pitch is this library's to choose: with row_stride = 16 (k = 15 or 16;
+ * 8 for k = 7, 8; 32 for k = 31, 32) and outputs aligned to 16 bytes a row is ONE aligned 64-byte piece, written with 16-byte
+ * stores.  Packed 60-byte rows scattered by input index cost every partial 32-byte sector twice at the memory side (read for
+ * ownership + write back): 1.57 GB written per 10 M queries for 0.76 GB of payload (profiles/r04_hbm_traffic.json). */
+int pcpx_knn_self_strided_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                              uint32_t row_stride, uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2);
 /* Rows by CURVE POSITION, device resident (additive): row p of every output belongs to the p-th point of the curve order,
  * i.e. to input point perm[p] (pcpx_index_perm_dev); neighbour indices inside the rows are input indices as everywhere.
  * A wavefront's 64 rows are then one contiguous piece of each output (the input-order form scatters 60-byte rows over the
@@ -200,6 +216,10 @@ int pcpx_normals_knn_self_curve_order(pcpx_index* idx, uint32_t k, float eps, fl
 int pcpx_normals_knn_self_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first,
                               uint64_t sorted_count, float* d_out_normals, uint32_t* d_opt_out_idx,
                               uint32_t* d_opt_out_count);
+/* The same with a row pitch (see pcpx_knn_self_strided_dev). */
+int pcpx_normals_knn_self_strided_dev(pcpx_index* idx, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
+                                      uint32_t row_stride, float* d_out_normals, uint32_t* d_opt_out_idx,
+                                      uint32_t* d_opt_out_count);
 /* ---- tangent planes / mean neighbour distance (the callers right next to the normal loop) -------- */
 /* estimate_tangent_planes (include/pcp/algorithm/estimate_tangent_planes.hpp:50-98): plane of point i =
  * (center_of_geometry of its k nearest neighbours, include/pcp/common/vector3d_queries.hpp:77-99; their PCA
@@ -308,6 +328,21 @@ int pcpx_device_trim(int device);
 /* Contiguous, 64-aligned shard of the curve-sorted query order for `rank` of `world`. */
 int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_first, uint64_t* out_count);
 
+/* Shards of equal WORK.  Equal numbers of queries are not equal work on a clustered cloud (BASELINE configs[3]: the slowest of
+ * eight equal-count shards takes 14 % longer than their mean).  pcpx_knn_group_costs_dev runs the k-NN walk (no rows are written)
+ * for one query group in every `group_stride` of the whole cloud's curve order -- group i * stride + stride / 2 stands for groups
+ * [i * stride, (i + 1) * stride) -- on a WHOLE-CLOUD handle and leaves four event counts per sampled group in d_out_events
+ * ({node expansions, leaves looked at lane-per-query, leaves looked at in the packed form, folds << 16 | packed steps}):
+ * integers that depend on the cloud, the grid and (k, eps) alone, so every rank of a job computes the same table from its
+ * replica of the cloud, and the all-gather of the boxes stays the only collective.  *out_samples = groups / group_stride
+ * (PCPX_ERR_CAPACITY if `capacity` samples do not hold them; d_out_events may be NULL to ask).  1 <= k <= 32.
+ * pcpx_shard_cuts_by_cost (host arrays) turns the table into world + 1 positions: rank r answers
+ * [out_first[r], out_first[r + 1]) -- multiples of 64 -- e.g. through PCPX_BUILD_SHARD_RANGE. */
+int pcpx_knn_group_costs_dev(pcpx_index* idx, uint32_t k, float eps, uint32_t group_stride, uint32_t* d_out_events,
+                             uint64_t capacity, uint64_t* out_samples);
+int pcpx_shard_cuts_by_cost(uint64_t n, uint32_t world, uint32_t group_stride, const uint32_t* events, uint64_t nsamples,
+                            uint64_t* out_first);
+
 /* The path's one collective -- an RCCL all-gather of the per-rank bounding boxes (6 floats = 24 B per rank over
  * xGMI) -- behind the ABI, so that a C++ host of the drop-in headers has the multi-GPU path too.  The reference has
  * no counterpart (it is single-process).  Sequence per rank: communicator (either created here from an id that rank 0
@@ -360,6 +395,14 @@ int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t* out_s
  * default), 1 = on buffered keys when they are folded into the best-list, 2 = on every candidate.  Results are the same;
  * the tests run all three. */
 int pcpx_debug_eps_test_mode(pcpx_index* idx, int mode);
+/* Switches of the handle that change how work is done, never what comes out (the tests run both sides of each):
+ * "long_groups_first" (default 1): a self-kNN launch that repeats the previous one's question on the same tree hands its query
+ * groups out by the times that launch recorded, the longest first; "gather_outputs" (default 1): input-order normals and counts
+ * are written at curve positions and permuted by a gather instead of being scattered from the search kernel. */
+int pcpx_debug_set(pcpx_index* idx, const char* name, int64_t value);
+/* What the handle's last recorded self-kNN launch took per query group (shader-clock ticks / 64, search only; host array of
+ * *out_groups entries, the launch's groups in curve order; 0 groups: nothing recorded).  PCPX_ERR_CAPACITY reports the size. */
+int pcpx_debug_group_times(pcpx_index* idx, uint32_t* out_ticks, uint64_t capacity, uint64_t* out_groups);
 /* Diagnostic access to the build's radix sort: stable sort of 64-bit words by their bits [first_bit, 64)
  * (first_bit a multiple of 8): words that agree on those bits keep their input order. */
 int pcpx_debug_sort_keys(const uint64_t* keys, uint64_t n, int first_bit, int device, uint64_t* out_keys);

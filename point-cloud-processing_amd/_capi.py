@@ -10,7 +10,7 @@ f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 
-ABI_VERSION = 4  # include/pcpx.h PCPX_ABI_VERSION
+ABI_VERSION = 5  # include/pcpx.h PCPX_ABI_VERSION
 PCPX_OK = 0
 PCPX_ERR_INVALID = -1
 PCPX_ERR_DEVICE = -2
@@ -21,13 +21,14 @@ PCPX_BUILD_USE_GRID = 1
 PCPX_BUILD_COARSE_ORDER = 2
 PCPX_BUILD_SHARD = 4
 PCPX_BUILD_BORROW_CLOUD = 8
+PCPX_BUILD_SHARD_RANGE = 16
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 
 class BuildParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("grid_min", C.c_float * 3),
                 ("grid_max", C.c_float * 3), ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32),
-                ("shard_k_hint", C.c_uint32), ("reserved", C.c_uint32)]
+                ("shard_k_hint", C.c_uint32), ("reserved", C.c_uint32), ("shard_first", C.c_uint64), ("shard_count", C.c_uint64)]
 
 
 class Profile(C.Structure):
@@ -69,6 +70,14 @@ SIGNATURES = {
                                  C.c_void_p]),
     "pcpx_knn_self_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    "pcpx_knn_self_strided_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
+    "pcpx_normals_knn_self_strided_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]),
+    "pcpx_knn_group_costs_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_uint64, u64p]),
+    "pcpx_shard_cuts_by_cost": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p]),
+    "pcpx_debug_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "pcpx_debug_group_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "pcpx_knn_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "pcpx_range_count_self": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),

@@ -476,12 +476,13 @@ int no_throw(const char* what, Body&& body)
 }
 
 // pcpx_build_params as this library knows it, from what the caller passed: ABI 3 callers pass the first 32 bytes
-constexpr size_t BUILD_PARAMS_ABI3 = 32;
+constexpr size_t BUILD_PARAMS_ABI3 = 32, BUILD_PARAMS_ABI4 = 48;  // (ABI 4 ends before shard_first / shard_count)
 int normalise_params(const pcpx_build_params* in, bool device_form, pcpx_build_params& out, const pcpx_build_params*& use)
 {
     use = nullptr;
     if (!in) return PCPX_OK;
-    if (in->struct_size != sizeof(pcpx_build_params) && in->struct_size != BUILD_PARAMS_ABI3) {
+    static_assert(sizeof(pcpx_build_params) == 64, "pcpx_build_params is part of the ABI");
+    if (in->struct_size != sizeof(pcpx_build_params) && in->struct_size != BUILD_PARAMS_ABI3 && in->struct_size != BUILD_PARAMS_ABI4) {
         set_error("pcpx: params->struct_size mismatch");
         return PCPX_ERR_INVALID;
     }
@@ -489,6 +490,11 @@ int normalise_params(const pcpx_build_params* in, bool device_form, pcpx_build_p
     std::memcpy(&out, in, in->struct_size);
     out.struct_size = sizeof(pcpx_build_params);
     if (in->struct_size == BUILD_PARAMS_ABI3) out.flags &= (PCPX_BUILD_USE_GRID | PCPX_BUILD_COARSE_ORDER);
+    if (in->struct_size == BUILD_PARAMS_ABI4) out.flags &= ~PCPX_BUILD_SHARD_RANGE;
+    if ((out.flags & PCPX_BUILD_SHARD_RANGE) && (!(out.flags & PCPX_BUILD_SHARD) || out.shard_first % GROUP != 0)) {
+        set_error("pcpx: PCPX_BUILD_SHARD_RANGE goes with PCPX_BUILD_SHARD, and shard_first must be a multiple of %d", GROUP);
+        return PCPX_ERR_INVALID;
+    }
     if ((out.flags & PCPX_BUILD_BORROW_CLOUD) && !device_form) {
         set_error("pcpx: PCPX_BUILD_BORROW_CLOUD needs a device-pointer build (the host-pointer forms stage the cloud in a temporary)");
         return PCPX_ERR_INVALID;
@@ -536,6 +542,10 @@ void free_index(Index* ix)
     index_block_free(ix->d_nodes);
     index_block_free(ix->d_scalars);
     index_block_free(ix->d_scratch);
+    index_block_free(ix->d_nc4);
+    index_block_free(ix->d_pos_of);
+    (void)hipFree(ix->sched.d_gtime);
+    (void)hipFree(ix->sched.d_order);
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
     free_shard(*ix);
@@ -788,6 +798,12 @@ int pcpx_bounding_box(const float* xyz, uint64_t n, int device, float out6[6])
 int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
                       uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2)
 {
+    return pcpx_knn_self_strided_dev(h, k, eps, sorted_first, sorted_count, 0, d_out_idx, d_out_count, d_out_d2);
+}
+
+int pcpx_knn_self_strided_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count, uint32_t row_stride,
+                              uint32_t* d_out_idx, uint32_t* d_out_count, float* d_out_d2)
+{
     Index* ix = reinterpret_cast<Index*>(h);
     DeviceScope dscope;
     int st = dscope.use(ix);
@@ -803,6 +819,11 @@ int pcpx_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_firs
     o.idx = d_out_idx;
     o.cnt = d_out_count;
     o.d2 = d_out_d2;
+    if (row_stride != 0 && (row_stride < k || k > 32)) {
+        set_error("pcpx_knn_self_strided_dev: row_stride must be 0 or >= k, and k <= 32");
+        return PCPX_ERR_INVALID;
+    }
+    o.row_stride = row_stride;
     if (ix->shard.on) return shard_knn_self(*ix, sorted_first, sorted_count, k, eps, o);
     u64 gf, gc;
     slice_to_groups(*ix, sorted_first, sorted_count, gf, gc);
@@ -1230,8 +1251,59 @@ int pcpx_range_aabb_batch(pcpx_index* h, const float* boxes6, uint64_t nb, uint6
 }
 
 // ---- normals -------------------------------------------------------------------------------------
+namespace pcpx {
+namespace {
+// d_pos_of (input index -> curve position) and d_nc4 ({normal, count} per curve position) of a whole-cloud handle, made on demand:
+// what the gather-form permute of the input-order normals needs.  PCPX_ERR_ALLOC leaves the handle as it was (the caller takes the
+// direct form).
+int ensure_gather_arrays(Index& ix)
+{
+    if (ix.n_in > ix.pos_of_cap || !ix.d_pos_of) {
+        PCPX_HIP(hipStreamSynchronize(ix.stream));
+        index_block_free(ix.d_pos_of);
+        ix.d_pos_of = nullptr;
+        ix.pos_of_cap = 0;
+        ix.pos_of_valid = false;
+        void* p = nullptr;
+        if (index_block_alloc(&p, (ix.n_in ? ix.n_in : 1) * sizeof(u32)) != hipSuccess) {
+            (void)hipGetLastError();
+            return PCPX_ERR_ALLOC;
+        }
+        ix.d_pos_of = static_cast<u32*>(p);
+        ix.pos_of_cap = ix.n_in;
+    }
+    if (ix.n > ix.nc4_cap || !ix.d_nc4) {
+        PCPX_HIP(hipStreamSynchronize(ix.stream));
+        index_block_free(ix.d_nc4);
+        ix.d_nc4 = nullptr;
+        ix.nc4_cap = 0;
+        void* p = nullptr;
+        if (index_block_alloc(&p, (ix.n ? ix.n + GROUP : GROUP) * sizeof(float4)) != hipSuccess) {
+            (void)hipGetLastError();
+            return PCPX_ERR_ALLOC;
+        }
+        ix.d_nc4 = static_cast<float4*>(p);
+        ix.nc4_cap = ix.n;
+    }
+    if (!ix.pos_of_valid) {
+        PCPX_HIP(hipMemsetAsync(ix.d_pos_of, 0xFF, ix.n_in * sizeof(u32), ix.stream));
+        int st = ix.n ? launch_invert_perm(ix.d_perm, ix.n, ix.d_pos_of, ix.stream) : PCPX_OK;
+        if (st != PCPX_OK) return st;
+        ix.pos_of_valid = true;
+    }
+    return PCPX_OK;
+}
+}  // namespace
+}  // namespace pcpx
+
 int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count,
                               float* d_out_normals, uint32_t* d_opt_out_idx, uint32_t* d_opt_out_count)
+{
+    return pcpx_normals_knn_self_strided_dev(h, k, eps, sorted_first, sorted_count, 0, d_out_normals, d_opt_out_idx, d_opt_out_count);
+}
+
+int pcpx_normals_knn_self_strided_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sorted_first, uint64_t sorted_count, uint32_t row_stride,
+                                      float* d_out_normals, uint32_t* d_opt_out_idx, uint32_t* d_opt_out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);
     DeviceScope dscope;
@@ -1251,12 +1323,30 @@ int pcpx_normals_knn_self_dev(pcpx_index* h, uint32_t k, float eps, uint64_t sor
     o.idx = d_opt_out_idx;
     o.cnt = d_opt_out_count;
     o.normals = d_out_normals;
+    if (row_stride != 0 && (row_stride < k || k > 32)) {
+        set_error("pcpx_normals_knn_self_strided_dev: row_stride must be 0 or >= k, and k <= 32");
+        return PCPX_ERR_INVALID;
+    }
+    o.row_stride = row_stride;
     if (ix->shard.on) {
         if (k > 32 && (!o.idx || !o.cnt)) {
             set_error("pcpx_normals_knn_self_dev: a rank-local index with k > 32 needs the row outputs too");
             return PCPX_ERR_UNSUPPORTED;
         }
         return shard_knn_self(*ix, sorted_first, sorted_count, k, eps, o);
+    }
+    // Input-order normals (+ counts) by the gather-form permute: the kernel leaves {normal, count} at the query's CURVE position (one
+    // contiguous kilobyte per wave) and k_gather_nc4 takes them to input order with coalesced writes.  Written straight to row
+    // perm[p] they are 12 + 4 bytes scattered over the whole output: every store instruction touches 64 lines, and every partial
+    // 32-byte sector is read for ownership and written back.
+    if (ix->tuning.gather && k <= 32 && gc > 0 && ensure_gather_arrays(*ix) == PCPX_OK) {
+        o.nc4 = ix->d_nc4;
+        o.normals = nullptr;
+        o.cnt = nullptr;
+        if ((st = launch_knn(*ix, qv, true, gf, gc, k, eps, o)) != PCPX_OK) return st;
+        u64 lo = sorted_first > ix->n ? ix->n : sorted_first;
+        u64 hi = sorted_count > ix->n - lo ? ix->n : lo + sorted_count;
+        return launch_gather_nc4(*ix, ix->d_nc4, ix->d_pos_of, ix->n_in, static_cast<u32>(lo), static_cast<u32>(hi), d_out_normals, d_opt_out_count);
     }
     if (k > 32 && (!o.idx || !o.cnt)) {  // the multi-pass path materialises rows: keep them in index scratch
         size_t need_idx = (static_cast<size_t>(ix->n_in) * k * sizeof(u32) + 255) / 256 * 256;
@@ -1556,6 +1646,110 @@ int pcpx_debug_eps_test_mode(pcpx_index* h, int mode)
     }
     std::lock_guard<std::recursive_mutex> serialise(ix->mu);
     ix->eps_test_mode = mode;
+    return PCPX_OK;
+}
+
+int pcpx_debug_set(pcpx_index* h, const char* name, int64_t value)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    if (!ix || !name) return PCPX_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    const std::string key(name);
+    if (key == "long_groups_first") {
+        ix->tuning.lpt = value != 0;
+        ix->sched.state = 0;
+    } else if (key == "gather_outputs") {
+        ix->tuning.gather = value != 0;
+    } else {
+        set_error("pcpx_debug_set: no setting called '%s'", name);
+        return PCPX_ERR_INVALID;
+    }
+    return PCPX_OK;
+}
+
+int pcpx_debug_group_times(pcpx_index* h, uint32_t* out_ticks, uint64_t capacity, uint64_t* out_groups)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    if (!out_groups) return PCPX_ERR_INVALID;
+    *out_groups = ix->sched.state ? ix->sched.gc : 0;
+    if (*out_groups == 0) return PCPX_OK;
+    if (!out_ticks || capacity < *out_groups) return PCPX_ERR_CAPACITY;
+    PCPX_HIP(hipMemcpyAsync(out_ticks, ix->sched.d_gtime, *out_groups * sizeof(u32), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    return PCPX_OK;
+}
+
+int pcpx_knn_group_costs_dev(pcpx_index* h, uint32_t k, float eps, uint32_t group_stride, uint32_t* d_out_events, uint64_t capacity,
+                             uint64_t* out_samples)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    if (!out_samples || group_stride == 0) return PCPX_ERR_INVALID;
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_knn_group_costs_dev");
+    const u64 groups = (ix->n + GROUP - 1) / GROUP;
+    const u64 nsamples = groups / group_stride;
+    *out_samples = nsamples;
+    if (!d_out_events || capacity < nsamples) return nsamples == 0 ? PCPX_OK : PCPX_ERR_CAPACITY;
+    u32 ns = 0;
+    return launch_knn_cost_sample(*ix, k, eps, group_stride, d_out_events, &ns);
+}
+
+// cost of a sampled group from its event counts, in instructions of the k <= 16 kernel (ISA counts, DESIGN.md "k_knn budget"): an
+// expansion is 4 box tests + the walk's scalar side, a dense leaf 8 candidates x 64 lanes, a packed leaf its publish + read-back and
+// ~10 per step of eight needing lanes, a fold the selection network; the constant is a group's seed phase, cap and epilogue.
+static inline uint64_t group_cost_of(const uint32_t e[4])
+{
+    const uint64_t folds = e[3] >> 16, steps = e[3] & 0xFFFFu, dense = e[1], packed = e[2];
+    return 6000ull + 112ull * e[0] + 108ull * dense + 38ull * packed + 11ull * steps + 140ull * folds;
+}
+
+int pcpx_shard_cuts_by_cost(uint64_t n, uint32_t world, uint32_t group_stride, const uint32_t* events, uint64_t nsamples, uint64_t* out_first)
+{
+    if (!out_first || world == 0 || group_stride == 0 || (nsamples && !events)) return PCPX_ERR_INVALID;
+    const u64 groups = (n + GROUP - 1) / GROUP;
+    if (nsamples != groups / group_stride) {
+        set_error("pcpx_shard_cuts_by_cost: %llu samples do not describe %llu groups at stride %u", static_cast<unsigned long long>(nsamples),
+                  static_cast<unsigned long long>(groups), group_stride);
+        return PCPX_ERR_INVALID;
+    }
+    out_first[0] = 0;
+    out_first[world] = n;
+    if (nsamples == 0) {  // too small to sample: cut by count
+        for (u32 r = 1; r < world; ++r) {
+            u64 f = groups * r / world * GROUP;
+            out_first[r] = f > n ? n : f;
+        }
+        return PCPX_OK;
+    }
+    // cost per group, block by block (sample i stands for groups [i stride, (i + 1) stride); the tail beyond the last whole block takes
+    // the last sample's), prefix sums in 64-bit integers: every rank of a job gets the same cuts from the same counts
+    std::vector<u64> prefix(nsamples + 2, 0);
+    for (u64 i = 0; i < nsamples; ++i) prefix[i + 1] = prefix[i] + group_cost_of(events + 4 * i) * group_stride;
+    const u64 tail_groups = groups - nsamples * group_stride;
+    prefix[nsamples + 1] = prefix[nsamples] + group_cost_of(events + 4 * (nsamples - 1)) * tail_groups;
+    const u64 total = prefix[nsamples + 1];
+    u64 i = 0;
+    for (u32 r = 1; r < world; ++r) {
+        const u64 target = static_cast<u64>((static_cast<unsigned __int128>(total) * r) / world);
+        while (i + 1 < nsamples + 1 && prefix[i + 1] <= target) ++i;  // block i holds the target
+        const u64 block_groups = i < nsamples ? group_stride : tail_groups;
+        const u64 block_cost = prefix[i + 1] - prefix[i];
+        u64 inside = block_cost ? static_cast<u64>((static_cast<unsigned __int128>(target - prefix[i]) * block_groups) / block_cost) : 0;
+        if (inside > block_groups) inside = block_groups;
+        u64 g = i * group_stride + inside;
+        if (g > groups) g = groups;
+        u64 f = g * GROUP;
+        if (f > n) f = n;
+        if (f < out_first[r - 1]) f = out_first[r - 1];
+        out_first[r] = f;
+    }
     return PCPX_OK;
 }
 

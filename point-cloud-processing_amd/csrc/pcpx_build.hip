@@ -615,6 +615,8 @@ int build_tree_from_sorted(Index& ix, u32 nvalid)
 {
     hipStream_t s = ix.stream;
     ix.n = nvalid;
+    ix.sched.state = 0;        // (what an earlier tree's launches recorded says nothing about this one's groups)
+    ix.pos_of_valid = false;
     u32 nleaves = (nvalid + LEAF - 1) / LEAF;
     ix.nleaves = nleaves;
     int depth = depth_for(nleaves);

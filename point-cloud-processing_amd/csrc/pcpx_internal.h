@@ -102,6 +102,20 @@ struct KnnOutputs {
     u32 pos_bias = 0;           // by_position: row = position + pos_bias (a rank-local index: local -> global curve position)
     float* tau = nullptr;       // self queries: d2 of the k-th neighbour (+inf: fewer than k found) of sorted position p at [p]
                                 // -- what the coverage check of a rank-local index needs (pcpx_shard.hip)
+    u32 row_stride = 0;         // entries between the rows of idx / d2 (0: k).  A stride of KCAP (8 / 16 / 32) with k = KCAP or KCAP - 1
+                                // makes a row one aligned piece written with 16-byte stores: a 60-byte row scattered by input index
+                                // costs its partial 32-byte sectors twice (read for ownership + write back)
+    float4* nc4 = nullptr;      // self queries: {normal, count as bits} of sorted position p at [p] INSTEAD of normals / cnt by row -- the
+                                // first half of the gather-form permute to input order (k_gather_nc4: coalesced writes, cached reads)
+};
+
+// What steers a self-kNN launch besides its outputs (all optional).
+struct KnnSchedule {
+    const u32* order = nullptr;  // the launch answers groups order[0 .. group_count) (absolute group ids) instead of group_first + i; queue q
+                                 // hands out its eighth of the array in array order (long groups first: pcpx_query.hip, k_make_order)
+    u32* gtime = nullptr;        // [g - group_first]: shader-clock ticks / 64 the group took (what the next launch's order is made from)
+    u32* events = nullptr;       // diagnostic-cost kernel only: 4 words per slot of the launch {expansions, dense leaves, packed leaves,
+                                 // folds << 16 | packed steps}: deterministic, what pcpx_knn_group_costs_dev reports
 };
 
 // Queries of a batch, in curve-sorted order.  For self queries qx == nullptr and the query of
@@ -214,6 +228,27 @@ struct Index {
     DevPool pool;        // staging buffers of the host-pointer entry points
     PinnedStage pinned;  // small-transfer staging
     u32 few_epoch = 0;   // launch counter of the latency path (its completion flag carries the epoch)
+    // ---- long groups first (pcpx_query.hip: k_make_order).  A self-kNN launch records what every group took; when the same question
+    // (slice, k class) comes again on the same tree, the launch hands the groups out by those times -- the longest third first, curve
+    // order inside a class -- so that a short launch (one rank's eighth of a cloud: 2.7 groups per resident wave) does not end with a
+    // 3x-the-mean group started last.  Results do not depend on the order.
+    struct Sched {
+        u32* d_gtime = nullptr;   // per group of the recorded launch
+        u32* d_order = nullptr;
+        u64 cap = 0;              // groups both arrays hold
+        u64 gf = 0, gc = 0;       // the recorded launch's groups
+        int kcap = 0;
+        u32 k = 0;
+        int state = 0;            // 0: nothing, 1: times recorded, 2: order made
+    } sched;
+    float4* d_nc4 = nullptr;      // {normal, count} per curve position (gather-form outputs), n entries
+    u32* d_pos_of = nullptr;      // input index -> curve position (0xFFFFFFFF: not indexed), n_in entries; valid while pos_of_valid
+    u64 nc4_cap = 0, pos_of_cap = 0;
+    bool pos_of_valid = false;
+    struct Tuning {
+        int lpt = 1;              // long groups first on repeated self-kNN launches
+        int gather = 1;           // input-order normals + counts through the gather-form permute
+    } tuning;
     int eps_test_mode = 0;  // k_knn's eps-box test: 0 = where it is cheaper (query.hip: eps_box_threshold), 1 = in the compaction, 2 = per candidate
 
     // ---- rank-local index (PCPX_BUILD_SHARD, pcpx_shard.hip): the tree holds only the points a rank's shard of the curve-sorted
@@ -229,6 +264,8 @@ struct Index {
         u64 core_count = 0;
         u32 halo_cells = 0;          // cells (of the selection grid) the core was dilated by
         u32 k_hint = 0;
+        bool explicit_range = false;  // PCPX_BUILD_SHARD_RANGE: the shard is [range_first, range_first + range_count), not pcpx_shard_range(rank, world)
+        u64 range_first = 0, range_count = 0;
         bool everything = false;     // the selection covers the whole grid: nothing to verify
         bool borrowed = false;       // the cloud is read in the caller's array (PCPX_BUILD_BORROW_CLOUD)
         const float* cloud = nullptr;  // n_in x 3, input order: the index's copy or the caller's array
@@ -335,6 +372,9 @@ int orient_normals_device(const float* d_xyz, u64 n, const u32* d_nbr, const u32
 // kNN + whatever per-neighbourhood products are requested (any pointer may be nullptr); all fused in k_knn
 int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 group_count, u32 k, float eps,
                const KnnOutputs& o);
+// event counts of sampled groups (every `stride`-th group of the curve order, from group stride / 2 on): d_events = 4 words per sample
+int launch_knn_cost_sample(Index& ix, u32 k, float eps, u32 stride, u32* d_events, u32* out_samples);
+int launch_gather_nc4(Index& ix, const float4* d_nc4, const u32* d_pos_of, u64 n_rows, u32 pos_lo, u32 pos_hi, float* d_normals, u32* d_cnt);
 // (q_host: the queries where the host can read them, or nullptr -- a single query is then passed in the kernel arguments)
 int launch_knn_few(Index& ix, const float* q_aos, const float* q_host, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2,
                    u32* flags, u32* done_count, u32* done_flag, u32 epoch);

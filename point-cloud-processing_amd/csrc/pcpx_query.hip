@@ -557,6 +557,7 @@ struct KnnArgs {
     MultiPass mp;
     u32* queue;
     unsigned long long* stats;
+    KnnSchedule sch;
 };
 typedef const __attribute__((address_space(4))) KnnArgs* knn_args_ptr;
 __device__ __forceinline__ knn_args_ptr knn_args_here()
@@ -580,10 +581,15 @@ __device__ __forceinline__ T cold(const __attribute__((address_space(4))) T* fie
 
 // One query group (64 curve-consecutive queries, one per lane) from start to finish.
 // NZ: the caller guarantees k <= KCAP - NZ (NZ sentinel slots at the bottom of the best-list hold 0 throughout)
-template <int KCAP, bool SELF, bool STATS, bool MULTI, bool EPS_EACH, int NZ>
+// DIAG: 0 = the product; 1 = the diagnostic build (pcpx_debug_knn_stats: event counts and clocks per phase, summed over the launch);
+// 2 = the product's walk with its events counted per group (launch_knn_cost_sample: what a work-balanced shard cut is made from --
+// integers that depend on the tree and the question alone, so every rank of a job computes the same ones); `slot` = where its counts go
+template <int KCAP, bool SELF, int DIAG, bool MULTI, bool EPS_EACH, int NZ>
 __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, const float eps, const float eps_thr,
-                                          unsigned long long* __restrict__ stats, u64* __restrict__ col, float* __restrict__ pub, const u32 lane)
+                                          unsigned long long* __restrict__ stats, u64* __restrict__ col, float* __restrict__ pub, const u32 lane,
+                                          const u32 slot)
 {
+    constexpr bool STATS = DIAG == 1, COST = DIAG == 2;
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
     // (the depth is made opaque per group, like k below: depth - 1, its multiples and the level masks are otherwise computed once
     //  per kernel and parked in spilled scalar registers)
@@ -608,11 +614,14 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     // [3] keys appended, [4] waves, [5] seed leaves
     //                                           [6] groups that needed the second (uncapped) walk round
     u32 st_leaves = 0, st_expand = 0, st_compact = 0, st_app = 0, st_round2 = 0, st_seed_compact = 0, st_seed_app = 0, st_sparse = 0, st_owners = 0;
+    u32 st_steps = 0;  // COST: steps (eight needing lanes each) of the packed leaves
     // [7] shader cycles in the walker (pop + node expansions), [8] in compactions, [9] in leaf candidates,
     // [10] in the whole search loop, [11] whole group incl. the epilogue (id gather, tie repair, stores, fused normal)
     unsigned long long tc_walk = 0, tc_compact = 0, tc_leaf = 0, tc0 = 0, tc_mark = 0, tc_later_mark = 0;
     u32 st_later_lanes = 0;
     if (STATS) tc0 = __builtin_amdgcn_s_memtime();
+    u32 tick0 = 0;  // (the low word: a group takes far less than 2^32 cycles)
+    if (!MULTI && DIAG == 0) tick0 = static_cast<u32>(__builtin_amdgcn_s_memtime());
 
     // ---- my query ----
     u32 p_here = g * GROUP + lane;
@@ -715,6 +724,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         tau = active ? fminf(nt, cap) : -1.f;
         if (STATS) tau = fminf(tau, tau_known);
         wa = col_addr + (static_cast<u32>(cnt) << 9);
+        if (COST) ++st_compact;
         if (STATS) {
             ++st_compact;
             if (in_seed_phase) ++st_seed_compact;
@@ -731,6 +741,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
 
     // candidates of one leaf: SMEM broadcast, branch-free accept; `shell`: a later walk round
     auto candidates = [&](const u32 leaf, const bool shell) {
+        if (COST) ++st_leaves;
         if (STATS) {
             ++st_leaves;
             tc_mark = __builtin_amdgcn_s_memtime();
@@ -989,6 +1000,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                             if (!packed_form) break;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                             todo = packed_leaf(loc, todo, how_many);
+                            if (COST) st_steps += (how_many + 7u) >> 3;
                             if (STATS) {
                                 asm volatile("" ::"v"(wa));
                                 tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
@@ -997,6 +1009,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                             how_many = static_cast<u32>(__builtin_popcountll(todo));
                         }
                         if (packed_form) {
+                            if (COST) ++st_sparse;
                             if (STATS) ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;  // ([14], [15]: the packed leaves and their needing lanes)
                         } else {
                             candidates(loc, rounds != 0u);
@@ -1065,6 +1078,24 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         }
     }
 
+    if (!MULTI && DIAG == 0) {  // what the search took (shader clock / 64), for the next launch's order: one store per ~32 000 instructions
+        const knn_args_ptr kt = knn_args_here();
+        u32* const gtime = cold(&kt->sch.gtime);
+        if (gtime) {
+            const u32 ticks = (static_cast<u32>(__builtin_amdgcn_s_memtime()) - tick0) >> 6;
+            u32 lane_again = lane;
+            asm volatile("" : "+v"(lane_again));
+            if (lane_again == 0) gtime[g - kt->group_first] = ticks;
+        }
+    }
+    if (COST) {
+        u32* const events = cold(&knn_args_here()->sch.events);
+        if (lane == 0) {
+            uint4 e;
+            e.x = st_expand, e.y = st_leaves, e.z = st_sparse, e.w = (st_compact << 16) | (st_steps < 0xFFFFu ? st_steps : 0xFFFFu);
+            reinterpret_cast<uint4*>(events)[slot] = e;
+        }
+    }
     const int first_slot = KCAP - static_cast<int>(k);
     if (PCPX_PRIO_EPI != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_EPI);
     // (the cold arguments are read again where the epilogue needs them: nothing read through `ka` above is alive any more)
@@ -1150,15 +1181,43 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     if (SELF && o.tau) o.tau[p_row] = key_d2(best[KCAP - 1]);  // (+inf when the row holds fewer than k)
     u32 found = 0;
     u32 okmask = 0;
-    const u64 ob = static_cast<u64>(row) * k;
+    const u32 stride = o.row_stride ? o.row_stride : k;
+    const u64 ob = static_cast<u64>(row) * stride;
+    // A row of KCAP entries (row_stride = KCAP; k = KCAP or KCAP - 1: the slots' shift is then a constant) leaves as 16-byte stores: one
+    // aligned piece per row.  Scattered by input index, a 60-byte row written word by word costs every 32-byte sector it touches twice
+    // (read for ownership, write back), and a store instruction of 64 lanes touches 64 lines whatever its width.
+    // (NZ = 1: the kernel for k < KCAP, whose slot 0 holds the sentinel: k = KCAP - 1 is the shift by one; NZ = 0: k = KCAP in the
+    //  deferred-eps kernels, any k in the per-candidate ones)
+    const bool whole_rows = stride == static_cast<u32>(KCAP) && first_slot == NZ && !STATS;
+    auto store_whole_rows = [&](auto FS) {
+        constexpr int fs = decltype(FS)::value;
+#pragma unroll
+        for (int c = 0; c < KCAP / 4; ++c) {
+            u32 id4[4];
+            float d4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sl = 4 * c + e + fs;  // (the slot whose key is entry 4 c + e of the row)
+                const u64 key = sl < KCAP ? best[sl < KCAP ? sl : 0] : PAD_KEY;
+                const bool ok = key != PAD_KEY;
+                id4[e] = ok ? static_cast<u32>(key) : INVALID_ID;
+                d4[e] = __uint_as_float(static_cast<u32>(key >> 32));
+            }
+            if (o.idx) *reinterpret_cast<uint4*>(o.idx + ob + 4 * c) = make_uint4(id4[0], id4[1], id4[2], id4[3]);
+            if (o.d2) *reinterpret_cast<float4*>(o.d2 + ob + 4 * c) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        }
+    };
+    if (whole_rows) store_whole_rows(std::integral_constant<int, NZ>{});
 #pragma unroll
     for (int s = 0; s < KCAP; ++s) {
         int j = s - first_slot;
         if (j >= 0) {
             u64 key = best[s];
             bool ok = key != PAD_KEY;
-            if (o.idx) o.idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
-            if (o.d2 && !STATS) o.d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
+            if (!whole_rows) {
+                if (o.idx) o.idx[ob + j] = ok ? static_cast<u32>(key) : INVALID_ID;
+                if (o.d2 && !STATS) o.d2[ob + j] = __uint_as_float(static_cast<u32>(key >> 32));
+            }
             found += ok ? 1u : 0u;
             okmask |= ok ? (1u << s) : 0u;
         }
@@ -1180,7 +1239,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
 
     // ---- fused pcp::estimate_normal over the row (normal_estimation.hpp:41-77), coordinates gathered
     //      from the leaf records in row order ----
-    if (o.normals || o.centroids) {
+    if (o.normals || o.centroids || (SELF && o.nc4)) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) {
@@ -1199,7 +1258,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             o.centroids[3ull * row + 1] = my;
             o.centroids[3ull * row + 2] = mz;
         }
-        if (!o.normals) {
+        if (!o.normals && !(SELF && o.nc4)) {
             restore_column();
             return;
         }
@@ -1220,9 +1279,13 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         }
         float nrm[3], ev[3];
         eig3_smallest(c00, c10, c20, c11, c21, c22, nrm, ev);
-        o.normals[3ull * row] = nrm[0];
-        o.normals[3ull * row + 1] = nrm[1];
-        o.normals[3ull * row + 2] = nrm[2];
+        if (SELF && o.nc4) {  // {normal, count} at the query's curve position: one contiguous kilobyte per wave (k_gather_nc4 takes them to input order)
+            o.nc4[p_row] = make_float4(nrm[0], nrm[1], nrm[2], __uint_as_float(found));
+        } else {
+            o.normals[3ull * row] = nrm[0];
+            o.normals[3ull * row + 1] = nrm[1];
+            o.normals[3ull * row + 2] = nrm[2];
+        }
     }
     restore_column();
 }
@@ -1237,10 +1300,11 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
 // under-reports on gfx950 (this grid is fully resident by construction).
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
 
-template <int KCAP, bool SELF, bool STATS, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS, int NZ = 0>
+template <int KCAP, bool SELF, int DIAG, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS, int NZ = 0>
 __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
     const KnnArgs a)
 {
+    constexpr bool STATS = DIAG == 1;
     // (the fields used all through a group; the others are read where they are needed: KnnArgs)
     const TreeView t = a.t;
     const float eps = a.eps, eps_thr = a.eps_thr;
@@ -1286,8 +1350,10 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
             tg = __builtin_amdgcn_s_memrealtime();
             tcg = __builtin_amdgcn_s_memtime();
         }
-        const u32 g = group_first + qbeg + gi;
-        knn_group<KCAP, SELF, STATS, MULTI, EPS_EACH, NZ>(t, g, eps, eps_thr, stats, col, pub, lane);
+        // (the launch's slots in curve order, or -- KnnSchedule::order -- in the order a recorded launch suggests: long groups first)
+        const u32* const order = cold(&ka->sch.order);
+        const u32 g = order ? load_const(order + qbeg + gi) : group_first + qbeg + gi;
+        knn_group<KCAP, SELF, DIAG, MULTI, EPS_EACH, NZ>(t, g, eps, eps_thr, stats, col, pub, lane, qbeg + gi);
         if (STATS) {
             if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
             ++n_done;
@@ -1359,6 +1425,99 @@ static float eps_box_threshold(const Index& ix, float eps)
     return t <= 0.01 * spacing * spacing ? thr : -1.f;
 }
 
+// ---- long groups first ---------------------------------------------------------------------------------------------------------
+// The groups of a launch take 0.4 ... 3 x their mean (a chunk of the curve that lies across one of its turns, points in a sparse
+// place that go round the walk again), and a persistent launch ends when its last group does: one rank's eighth of a 10 M cloud is
+// 2.7 groups per resident wave, and a 3 x group handed out in the last round ends a whole group's time after everything else.
+// k_knn leaves every group's time behind (KnnSchedule::gtime); when the same question comes again on the same tree, the queues
+// hand their groups out in three classes -- above 7/4 of the queue's mean, above 9/8, the rest -- in curve order inside a class
+// (the queue still walks its eighth of the curve three times front to back: neighbours keep sharing the XCD's L2).
+// One block per queue.
+constexpr u32 LPT_MIN_GROUPS = 512;
+__global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gtime, u32 ngroups, u32 group_first, u32* __restrict__ order)
+{
+    __shared__ unsigned long long sum_s;
+    __shared__ u32 cnt_s[3], base_s[3], wave_s[3][16];
+    const u32 t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    const u32 per = (ngroups + 7u) >> 3;
+    const u32 qbeg = blockIdx.x * per, qend = qbeg + per < ngroups ? qbeg + per : ngroups;
+    if (qbeg >= qend) return;
+    if (t == 0) sum_s = 0;
+    if (t < 3) cnt_s[t] = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (u32 i = qbeg + t; i < qend; i += 1024u) mine += gtime[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) atomicAdd(&sum_s, mine);
+    __syncthreads();
+    const unsigned long long mean = sum_s / (qend - qbeg);
+    const unsigned long long hi = mean * 7ull / 4ull, mid = mean * 9ull / 8ull;
+    auto cls = [&](u32 v) -> u32 { return v > hi ? 0u : v > mid ? 1u : 2u; };
+    u32 c[3] = {0, 0, 0};
+    for (u32 i = qbeg + t; i < qend; i += 1024u) ++c[cls(gtime[i])];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        u32 v = c[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && v) atomicAdd(&cnt_s[b], v);
+    }
+    __syncthreads();
+    if (t == 0) {
+        base_s[0] = 0;
+        base_s[1] = cnt_s[0];
+        base_s[2] = cnt_s[0] + cnt_s[1];
+    }
+    __syncthreads();
+    for (u32 i0 = qbeg; i0 < qend; i0 += 1024u) {
+        const u32 i = i0 + t;
+        const bool in = i < qend;
+        const u32 b = in ? cls(gtime[i]) : 3u;
+        u32 below = 0;
+#pragma unroll
+        for (u32 bb = 0; bb < 3; ++bb) {
+            const u64 m = __builtin_amdgcn_ballot_w64(b == bb);
+            if (lane == 0) wave_s[bb][w] = static_cast<u32>(__builtin_popcountll(m));
+            if (b == bb) below = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(m), 0u));
+        }
+        __syncthreads();
+        if (in) {
+            u32 before = 0;
+            for (u32 ww = 0; ww < w; ++ww) before += wave_s[b][ww];
+            order[qbeg + base_s[b] + before + below] = group_first + i;
+        }
+        __syncthreads();
+        if (t < 3) {
+            u32 tot = 0;
+            for (u32 ww = 0; ww < 16; ++ww) tot += wave_s[t][ww];
+            base_s[t] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+static int sched_reserve(Index& ix, u64 groups)
+{
+    Index::Sched& sc = ix.sched;
+    if (groups <= sc.cap) return PCPX_OK;
+    PCPX_HIP(hipStreamSynchronize(ix.stream));
+    (void)hipFree(sc.d_gtime);
+    (void)hipFree(sc.d_order);
+    sc = Index::Sched{};
+    const u64 cap = groups + groups / 8 + 64;
+    if (hipMalloc(reinterpret_cast<void**>(&sc.d_gtime), cap * sizeof(u32)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sc.d_order), cap * sizeof(u32)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(sc.d_gtime);
+        (void)hipFree(sc.d_order);
+        sc = Index::Sched{};
+        return PCPX_ERR_ALLOC;  // (the caller goes on without a schedule)
+    }
+    sc.cap = cap;
+    return PCPX_OK;
+}
+
 template <int KCAP, bool SELF, bool EPS_EACH, int NZ>
 static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcount, u32 k, float eps, float thr, const KnnOutputs& o)
 {
@@ -1366,13 +1525,56 @@ static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcoun
     constexpr int WPB = knn_wpb(KCAP, false);
     const size_t lds = static_cast<size_t>(WPB) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
     const u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
+    if (o.row_stride != 0 && (o.row_stride < k || ((o.row_stride == static_cast<u32>(KCAP)) && ((reinterpret_cast<uintptr_t>(o.idx) | reinterpret_cast<uintptr_t>(o.d2)) & 15u) != 0))) {
+        set_error("pcpx: row_stride must be >= k, and rows of %d entries must start at multiples of 16 bytes", KCAP);
+        return PCPX_ERR_INVALID;
+    }
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
-    auto* fn = k_knn<KCAP, SELF, false, false, EPS_EACH, NZ>;
+    KnnSchedule sch;
+    if (SELF && ix.tuning.lpt && gcount >= LPT_MIN_GROUPS) {
+        Index::Sched& sc = ix.sched;
+        const bool same = sc.state != 0 && sc.gf == gfirst && sc.gc == gcount && sc.kcap == KCAP && sc.k == k;
+        if (same && sc.state == 1) {
+            k_make_order<<<8, 1024, 0, ix.stream>>>(sc.d_gtime, static_cast<u32>(gcount), gf, sc.d_order);
+            sc.state = 2;
+        }
+        if (same) {
+            sch.order = sc.d_order;
+        } else if (sched_reserve(ix, gcount) == PCPX_OK) {
+            sch.gtime = sc.d_gtime;
+            sc.gf = gfirst, sc.gc = gcount, sc.kcap = KCAP, sc.k = k, sc.state = 1;
+        }
+    }
+    auto* fn = k_knn<KCAP, SELF, 0, false, EPS_EACH, NZ>;
     const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WPB, lds, gcount, WPB);
     ProfileScope prof(ix, PCPX_K_KNN);
-    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr});
+    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr, sch});
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
+}
+
+// ---- event counts of sampled groups (what a work-balanced shard cut is made from) -------------------------------------------------
+__global__ void k_sample_order(u32 nsamples, u32 stride, u32* __restrict__ order)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nsamples) order[i] = i * stride + stride / 2u;
+}
+template <int KCAP, int NZ>
+static int launch_knn_cost_form(Index& ix, u32 nsamples, u32 k, float eps, float thr, const u32* d_order, u32* d_events)
+{
+    constexpr int BUF = buf_rows(KCAP);
+    constexpr int WPB = knn_wpb(KCAP, false);
+    const size_t lds = static_cast<size_t>(WPB) * lds_rows(BUF, false, KCAP) * 64 * sizeof(u64);
+    int st = prepare_queue(ix);
+    if (st != PCPX_OK) return st;
+    auto* fn = k_knn<KCAP, true, 2, false, false, NZ>;
+    const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WPB, lds, nsamples, WPB);
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
+    KnnSchedule sch;
+    sch.order = d_order;
+    sch.events = d_events;
+    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, 0u, nsamples, k, eps, thr, KnnOutputs{}, MultiPass{}, ix.d_queue, nullptr, sch});
+    return check_hip(hipGetLastError(), "k_knn cost sample launch", __FILE__, __LINE__);
 }
 
 template <int KCAP>
@@ -1465,8 +1667,8 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
     u64* lo[2] = {ix.d_multi + nslots * stride, ix.d_multi + nslots * stride + nslots};
     size_t lds = static_cast<size_t>(WAVES_PER_BLOCK) * lds_rows(BUF, true) * 64 * sizeof(u64);
     u32 gf = static_cast<u32>(gfirst), ge = static_cast<u32>(gfirst + gcount);
-    const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, false, true>)
-                          : reinterpret_cast<const void*>(k_knn<KCAP, false, false, true>);
+    const void* fn = self ? reinterpret_cast<const void*>(k_knn<KCAP, true, 0, true>)
+                          : reinterpret_cast<const void*>(k_knn<KCAP, false, 0, true>);
     u32 pgrid = persistent_grid(ix, fn, 64 * WAVES_PER_BLOCK, lds, gcount, WAVES_PER_BLOCK);
     ProfileScope prof(ix, PCPX_K_KNN);
     for (u32 pass = 0; pass < npass; ++pass) {
@@ -1483,8 +1685,8 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
         KnnOutputs range_only;  // (a pass writes keys, not rows; it still answers the asked positions only)
         range_only.pos_lo = o.pos_lo;
         range_only.pos_hi = o.pos_hi;
-        if (self) k_knn<KCAP, true, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr});
-        else k_knn<KCAP, false, false, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr});
+        if (self) k_knn<KCAP, true, 0, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr, KnnSchedule{}});
+        else k_knn<KCAP, false, 0, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr, KnnSchedule{}});
     }
     const u32 n32 = static_cast<u32>(nslots);
     if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
@@ -1521,6 +1723,54 @@ int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 g
     return launch_knn_multipass(ix, qv, self, group_first, group_count, k, eps, o);
 }
 
+int launch_knn_cost_sample(Index& ix, u32 k, float eps, u32 stride, u32* d_events, u32* out_samples)
+{
+    const u64 groups = (ix.n + GROUP - 1) / GROUP;
+    if (stride == 0) stride = 1;
+    const u32 nsamples = static_cast<u32>(groups / stride);  // (sample i stands for groups [i stride, (i + 1) stride); a last partial block has none)
+    *out_samples = nsamples;
+    if (nsamples == 0) return PCPX_OK;
+    if (k == 0 || k > 32) {
+        set_error("pcpx: group costs are sampled with the single-pass kernels: 1 <= k <= 32");
+        return PCPX_ERR_UNSUPPORTED;
+    }
+    eps = sanitize_eps(eps);
+    float thr = eps_box_threshold(ix, eps);
+    if (thr < 0.f) thr = std::numeric_limits<float>::infinity();  // (as launch_knn_stats: the deferred form, every buffered key tested)
+    int st = sched_reserve(ix, nsamples);  // (the sample's group list borrows the schedule's order array: a cut is made before the queries it is for)
+    if (st != PCPX_OK) {
+        set_error("pcpx: out of device memory for the cost sample's group list");
+        return st;
+    }
+    ix.sched.state = 0;
+    k_sample_order<<<(nsamples + 255) / 256, 256, 0, ix.stream>>>(nsamples, stride, ix.sched.d_order);
+    if (k <= 8) return k < 8 ? launch_knn_cost_form<8, 1>(ix, nsamples, k, eps, thr, ix.sched.d_order, d_events) : launch_knn_cost_form<8, 0>(ix, nsamples, k, eps, thr, ix.sched.d_order, d_events);
+    if (k <= 16) return k < 16 ? launch_knn_cost_form<16, 1>(ix, nsamples, k, eps, thr, ix.sched.d_order, d_events) : launch_knn_cost_form<16, 0>(ix, nsamples, k, eps, thr, ix.sched.d_order, d_events);
+    return k < 32 ? launch_knn_cost_form<32, 1>(ix, nsamples, k, eps, thr, ix.sched.d_order, d_events) : launch_knn_cost_form<32, 0>(ix, nsamples, k, eps, thr, ix.sched.d_order, d_events);
+}
+
+// {normal, count} at curve positions -> rows by input index: out[i] = nc4[position_of[i]] for the inputs whose position lies in
+// [pos_lo, pos_hi).  Coalesced writes; the 16-byte reads hit the cache the kernel has just written through.
+__global__ __launch_bounds__(256) void k_gather_nc4(const float4* __restrict__ nc4, const u32* __restrict__ pos_of, u32 n_rows, u32 pos_lo, u32 pos_hi,
+                                                     float* __restrict__ normals, u32* __restrict__ cnt)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const u32 p = pos_of[i];
+    if (!(p - pos_lo < pos_hi - pos_lo)) return;  // (0xFFFFFFFF: not indexed)
+    const float4 v = nc4[p];
+    normals[3ull * i] = v.x;
+    normals[3ull * i + 1] = v.y;
+    normals[3ull * i + 2] = v.z;
+    if (cnt) cnt[i] = __float_as_uint(v.w);
+}
+int launch_gather_nc4(Index& ix, const float4* d_nc4, const u32* d_pos_of, u64 n_rows, u32 pos_lo, u32 pos_hi, float* d_normals, u32* d_cnt)
+{
+    if (n_rows == 0) return PCPX_OK;
+    k_gather_nc4<<<static_cast<u32>((n_rows + 255) / 256), 256, 0, ix.stream>>>(d_nc4, d_pos_of, static_cast<u32>(n_rows), pos_lo, pos_hi, d_normals, d_cnt);
+    return check_hip(hipGetLastError(), "k_gather_nc4 launch", __FILE__, __LINE__);
+}
+
 // instrumented self-kNN (k <= 16): traversal statistics summed over all waves into d_stats[8]
 int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, const float* d_known_d2)
 {
@@ -1532,14 +1782,14 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
-    u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, true>), 64 * WPB, lds, groups, WPB);
+    u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(k_knn<KCAP, true, 1>), 64 * WPB, lds, groups, WPB);
     // (this instantiation is the deferred-eps form whatever the threshold says: a negative one -- "test every candidate" -- becomes
     //  +inf here, so that every buffered key takes the exact test in the compaction)
     float thr = eps_box_threshold(ix, sanitize_eps(eps));
     if (thr < 0.f) thr = std::numeric_limits<float>::infinity();
-    k_knn<KCAP, true, true><<<pgrid, 64 * WPB, lds, ix.stream>>>(
+    k_knn<KCAP, true, 1><<<pgrid, 64 * WPB, lds, ix.stream>>>(
         KnnArgs{ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), thr,
-                KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats});
+                KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats, KnnSchedule{}});
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ u32 sel_prefix(u32 cx, u32 cy, u32 cz, const u32* __r
 }
 
 // ---- plan: which cells of the curve hold the shard -------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_shard_plan(const u32* __restrict__ hist12, u32 rank, u32 world, u32* __restrict__ plan)
+__global__ __launch_bounds__(1024) void k_shard_plan(const u32* __restrict__ hist12, u32 rank, u32 world, u32 explicit_range, u64 range_first,
+                                                     u64 range_count, u32* __restrict__ plan)
 {
     __shared__ u32 wsum[16];
     __shared__ u32 res[4];
@@ -101,6 +102,10 @@ __global__ __launch_bounds__(1024) void k_shard_plan(const u32* __restrict__ his
     const u64 nvalid = total;
     const u64 groups = (nvalid + GROUP - 1) / GROUP;
     u64 first = groups * rank / world * GROUP, end = groups * (static_cast<u64>(rank) + 1) / world * GROUP;
+    if (explicit_range) {  // (PCPX_BUILD_SHARD_RANGE: a cut by work, pcpx_shard_cuts_by_cost)
+        first = range_first;
+        end = range_count > nvalid - (first < nvalid ? first : nvalid) ? nvalid : first + range_count;
+    }
     if (first > nvalid) first = nvalid;
     if (end > nvalid) end = nvalid;
     if (end > first) {
@@ -167,8 +172,10 @@ __global__ __launch_bounds__(1024) void k_sel_pack(const unsigned char* __restri
     const u32 cx = cell & (SEL_AXIS - 1), cy = (cell >> SEL_LEVEL) & (SEL_AXIS - 1), cz = cell >> (2 * SEL_LEVEL);
     const u32 h = sel_prefix(cx, cy, cz, htab);
     const bool on = grid[cell] != 0 || ((need[h >> 5] >> (h & 31u)) & 1u) != 0;
-    if (on) atomicOr(&sel[h >> 5], 1u << (h & 31u));
-    const u64 b = __builtin_amdgcn_ballot_w64(on);
+    // (only cells that were not selected before are counted: the range path runs this again over a selection that already holds
+    //  the earlier halo, and P_NSEL >= SEL_CELLS means "everything is selected: nothing to verify")
+    const bool fresh = on && (atomicOr(&sel[h >> 5], 1u << (h & 31u)) & (1u << (h & 31u))) == 0u;
+    const u64 b = __builtin_amdgcn_ballot_w64(fresh);
     if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&plan[P_NSEL], static_cast<u32>(__builtin_popcountll(b)));
 }
 __global__ __launch_bounds__(1024) void k_sel_or(u32* __restrict__ sel, const u32* __restrict__ need, u32* __restrict__ plan)
@@ -514,11 +521,12 @@ int shard_local_build(Index& ix)
     PCPX_HIP(hipMemcpyAsync(plan, sh.d_plan, sizeof(plan), hipMemcpyDeviceToHost, s));
     PCPX_HIP(hipStreamSynchronize(s));
     const u32 m = plan[P_M];
-    sh.n_glob = plan[P_NVALID];
-    sh.g_first = plan[P_FIRST];
-    sh.g_count = plan[P_COUNT];
-    sh.core_g0 = plan[P_G0];
-    sh.everything = plan[P_NSEL] >= SEL_CELLS;
+    // what describes the shard is published at the end, when the tree exists: a build that fails on the way leaves a handle that
+    // answers nothing (n_glob = 0: every slice is empty), not one whose ranges point into a tree that is not there
+    const u64 new_n_glob = plan[P_NVALID], new_g_first = plan[P_FIRST], new_g_count = plan[P_COUNT], new_core_g0 = plan[P_G0];
+    const bool new_everything = plan[P_NSEL] >= SEL_CELLS;
+    sh.n_glob = sh.g_first = sh.g_count = sh.core_g0 = sh.core_l0 = sh.core_count = 0;
+    sh.verified_k = 0;
     // local arrays, with some room: a streaming cloud's selection changes a little from rebuild to rebuild
     if (m > sh.cap_loc || !sh.d_words) {
         const u64 cap = static_cast<u64>(m) + m / 8 + 4096;
@@ -566,15 +574,21 @@ int shard_local_build(Index& ix)
         set_error("pcpx: internal error, the radix sort's look-back gave up");
         return PCPX_ERR_DEVICE;
     }
-    sh.core_l0 = plan[P_L0];
-    sh.core_count = plan[P_LCORE];
-    if (sh.core_count != plan[P_CORE]) {
-        set_error("pcpx: internal error, the rank-local index holds %llu of the core's %u points", static_cast<unsigned long long>(sh.core_count),
-                  plan[P_CORE]);
+    if (plan[P_LCORE] != plan[P_CORE]) {
+        ix.n = 0;
+        ix.nleaves = 0;
+        set_error("pcpx: internal error, the rank-local index holds %u of the core's %u points", plan[P_LCORE], plan[P_CORE]);
         return PCPX_ERR_DEVICE;
     }
-    sh.verified_k = 0;
-    return build_tree_from_sorted(ix, m);
+    if ((st = build_tree_from_sorted(ix, m)) != PCPX_OK) return st;
+    sh.n_glob = new_n_glob;
+    sh.g_first = new_g_first;
+    sh.g_count = new_g_count;
+    sh.core_g0 = new_core_g0;
+    sh.core_l0 = plan[P_L0];
+    sh.core_count = plan[P_LCORE];
+    sh.everything = new_everything;
+    return PCPX_OK;
 }
 
 }  // namespace
@@ -605,6 +619,7 @@ int shard_unsupported(const Index& ix, const char* what)
 int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params)
 {
     Index::Shard& sh = ix.shard;
+    const bool explicit_range = (params->flags & PCPX_BUILD_SHARD_RANGE) != 0;
     if (params->struct_size < sizeof(pcpx_build_params) || params->shard_world == 0 || params->shard_rank >= params->shard_world) {
         set_error("pcpx: PCPX_BUILD_SHARD needs shard_rank < shard_world in a full-size pcpx_build_params");
         return PCPX_ERR_INVALID;
@@ -615,7 +630,8 @@ int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build
     int st;
     // a handle that changes its shard, or whose grid is not pinned by the caller, forgets the cells earlier checks asked for
     const bool use_grid = (params->flags & PCPX_BUILD_USE_GRID) != 0;
-    bool same_frame = sh.on && use_grid && sh.rank == params->shard_rank && sh.world == params->shard_world;
+    bool same_frame = sh.on && use_grid && sh.rank == params->shard_rank && sh.world == params->shard_world && sh.explicit_range == explicit_range &&
+                      (!explicit_range || (sh.range_first == params->shard_first && sh.range_count == params->shard_count));
     if (same_frame)
         for (int a = 0; a < 3; ++a) same_frame = same_frame && ix.bbox[a] == params->grid_min[a] && ix.bbox[3 + a] == params->grid_max[a];
     if (!sh.d_sel) {
@@ -626,9 +642,14 @@ int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build
         same_frame = false;
     }
     sh.on = true;
+    sh.n_glob = sh.g_first = sh.g_count = sh.core_g0 = sh.core_l0 = sh.core_count = 0;  // (published by shard_local_build when the tree exists)
+    sh.verified_k = 0;
     sh.rank = params->shard_rank;
     sh.world = params->shard_world;
     sh.k_hint = params->shard_k_hint ? params->shard_k_hint : 32u;
+    sh.explicit_range = explicit_range;
+    sh.range_first = explicit_range ? params->shard_first : 0;
+    sh.range_count = explicit_range ? params->shard_count : 0;
     sh.borrowed = borrowed;
     if ((st = build_grow_cloud_arrays(ix, n, !borrowed)) != PCPX_OK) return st;
     ix.n_in = n;
@@ -640,7 +661,7 @@ int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build
     if (!same_frame) PCPX_HIP(hipMemsetAsync(sh.d_need, 0, SEL_WORDS * sizeof(u32), s));
     PCPX_HIP(hipMemsetAsync(sh.d_sel, 0, SEL_WORDS * sizeof(u32), s));
     PCPX_HIP(hipMemsetAsync(sh.d_plan, 0, P_WORDS * sizeof(u32), s));
-    k_shard_plan<<<1, 1024, 0, s>>>(sh.d_hist12, sh.rank, sh.world, sh.d_plan);
+    k_shard_plan<<<1, 1024, 0, s>>>(sh.d_hist12, sh.rank, sh.world, explicit_range ? 1u : 0u, sh.range_first, sh.range_count, sh.d_plan);
     sh.halo_cells = halo_cells_for(n, sh.k_hint);
     unsigned char* ga = reinterpret_cast<unsigned char*>(sh.d_grid);
     unsigned char* gb = ga + SEL_CELLS;

@@ -48,6 +48,15 @@ def shard_range(n, rank, world):
     return a.value, b.value
 
 
+def shard_cuts_by_cost(n, world, group_stride, events):
+    """pcpx_shard_cuts_by_cost: world + 1 curve positions (multiples of 64) that cut the order into shards of equal estimated WORK;
+    events = the table of Index.knn_group_costs (nsamples x 4, uint32)."""
+    ev = np.ascontiguousarray(events, dtype=np.uint32).reshape(-1, 4)
+    out = (C.c_uint64 * (world + 1))()
+    check(_capi.load().pcpx_shard_cuts_by_cost(n, world, group_stride, _vp(ev) if len(ev) else None, len(ev), out))
+    return [int(v) for v in out]
+
+
 def estimate_normal(points, device=0):
     """pcp::estimate_normal (include/pcp/common/normals/normal_estimation.hpp:32-78)."""
     pts = _f32(points, 3)
@@ -69,10 +78,12 @@ class Index:
         check(self._lib.pcpx_index_create(_vp(xyz), len(xyz), p, device, C.byref(self._h)))
 
     @staticmethod
-    def _params(voxel_grid, coarse_order=False, shard=None, k_hint=0, borrow=False):
+    def _params(voxel_grid, coarse_order=False, shard=None, k_hint=0, borrow=False, shard_range=None):
         """pcpx_build_params: voxel_grid = the explicit grid (PCPX_BUILD_USE_GRID); coarse_order = PCPX_BUILD_COARSE_ORDER (an index that
         is rebuilt after a query pass or two: one radix pass fewer on a uniform cloud, same results); shard = (rank, world):
         PCPX_BUILD_SHARD, the rank-local index of the multi-GPU path (k_hint sizes its halo; borrow = PCPX_BUILD_BORROW_CLOUD)."""
+        if shard_range is not None and shard is None:
+            shard = (0, 1)
         if voxel_grid is None and not coarse_order and shard is None:
             return None
         p = BuildParams()
@@ -82,6 +93,9 @@ class Index:
             p.flags |= _capi.PCPX_BUILD_SHARD | (_capi.PCPX_BUILD_BORROW_CLOUD if borrow else 0)
             p.shard_rank, p.shard_world = int(shard[0]), int(shard[1])
             p.shard_k_hint = int(k_hint)
+            if shard_range is not None:  # PCPX_BUILD_SHARD_RANGE: explicit curve positions (first, count), e.g. a cut by work
+                p.flags |= _capi.PCPX_BUILD_SHARD_RANGE
+                p.shard_first, p.shard_count = int(shard_range[0]), int(shard_range[1])
         if voxel_grid is None:
             return C.pointer(p)
         g = np.asarray(voxel_grid, np.float32).reshape(6)
@@ -252,18 +266,18 @@ class Index:
 
     # ---- device-pointer forms (torch tensors / raw pointers), used by bench.py ----
     @classmethod
-    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None, coarse_order=False, shard=None, k_hint=0, borrow=False):
+    def from_device(cls, d_xyz_ptr, n, device=0, stream=None, voxel_grid=None, coarse_order=False, shard=None, k_hint=0, borrow=False, shard_range=None):
         self = cls.__new__(cls)
         self._lib = _capi.load()
         self._h = C.c_void_p(None)
         self.device = device
         self.n_in = n
-        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid, coarse_order, shard, k_hint, borrow), device,
+        check(self._lib.pcpx_index_create_dev(C.c_void_p(d_xyz_ptr), n, cls._params(voxel_grid, coarse_order, shard, k_hint, borrow, shard_range), device,
                                               C.c_void_p(stream) if stream else None, C.byref(self._h)))
         return self
 
-    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None, coarse_order=False, shard=None, k_hint=0, borrow=False):
-        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid, coarse_order, shard, k_hint, borrow)))
+    def rebuild_dev(self, d_xyz_ptr, n, voxel_grid=None, coarse_order=False, shard=None, k_hint=0, borrow=False, shard_range=None):
+        check(self._lib.pcpx_index_rebuild_dev(self._h, C.c_void_p(d_xyz_ptr), n, self._params(voxel_grid, coarse_order, shard, k_hint, borrow, shard_range)))
         self.n_in = n
 
     def knn_self_curve_order_dev(self, k, eps, d_idx, d_cnt, d_d2=None, d_normals=None, first=0, count=_capi.UINT64_MAX):
@@ -277,6 +291,50 @@ class Index:
     def knn_self_dev(self, k, eps, d_idx, d_cnt, d_d2=None, first=0, count=_capi.UINT64_MAX):
         check(self._lib.pcpx_knn_self_dev(self._h, k, eps, first, count, C.c_void_p(d_idx), C.c_void_p(d_cnt),
                                           C.c_void_p(d_d2) if d_d2 else None))
+
+    def knn_self_strided_dev(self, k, eps, row_stride, d_idx, d_cnt, d_d2=None, first=0, count=_capi.UINT64_MAX):
+        """knn_self_dev with row_stride entries between rows (16 for k = 15 / 16: a row is one aligned 64-byte piece)."""
+        check(self._lib.pcpx_knn_self_strided_dev(self._h, k, eps, first, count, row_stride, C.c_void_p(d_idx), C.c_void_p(d_cnt),
+                                                  C.c_void_p(d_d2) if d_d2 else None))
+
+    def normals_knn_self_strided_dev(self, k, eps, row_stride, d_normals, d_idx=None, d_cnt=None, first=0, count=_capi.UINT64_MAX):
+        check(self._lib.pcpx_normals_knn_self_strided_dev(self._h, k, eps, first, count, row_stride, C.c_void_p(d_normals),
+                                                          C.c_void_p(d_idx) if d_idx else None, C.c_void_p(d_cnt) if d_cnt else None))
+
+    def knn_group_costs(self, k, eps=1e-5, group_stride=16):
+        """pcpx_knn_group_costs_dev: event counts (nsamples x 4, uint32, on the host) of one query group in every group_stride of the
+        curve order -- what shard_cuts_by_cost cuts by.  Deterministic: every rank gets the same table from the same cloud and grid."""
+        ns = C.c_uint64(0)
+        st = self._lib.pcpx_knn_group_costs_dev(self._h, k, eps, group_stride, None, 0, C.byref(ns))
+        if st not in (_capi.PCPX_OK, _capi.PCPX_ERR_CAPACITY):
+            check(st)
+        out = np.zeros((int(ns.value), 4), np.uint32)
+        if ns.value == 0:
+            return out
+        d = C.c_void_p(None)
+        check(self._lib.pcpx_device_malloc(out.nbytes, self.device, C.byref(d)))
+        try:
+            check(self._lib.pcpx_knn_group_costs_dev(self._h, k, eps, group_stride, d, ns.value, C.byref(ns)))
+            self.synchronize()
+            check(self._lib.pcpx_device_download(_vp(out), d, out.nbytes, self.device, None))
+        finally:
+            self._lib.pcpx_device_free(d, self.device)
+        return out
+
+    def debug_set(self, name, value):
+        """pcpx_debug_set: 'long_groups_first', 'gather_outputs' (how work is done, never what comes out)."""
+        check(self._lib.pcpx_debug_set(self._h, name.encode(), int(value)))
+
+    def debug_group_times(self):
+        """Ticks / 64 per query group of the last recorded self-kNN launch (uint32 array; empty: nothing recorded)."""
+        ng = C.c_uint64(0)
+        st = self._lib.pcpx_debug_group_times(self._h, None, 0, C.byref(ng))
+        if st not in (_capi.PCPX_OK, _capi.PCPX_ERR_CAPACITY):
+            check(st)
+        out = np.zeros(int(ng.value), np.uint32)
+        if ng.value:
+            check(self._lib.pcpx_debug_group_times(self._h, _vp(out), ng.value, C.byref(ng)))
+        return out
 
     def knn_batch_dev(self, d_queries, nq, k, eps, d_idx, d_cnt, d_d2=None):
         """kNN of nq arbitrary device-resident query points (curve-sorted internally, rows in query order)."""

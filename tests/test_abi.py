@@ -48,7 +48,7 @@ def test_header_compiles_as_c(tmp_path):
 
 def test_abi_version_and_shard_range(lib):
     hdr = open(os.path.join(ROOT, "include", "pcpx.h")).read()
-    assert lib.pcpx_abi_version() == int(re.search(r"#define PCPX_ABI_VERSION (\d+)", hdr).group(1)) == 4
+    assert lib.pcpx_abi_version() == int(re.search(r"#define PCPX_ABI_VERSION (\d+)", hdr).group(1)) == 5
     a, b = C.c_uint64(), C.c_uint64()
     n = 10_000_019
     total, prev_end = 0, 0
@@ -59,6 +59,34 @@ def test_abi_version_and_shard_range(lib):
         total += b.value
     assert total == n
     assert lib.pcpx_shard_range(n, 8, 8, C.byref(a), C.byref(b)) != 0
+
+
+def test_shard_cuts_by_cost_are_balanced_and_exhaustive(lib, pkg):
+    """pcpx_shard_cuts_by_cost (host arithmetic, no GPU): cuts are 64-aligned, ordered, cover [0, n), and shards carry equal
+    estimated cost; a flat table reproduces pcpx_shard_range to within one sampled block."""
+    rng = np.random.default_rng(5)
+    n, stride, world = 1_000_003, 16, 8
+    groups = (n + 63) // 64
+    ns = groups // stride
+    ev = np.zeros((ns, 4), np.uint32)
+    ev[:, 0] = rng.integers(60, 140, ns)
+    ev[: ns // 4, 0] *= 3  # the first quarter of the curve is three times as expensive
+    ev[:, 2] = rng.integers(40, 90, ns)
+    ev[:, 3] = (rng.integers(10, 40, ns) << 16) | rng.integers(50, 120, ns)
+    cuts = pkg.shard_cuts_by_cost(n, world, stride, ev)
+    assert cuts[0] == 0 and cuts[-1] == n and all(c % 64 == 0 for c in cuts[:-1]) and cuts == sorted(cuts)
+    cost = 6000 + 112 * ev[:, 0].astype(np.int64) + 108 * ev[:, 1] + 38 * ev[:, 2] + 11 * (ev[:, 3] & 0xFFFF) + 140 * (ev[:, 3] >> 16)
+    per_group = np.repeat(cost, stride)
+    per_group = np.concatenate([per_group, np.full(groups - len(per_group), cost[-1])])
+    shard_cost = [per_group[cuts[r] // 64:(cuts[r + 1] + 63) // 64].sum() for r in range(world)]
+    assert max(shard_cost) / (sum(shard_cost) / world) < 1.01
+    assert cuts[2] < n // 4 < cuts[3] or cuts[3] <= n // 4 + 64 * stride  # the expensive quarter is cut into more than two shards
+    flat = pkg.shard_cuts_by_cost(n, world, stride, np.ones((ns, 4), np.uint32))
+    for r in range(world):
+        assert abs(flat[r] - pkg.shard_range(n, r, world)[0]) <= 64 * stride
+    assert pkg.shard_cuts_by_cost(100, 4, 16, np.zeros((0, 4), np.uint32)) == [0, 0, 64, 64, 100]
+    with pytest.raises(pkg.PcpxError):
+        pkg.shard_cuts_by_cost(n, world, stride, ev[:-1])
 
 
 def test_code_object_targets_gfx950(lib, pkg):

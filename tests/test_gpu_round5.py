@@ -1,0 +1,223 @@
+"""Round 5's ways of doing the same work differently, each against the plain form BIT FOR BIT (torch.equal):
+
+* rows with a pitch (pcpx_knn_self_strided_dev / pcpx_normals_knn_self_strided_dev): whole 64-byte rows in 16-byte stores;
+* input-order normals + counts through the gather-form permute ("gather_outputs");
+* query groups handed out by recorded times, long groups first ("long_groups_first");
+* shards cut by sampled WORK (pcpx_knn_group_costs_dev -> pcpx_shard_cuts_by_cost -> PCPX_BUILD_SHARD_RANGE): the table is the same
+  from two handles (every rank of a job must compute the same cuts), the rank-local handles of the cuts reproduce the whole-cloud
+  index, and the shards' measured times are closer together than equal-count shards' on the clustered cloud;
+* one rank-local handle asked a growing sequence of radii and then a kNN (the selection's cell count was double
+  counted when a radius widened the halo, which switched the coverage check off).
+
+Reference semantics: include/pcp/octree/linked_octree_node.hpp:453-570 (nearest_neighbours), :581-614 (range_search),
+include/pcp/algorithm/estimate_normals.hpp:80-92 (the loop the shards cut)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    return pytest.importorskip("torch")
+
+
+def _cloud(pkg, kind, n):
+    return pkg.synthetic.uniform_cloud(n, 11) if kind == "uniform" else pkg.synthetic.clustered_cloud(n, 12)
+
+
+def _plain(torch, ix, n, k, first=0, count=None):
+    dev = torch.device("cuda", 0)
+    idx = torch.full((n, k), -7, dtype=torch.int32, device=dev)
+    cnt = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    d2 = torch.full((n, k), -7.0, dtype=torch.float32, device=dev)
+    nrm = torch.full((n, 3), -7.0, dtype=torch.float32, device=dev)
+    kw = {} if count is None else dict(first=first, count=count)
+    ix.debug_set("gather_outputs", 0)
+    ix.debug_set("long_groups_first", 0)
+    ix.knn_self_dev(k, 1e-5, idx.data_ptr(), cnt.data_ptr(), d2.data_ptr(), **kw)
+    if k <= 32:
+        i2, c2 = torch.empty_like(idx), torch.empty_like(cnt)
+        ix.normals_knn_self_dev(k, 1e-5, nrm.data_ptr(), i2.data_ptr(), c2.data_ptr(), **kw)
+    ix.synchronize()
+    ix.debug_set("gather_outputs", 1)
+    ix.debug_set("long_groups_first", 1)
+    return idx, cnt, d2, nrm
+
+
+@pytest.mark.parametrize("k,stride", [(15, 16), (16, 16), (7, 8), (8, 8), (31, 32), (32, 32), (12, 16), (15, 20), (3, 8), (20, 32)])
+def test_rows_with_a_pitch_equal_packed_rows(pkg, k, stride):
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(k)
+    pts = np.concatenate([_cloud(pkg, "clustered", 150_000), rng.uniform(-0.3, 1.3, (5_000, 3)).astype(np.float32)])
+    pts[-50:] = pts[:50]  # exact ties
+    n = len(pts)
+    grid = np.array([0, 0, 0, 1, 1, 1], np.float32)  # some points fall outside: their rows are left alone
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid)
+    idx, cnt, d2, nrm = _plain(torch, ix, n, k)
+    for gather in (0, 1):
+        ix.debug_set("gather_outputs", gather)
+        sidx = torch.full((n, stride), -7, dtype=torch.int32, device=dev)
+        sd2 = torch.full((n, stride), -7.0, dtype=torch.float32, device=dev)
+        scnt = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        ix.knn_self_strided_dev(k, 1e-5, stride, sidx.data_ptr(), scnt.data_ptr(), sd2.data_ptr())
+        nidx = torch.full((n, stride), -7, dtype=torch.int32, device=dev)
+        ncnt = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        snrm = torch.full((n, 3), -7.0, dtype=torch.float32, device=dev)
+        ix.normals_knn_self_strided_dev(k, 1e-5, stride, snrm.data_ptr(), nidx.data_ptr(), ncnt.data_ptr())
+        ix.synchronize()
+        assert torch.equal(sidx[:, :k], idx) and torch.equal(sd2[:, :k], d2) and torch.equal(scnt, cnt)
+        assert torch.equal(nidx[:, :k], idx) and torch.equal(ncnt, cnt) and torch.equal(snrm, nrm)
+        answered = cnt >= 0  # (a point outside the grid has no row: everything about it stays as it was)
+        assert int((~answered).sum()) > 0
+        kcap = 8 if k <= 8 else 16 if k <= 16 else 32  # (the kernel's list length for this k)
+        if stride == kcap and k >= kcap - 1:
+            # a whole row is written: the entries beyond k are padding
+            assert bool((sidx[answered][:, k:] == -1).all()) and bool(torch.isinf(sd2[answered][:, k:]).all())
+        assert bool((sidx[~answered] == -7).all()) and bool((snrm[~answered] == -7).all())
+    with pytest.raises(pkg.PcpxError):
+        ix.knn_self_strided_dev(k, 1e-5, k - 1, sidx.data_ptr(), scnt.data_ptr())
+    ix.close()
+
+
+@pytest.mark.parametrize("kind,n,k", [("uniform", 300_000, 15), ("clustered", 400_000, 15), ("clustered", 250_000, 32), ("uniform", 100_000, 8)])
+def test_gather_form_and_recorded_order_change_nothing(pkg, kind, n, k):
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    pts = _cloud(pkg, kind, n)
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n)
+    idx, cnt, d2, nrm = _plain(torch, ix, n, k)
+    # three identical launches: the first records, the second makes and uses the order, the third uses it; then slices (a slice that
+    # starts and ends inside groups), which record anew
+    for trip in range(3):
+        i2 = torch.full((n, k), -7, dtype=torch.int32, device=dev)
+        c2 = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        n2 = torch.full((n, 3), -7.0, dtype=torch.float32, device=dev)
+        ix.normals_knn_self_dev(k, 1e-5, n2.data_ptr(), i2.data_ptr(), c2.data_ptr())
+        ix.synchronize()
+        assert torch.equal(i2, idx) and torch.equal(c2, cnt) and torch.equal(n2, nrm), trip
+    size = ix.size()
+    first, count = (size // 3) // 64 * 64, size // 2 + 17
+    pidx, pcnt, pd2, pnrm = _plain(torch, ix, n, k, first, count)
+    for trip in range(3):
+        i2 = torch.full((n, k), -7, dtype=torch.int32, device=dev)
+        c2 = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        n2 = torch.full((n, 3), -7.0, dtype=torch.float32, device=dev)
+        ix.normals_knn_self_dev(k, 1e-5, n2.data_ptr(), i2.data_ptr(), c2.data_ptr(), first=first, count=count)
+        ix.synchronize()
+        assert torch.equal(i2, pidx) and torch.equal(c2, pcnt) and torch.equal(n2, pnrm), trip
+        assert int((c2 >= 0).sum()) == count
+    # a rebuild forgets the recorded order (the groups are other groups)
+    ix.rebuild_dev(d_pts.data_ptr(), n // 2)
+    m = n // 2
+    i3 = torch.full((m, k), -7, dtype=torch.int32, device=dev)
+    c3 = torch.full((m,), -7, dtype=torch.int32, device=dev)
+    n3 = torch.full((m, 3), -7.0, dtype=torch.float32, device=dev)
+    ix.normals_knn_self_dev(k, 1e-5, n3.data_ptr(), i3.data_ptr(), c3.data_ptr())
+    ix.synchronize()
+    ridx, rcnt, rd2, rnrm = _plain(torch, ix, m, k)
+    assert torch.equal(i3, ridx) and torch.equal(c3, rcnt) and torch.equal(n3, rnrm)
+    ix.close()
+
+
+def _time_ms(torch, fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+@pytest.mark.parametrize("kind,n,k,world", [("clustered", 2_000_000, 15, 8), ("uniform", 500_000, 15, 4), ("clustered", 600_000, 32, 3)])
+def test_shards_cut_by_sampled_work(pkg, kind, n, k, world):
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    pts = _cloud(pkg, kind, n)
+    grid = np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32)
+    d_pts = torch.from_numpy(pts).to(dev)
+    cs = torch.cuda.current_stream().cuda_stream
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid, stream=cs)
+    stride = 16
+    ev = ix.knn_group_costs(k, 1e-5, stride)
+    groups = (ix.size() + 63) // 64
+    assert ev.shape == (groups // stride, 4) and (ev[:, 0] > 0).all()
+    # the same table from a second handle and from a second call (every rank of a job must compute the same cuts)
+    iy = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid, stream=cs)
+    assert np.array_equal(iy.knn_group_costs(k, 1e-5, stride), ev) and np.array_equal(ix.knn_group_costs(k, 1e-5, stride), ev)
+    iy.close()
+    cuts = pkg.shard_cuts_by_cost(ix.size(), world, stride, ev)
+    assert cuts[0] == 0 and cuts[-1] == ix.size() and cuts == sorted(cuts)
+    idx, cnt, d2, nrm = _plain(torch, ix, n, k)
+    sidx = torch.full((n, k), -7, dtype=torch.int32, device=dev)
+    scnt = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    snrm = torch.full((n, 3), -7.0, dtype=torch.float32, device=dev)
+    by_work, by_count = [], []
+    sh = None
+    for rank in range(world):
+        first, count = cuts[rank], cuts[rank + 1] - cuts[rank]
+        kw = dict(voxel_grid=grid, shard=(rank, world), shard_range=(first, count), k_hint=k, stream=cs)
+        if sh is None:
+            sh = pkg.Index.from_device(d_pts.data_ptr(), n, **kw)
+        else:
+            kw.pop("stream")
+            sh.rebuild_dev(d_pts.data_ptr(), n, **kw)
+        si = sh.shard_info()
+        assert si["shard_first"] == first and si["shard_count"] == count
+        sh.normals_knn_self_dev(k, 1e-5, snrm.data_ptr(), sidx.data_ptr(), scnt.data_ptr(), first, count)
+        sh.synchronize()
+        by_work.append(_time_ms(torch, lambda: sh.normals_knn_self_dev(k, 1e-5, snrm.data_ptr(), sidx.data_ptr(), scnt.data_ptr(), first, count)))
+    assert torch.equal(sidx, idx) and torch.equal(scnt, cnt) and torch.equal(snrm, nrm)
+    tidx, tcnt, tnrm = torch.empty_like(sidx), torch.empty_like(scnt), torch.empty_like(snrm)
+    for rank in range(world):
+        first, count = pkg.shard_range(ix.size(), rank, world)
+        sh.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid, shard=(rank, world), k_hint=k)
+        by_count.append(_time_ms(torch, lambda: sh.normals_knn_self_dev(k, 1e-5, tnrm.data_ptr(), tidx.data_ptr(), tcnt.data_ptr(), first, count)))
+    sh.close()
+    ix.close()
+    spread_work, spread_count = max(by_work) / (sum(by_work) / world), max(by_count) / (sum(by_count) / world)
+    print("%s n=%d k=%d world=%d: slowest/mean by work %.3f (slowest %.3f ms), by count %.3f (slowest %.3f ms)"
+          % (kind, n, k, world, spread_work, max(by_work), spread_count, max(by_count)))
+    if kind == "clustered" and world == 8:
+        assert spread_work < spread_count and spread_work < 1.10
+
+
+def test_one_rank_local_handle_asked_growing_radii_then_knn(pkg):
+    """a radius that widens the halo re-ran the selection's pack step, which counted cells that were selected
+    already; at world = 2 the count passed the number of cells, `everything` became true and later calls skipped both the coverage
+    check and further halo growth."""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    n, k, world = 400_000, 15, 2
+    pts = pkg.synthetic.uniform_cloud(n, 21)
+    grid = np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32)
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid)
+    idx, cnt, d2, nrm = _plain(torch, ix, n, k)
+    for rank in range(world):
+        first, count = pkg.shard_range(ix.size(), rank, world)
+        sh = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid, shard=(rank, world), k_hint=k)
+        for r in (0.01, 0.03, 0.08, 0.2):  # each wider than the halo before it
+            want = torch.zeros(n, dtype=torch.int32, device=dev)
+            got = torch.zeros(n, dtype=torch.int32, device=dev)
+            ix.range_count_self_dev(r, want.data_ptr(), first, count)
+            sh.range_count_self_dev(r, got.data_ptr(), first, count)
+            ix.synchronize()
+            sh.synchronize()
+            assert torch.equal(got, want), r
+        assert sh.shard_info()["local_points"] < ix.size()  # (not everything: the check stays on)
+        sidx = torch.full((n, k), -7, dtype=torch.int32, device=dev)
+        scnt = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        sd2 = torch.full((n, k), -7.0, dtype=torch.float32, device=dev)
+        sh.knn_self_dev(k, 1e-5, sidx.data_ptr(), scnt.data_ptr(), sd2.data_ptr(), first, count)
+        sh.synchronize()
+        sel = scnt >= 0
+        assert int(sel.sum()) == count and torch.equal(sidx[sel], idx[sel]) and torch.equal(sd2[sel], d2[sel])
+        sh.close()
+    ix.close()
