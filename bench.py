@@ -118,6 +118,33 @@ def cpu_baseline(pts, k, budget_s=12.0):
                                             "runs the policy on the calling thread" % par_n}}
 
 
+def row_pitch(k):
+    """Entries between the rows of the index output: a row of k = 15 neighbours is written with a pitch of 16 -- one aligned 64-byte
+    piece, in 16-byte stores (pcpx_knn_self_strided_dev; the reference returns a std::vector per query, so the pitch is the
+    library's to choose).  PCPX_BENCH_ROW_PITCH=0: packed rows of k entries, as rounds 1-4 measured."""
+    env = os.environ.get("PCPX_BENCH_ROW_PITCH", "auto")
+    if env != "auto":
+        return int(env)
+    kcap = 8 if k <= 8 else 16 if k <= 16 else 32
+    return kcap if k in (kcap - 1, kcap) else 0
+
+
+def shard_cuts(pkg, torch, d_pts, n, k, grid, world, stream, dev_index, by_work):
+    """world + 1 curve positions.  by_work: every rank indexes the whole cloud once (set-up, outside the step), runs the k-NN walk
+    for one query group in 16 (pcpx_knn_group_costs_dev: deterministic event counts -- every rank computes the same table from its
+    replica of the cloud, nothing is exchanged) and cuts the curve order into shards of equal estimated work
+    (pcpx_shard_cuts_by_cost); otherwise equal query counts (pcpx_shard_range)."""
+    if not by_work:
+        return [pkg.shard_range(n, r, world)[0] for r in range(world)] + [n], None
+    t0 = time.perf_counter()
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=dev_index, stream=stream, voxel_grid=grid)
+    ev = ix.knn_group_costs(k, 1e-5, 16)
+    cuts = pkg.shard_cuts_by_cost(ix.size(), world, 16, ev)
+    ix.close()
+    torch.cuda.synchronize()
+    return cuts, (time.perf_counter() - t0) * 1e3
+
+
 def _reduce(torch, dist, value, op, dev, rehearse):
     """All-reduce one number over the ranks (RCCL on the device; CPU tensor over gloo in the one-GPU rehearsal)."""
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -147,16 +174,24 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
     streaming = name in STREAMING
     # N > 1: the rank-local index (PCPX_BUILD_SHARD); the cloud is read in place (PCPX_BUILD_BORROW_CLOUD) when it is rebuilt every step
     local = world > 1 and os.environ.get("PCPX_BENCH_REPLICATED") != "1"
+    # ... of a shard cut by WORK for a static index (the streaming cloud moves every step and is uniform: equal counts)
+    by_work = local and not streaming and os.environ.get("PCPX_BENCH_CUT", "work") == "work"
+    cuts, cut_ms = shard_cuts(pkg, torch, d_pts, n, k, grid, world, stream, dev.index, by_work)
+    first, count = cuts[rank], cuts[rank + 1] - cuts[rank]
     build_kw = dict(voxel_grid=grid, shard=(rank, world), k_hint=k, borrow=streaming) if local else dict(voxel_grid=grid)
+    if by_work:
+        build_kw["shard_range"] = (first, count)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=dev.index, stream=stream, **build_kw)
     torch.cuda.synchronize()
     first_build_ms = (time.perf_counter() - t0) * 1e3
     assert ix.size() == n
-    first, count = mg.query_shard(n, rank, world)
+    if not by_work:
+        first, count = mg.query_shard(n, rank, world)
 
-    d_idx = torch.empty((n, k), dtype=torch.int32, device=dev)
+    pitch = row_pitch(k)
+    d_idx = torch.empty((n, pitch or k), dtype=torch.int32, device=dev)
     d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)  # rows outside this rank's shard stay 0
     d_nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
 
@@ -172,15 +207,22 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         def step():
             it_no[0] += 1
             ix.rebuild_dev(variants[it_no[0] % len(variants)].data_ptr(), n, **build_kw)
-            ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
+            ix.knn_self_strided_dev(k, 1e-5, pitch, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
     elif at_curve_positions:  # (--rows-at-curve-positions: the same launch with rows and normals at curve positions; for the counter passes)
         def step():
             ix.knn_self_curve_order_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, d_nrm.data_ptr(), first, count)
     else:
         def step():
-            ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
+            ix.normals_knn_self_strided_dev(k, 1e-5, pitch, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
 
-    for _ in range(warmup):
+    # the first step on its own: it includes what later ones do not repeat on a static index -- the rank-local index's coverage
+    # check (N > 1) and the recording of the query groups' times that the later steps' order is made from
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_step_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(max(0, warmup - 1)):
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -248,7 +290,8 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
            "mqps": n * steps / elapsed / 1e6, "first_build_ms": first_build_ms, "rebuild_ms": rebuild_ms,
            "profile": prof, "shard": (first, count), "pts": pts, "complete": complete,
            "min_count": int(d_cnt.min().item()) if world == 1 else None, "grid": grid,
-           "local_index": ix.shard_info() if local else None}
+           "local_index": ix.shard_info() if local else None, "first_step_ms": first_step_ms, "row_pitch": pitch,
+           "cut": ("work: one group in 16 sampled on a whole-cloud index, %.1f ms of set-up per rank" % cut_ms) if by_work else "equal query counts"}
     ix.close()
     return res
 
@@ -261,27 +304,37 @@ def eighth_shard_projection(pkg, torch, name, pts, grid, steps=3, world=8):
     stream = torch.cuda.current_stream().cuda_stream
     streaming = name in STREAMING
     d_pts = torch.from_numpy(pts).to(dev)
-    d_idx = torch.empty((n, k), dtype=torch.int32, device=dev)
+    pitch = row_pitch(k)
+    d_idx = torch.empty((n, pitch or k), dtype=torch.int32, device=dev)
     d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     d_nrm = None if streaming else torch.empty((n, 3), dtype=torch.float32, device=dev)
-    per_rank, builds, trees = [], [], []
+    per_rank, builds, trees, firsts = [], [], [], []
+    by_work = not streaming and os.environ.get("PCPX_BENCH_CUT", "work") == "work"
+    cuts, cut_ms = shard_cuts(pkg, torch, d_pts, n, k, grid, world, stream, dev.index, by_work)
     ix = None
     for rank in range(world):
+        first, count = cuts[rank], cuts[rank + 1] - cuts[rank]
         kw = dict(voxel_grid=grid, shard=(rank, world), k_hint=k, borrow=streaming)
+        if by_work:
+            kw["shard_range"] = (first, count)
         t0 = time.perf_counter()
         if ix is None:
             ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=dev.index, stream=stream, **kw)
         else:
             ix.rebuild_dev(d_pts.data_ptr(), n, **kw)
-        first, count = pkg.shard_range(n, rank, world)
 
         def step():
             if streaming:
                 ix.rebuild_dev(d_pts.data_ptr(), n, **kw)
-                ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
+                ix.knn_self_strided_dev(k, 1e-5, pitch, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
             else:
-                ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
+                ix.normals_knn_self_strided_dev(k, 1e-5, pitch, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
 
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        firsts.append((time.perf_counter() - t0) * 1e3)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -298,8 +351,12 @@ def eighth_shard_projection(pkg, torch, name, pts, grid, steps=3, world=8):
         trees.append(ix.shard_info()["local_points"])
     ix.close()
     return {"projection": "one rank's share of an %d-rank step, every rank in turn on this one GPU (rank-local index, no RCCL); not a "
-                          "measurement on %d GPUs" % (world, world),
+                          "measurement on %d GPUs.  ms_*_rank: the steady state of a static index asked the same question again (coverage "
+                          "verified once, query groups handed out by the times the first step recorded); ms_first_step_slowest_rank: a "
+                          "rank's first step, with both" % (world, world),
+            "cut": ("shards of equal estimated work (pcpx_shard_cuts_by_cost; %.1f ms of set-up per rank)" % cut_ms) if by_work else "shards of equal query counts",
             "ms_slowest_rank": round(max(per_rank), 4), "ms_mean_rank": round(sum(per_rank) / world, 4),
+            "slowest_over_mean": round(max(per_rank) / (sum(per_rank) / world), 3), "ms_first_step_slowest_rank": round(max(firsts), 4),
             "rank_local_build_ms_slowest": round(max(builds), 4), "rank_local_tree_points_max": max(trees),
             "rank_local_tree_fraction_of_cloud": round(max(trees) / n, 4)}
 
@@ -526,7 +583,8 @@ def main():
                             rehearse=rehearse, side=side, collective=collective, at_curve_positions=args.rows_at_curve_positions)
     n, k = main_res["n"], main_res["k"]
 
-    extra = {"index_build_ms_first": round(main_res["first_build_ms"], 3), "shard_of_rank0": list(main_res["shard"])}
+    extra = {"index_build_ms_first": round(main_res["first_build_ms"], 3), "shard_of_rank0": list(main_res["shard"]),
+             "first_step_ms": round(main_res["first_step_ms"], 4), "row_pitch_entries": main_res["row_pitch"] or k, "shard_cut": main_res["cut"]}
     if main_res["rebuild_ms"] is not None:
         reb = main_res["rebuild_ms"]
         extra["index_rebuild_ms"] = round(reb, 3)

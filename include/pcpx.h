@@ -332,7 +332,8 @@ int pcpx_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t* out_fi
  * eight equal-count shards takes 14 % longer than their mean).  pcpx_knn_group_costs_dev runs the k-NN walk (no rows are written)
  * for one query group in every `group_stride` of the whole cloud's curve order -- group i * stride + stride / 2 stands for groups
  * [i * stride, (i + 1) * stride) -- on a WHOLE-CLOUD handle and leaves four event counts per sampled group in d_out_events
- * ({node expansions, leaves looked at lane-per-query, leaves looked at in the packed form, folds << 16 | packed steps}):
+ * ({node expansions, leaves looked at lane-per-query [bits 24-31: walk rounds after the first], leaves looked at in the packed form
+ * [bits 20-31: lanes those rounds ran for], folds << 16 | packed steps}):
  * integers that depend on the cloud, the grid and (k, eps) alone, so every rank of a job computes the same table from its
  * replica of the cloud, and the all-gather of the boxes stays the only collective.  *out_samples = groups / group_stride
  * (PCPX_ERR_CAPACITY if `capacity` samples do not hold them; d_out_events may be NULL to ask).  1 <= k <= 32.
@@ -397,8 +398,8 @@ int pcpx_debug_knn_stats(pcpx_index* idx, uint32_t k, float eps, uint64_t* out_s
 int pcpx_debug_eps_test_mode(pcpx_index* idx, int mode);
 /* Switches of the handle that change how work is done, never what comes out (the tests run both sides of each):
  * "long_groups_first" (default 1): a self-kNN launch that repeats the previous one's question on the same tree hands its query
- * groups out by the times that launch recorded, the longest first; "gather_outputs" (default 1): input-order normals and counts
- * are written at curve positions and permuted by a gather instead of being scattered from the search kernel. */
+ * groups out by the times that launch recorded, the longest first; "gather_outputs" (default 0: measured slower): input-order
+ * normals and counts are written at curve positions and permuted by a gather instead of being scattered from the search kernel. */
 int pcpx_debug_set(pcpx_index* idx, const char* name, int64_t value);
 /* What the handle's last recorded self-kNN launch took per query group (shader-clock ticks / 64, search only; host array of
  * *out_groups entries, the launch's groups in curve order; 0 groups: nothing recorded).  PCPX_ERR_CAPACITY reports the size. */

@@ -1344,8 +1344,8 @@ int pcpx_normals_knn_self_strided_dev(pcpx_index* h, uint32_t k, float eps, uint
         o.normals = nullptr;
         o.cnt = nullptr;
         if ((st = launch_knn(*ix, qv, true, gf, gc, k, eps, o)) != PCPX_OK) return st;
-        u64 lo = sorted_first > ix->n ? ix->n : sorted_first;
-        u64 hi = sorted_count > ix->n - lo ? ix->n : lo + sorted_count;
+        // (what the launch answered: whole groups -- a slice that ends inside a group is answered to that group's end)
+        const u64 lo = gf * GROUP, hi = (gf + gc) * GROUP < ix->n ? (gf + gc) * GROUP : ix->n;
         return launch_gather_nc4(*ix, ix->d_nc4, ix->d_pos_of, ix->n_in, static_cast<u32>(lo), static_cast<u32>(hi), d_out_normals, d_opt_out_count);
     }
     if (k > 32 && (!o.idx || !o.cnt)) {  // the multi-pass path materialises rows: keep them in index scratch
@@ -1706,7 +1706,7 @@ int pcpx_knn_group_costs_dev(pcpx_index* h, uint32_t k, float eps, uint32_t grou
 // ~10 per step of eight needing lanes, a fold the selection network; the constant is a group's seed phase, cap and epilogue.
 static inline uint64_t group_cost_of(const uint32_t e[4])
 {
-    const uint64_t folds = e[3] >> 16, steps = e[3] & 0xFFFFu, dense = e[1], packed = e[2];
+    const uint64_t folds = e[3] >> 16, steps = e[3] & 0xFFFFu, dense = e[1] & 0xFFFFFFu, packed = e[2] & 0xFFFFFu;
     return 6000ull + 112ull * e[0] + 108ull * dense + 38ull * packed + 11ull * steps + 140ull * folds;
 }
 

@@ -247,7 +247,8 @@ struct Index {
     bool pos_of_valid = false;
     struct Tuning {
         int lpt = 1;              // long groups first on repeated self-kNN launches
-        int gather = 1;           // input-order normals + counts through the gather-form permute
+        int gather = 0;           // input-order normals + counts through the gather-form permute (measured round 5: 1-3 % SLOWER than the
+                                  // direct scattered stores on the 10 M clouds -- the search kernel is not bound by them; kept as a switch)
     } tuning;
     int eps_test_mode = 0;  // k_knn's eps-box test: 0 = where it is cheaper (query.hip: eps_box_threshold), 1 = in the compaction, 2 = per candidate
 

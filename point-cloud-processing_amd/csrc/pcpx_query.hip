@@ -176,6 +176,12 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_PRIO_PACKED
 #define PCPX_PRIO_PACKED 2  // the packed leaf (three dependent LDS round trips on top of its loads) one step above the rest: +0.8 % (five rounds)
 #endif
+#ifndef PCPX_PRIO_LATER
+#define PCPX_PRIO_LATER 3  // a group from its second walk round on (see knn_group: fold)
+#endif
+#ifndef PCPX_SHELL_PACKED
+#define PCPX_SHELL_PACKED 1  // the packed leaf form in the later walk rounds too (few lanes are still searching there)
+#endif
 #ifndef PCPX_PRIO_WALK
 #define PCPX_PRIO_WALK PCPX_PRIO_BASE
 #endif
@@ -587,7 +593,7 @@ __device__ __forceinline__ T cold(const __attribute__((address_space(4))) T* fie
 template <int KCAP, bool SELF, int DIAG, bool MULTI, bool EPS_EACH, int NZ>
 __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, const float eps, const float eps_thr,
                                           unsigned long long* __restrict__ stats, u64* __restrict__ col, float* __restrict__ pub, const u32 lane,
-                                          const u32 slot)
+                                          const u32 slot, const u32 part)
 {
     constexpr bool STATS = DIAG == 1, COST = DIAG == 2;
     constexpr int BUF = buf_rows(KCAP);  // usable rows (the multi-pass kernels have one more: the trash row BUF)
@@ -629,7 +635,9 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     const u32 p = p_here;
     const u32 nq = SELF ? t.n : ka->qv.nq;
     // (self queries: only the positions [pos_lo, pos_hi) the caller asked for -- a slice that starts or ends inside a group)
-    const bool valid = p < nq && (!SELF || p - pos_lo < pos_hi - pos_lo);
+    // (`part` = 0: the whole group; 1 ... ORDER_PARTS: only lanes 8 (part - 1) ... 8 part - 1 -- an eighth of a LONG group, whose other
+    //  eighths other waves answer at the same time: order_entries)
+    const bool valid = p < nq && (!SELF || p - pos_lo < pos_hi - pos_lo) && (part == 0u || ((p >> 3) & 7u) + 1u == part);  // (from p, which is opaque per group: from `lane` it is one more value kept from group to group)
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (valid) {
         if (SELF) {
@@ -713,13 +721,18 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;  // keeps only the write address `wa`; the other accept paths only `cnt`
 
     // fold the buffered keys into the best-list (one copy of the selection network per call site)
-    auto fold = [&](bool in_seed_phase) {
+    // `later`: the group is in a walk round after its first.  Such a group is a LONG one -- a few of its lanes sit in a sparse place and go
+    // round again with 4x the radius^2, up to a dozen times, while the rest of the launch moves on: on the clustered cloud the longest
+    // group takes 6x the mean, 0.9 ms of one wave's dependent instructions under the contention of the six other waves of its SIMD,
+    // and a short launch (one rank's eighth: 0.65 ms) cannot end before it does.  From its second round on a group therefore runs at
+    // PCPX_PRIO_LATER, above everything else on its SIMD, and its folds are not lowered: the chain then moves at a lone wave's pace.
+    auto fold = [&](bool in_seed_phase, bool later = false) {
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
         if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
-        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_FOLD);
+        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE && !later) __builtin_amdgcn_s_setprio(PCPX_PRIO_FOLD);
         if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF, NZ>(best, col, cnt, eps_filter);
         else compact<KCAP, BUF>(best, col, cnt);
-        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
+        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE && !later) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         tau = active ? fminf(nt, cap) : -1.f;
         if (STATS) tau = fminf(tau, tau_known);
@@ -734,9 +747,9 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         }
     };
     // before a leaf: fold if some lane could not take LEAF more keys; at the end of a phase: if any lane holds a key
-    auto fold_if_needed = [&](bool before_leaf, bool in_seed_phase) {
+    auto fold_if_needed = [&](bool before_leaf, bool in_seed_phase, bool later = false) {
         if (!fast) wa = col_addr + (static_cast<u32>(cnt) << 9);
-        if (any_lane(wa >= (before_leaf ? wa_full : lds_row0 + 512u))) fold(in_seed_phase);
+        if (any_lane(wa >= (before_leaf ? wa_full : lds_row0 + 512u))) fold(in_seed_phase, later);
     };
 
     // candidates of one leaf: SMEM broadcast, branch-free accept; `shell`: a later walk round
@@ -883,10 +896,13 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     // the publish row instead; the needing lane sees from the address it reads back that keys were lost, takes its column back
     // to where it was before the leaf (the rows written since hold PAD_KEY again), and the leaf is looked at once more for
     // those lanes after a fold.  Returns the lanes that want that (0: done).
-    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) -> u64 {
+    // SHELL (a tag): a later walk round -- only the new shell lo_d2 < d2 is accepted, and the wave keeps its raised priority.
+    // (one copy for both: a second inlined copy for the later rounds cost the k <= 16 kernel 20 B of scratch.  lo_d2 = -1 in the first
+    //  round, so its test passes there; the two priority steps are jumped over in the later rounds: two scalar instructions each)
+    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many, const bool shell) -> u64 {
         float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
         u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
-        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_PACKED);
+        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE && !shell) __builtin_amdgcn_s_setprio(PCPX_PRIO_PACKED);
         u32 lane_here = lane;
         asm volatile("" : "+v"(lane_here));  // (or everything below that depends on the lane alone sits in registers from group to group)
         const u32 j = lane_here & 7u, i = lane_here >> 3;
@@ -904,7 +920,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             const float4 q = pub_q[s + i];
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
             const float d2 = sq3(dx, dy, dz);
-            if (d2 <= q.w) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
+            if (d2 <= q.w && d2 > lo_d2) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
                 u32 one_row = 512u;
                 asm volatile("" : "+v"(one_row));  // (a v_mov here, not a register held from group to group)
                 u32 at = atomicAdd(pub_wa + s + i, one_row);
@@ -919,7 +935,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             reinterpret_cast<float*>(pub_q + r)[3] = -1.f;
         }
         __builtin_amdgcn_wave_barrier();
-        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
+        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE && !shell) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         if (packed_free == 0) {
             wa = now;
             return 0ull;
@@ -937,7 +953,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         return lost;
     };
     const u32 seed_count = s1 - s0;
-    u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;  // 0 in the shell rounds (they also want lo_d2 < d2)
+    u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;
     for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
@@ -977,7 +993,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                 if (loc - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
                     if (!packed_leaves) {
-                        fold_if_needed(true, false);
+                        fold_if_needed(true, false, rounds != 0u);
                         candidates(loc, rounds != 0u);
                     } else {
                         const u32 c = loc & (W - 1u);
@@ -996,10 +1012,10 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                         const u32 wa_was = wa;
                         u64 todo = who;  // (the lanes the leaf is still to be looked at for)
                         for (bool again = false;; again = true) {  // (one call site of the fold: one copy of the selection network)
-                            if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false);
+                            if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false, rounds != 0u);
                             if (!packed_form) break;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            todo = packed_leaf(loc, todo, how_many);
+                            todo = packed_leaf(loc, todo, how_many, rounds != 0u);
                             if (COST) st_steps += (how_many + 7u) >> 3;
                             if (STATS) {
                                 asm volatile("" ::"v"(wa));
@@ -1020,13 +1036,14 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             }
         }
         if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
-        fold_if_needed(false, false);
+        fold_if_needed(false, false, rounds != 0u);
         if (!(cap < inf)) break;
         // a capped round ended: lanes whose k-th distance is within the cap are exact; the others go round again with 4x the
         // radius^2, accepting only the new shell (lo_d2, cap]
         const float kth = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         const bool failed = active && !(kth <= cap);
         if (!any_lane(failed)) break;
+        if (COST) ++st_round2, st_later_lanes += static_cast<u32>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(failed)));
         if (STATS) {
             ++st_round2;
             if (tc_later_mark == 0) tc_later_mark = __builtin_amdgcn_s_memtime();  // the group's later rounds start here
@@ -1041,7 +1058,8 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         // after 12 rounds
         const float grown = cap * PCPX_CAP_GROW;
         ++rounds;
-        packed_limit = 0;
+        if (!PCPX_SHELL_PACKED) packed_limit = 0;  // (the later rounds want lo_d2 < d2 as well: packed_leaf tests it)
+        if (PCPX_PRIO_LATER != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_LATER);
         cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
         active = failed;
         tau = active ? fminf(kth, cap) : -1.f;
@@ -1092,7 +1110,9 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         u32* const events = cold(&knn_args_here()->sch.events);
         if (lane == 0) {
             uint4 e;
-            e.x = st_expand, e.y = st_leaves, e.z = st_sparse, e.w = (st_compact << 16) | (st_steps < 0xFFFFu ? st_steps : 0xFFFFu);
+            // (high bits, for diagnosis -- pcpx_shard_cuts_by_cost masks them off: walk rounds after the first, and the lanes they ran for)
+            e.x = st_expand, e.y = (st_leaves & 0xFFFFFFu) | (st_round2 << 24), e.z = (st_sparse & 0xFFFFFu) | ((st_later_lanes < 0xFFFu ? st_later_lanes : 0xFFFu) << 20),
+            e.w = (st_compact << 16) | (st_steps < 0xFFFFu ? st_steps : 0xFFFFu);
             reinterpret_cast<uint4*>(events)[slot] = e;
         }
     }
@@ -1299,6 +1319,11 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
 // on MI355X (19.0 vs 19.1 ms); note rocprofv3's MeanOccupancyPerCU reads 11.5 of 20 for both, i.e. it
 // under-reports on gfx950 (this grid is fully resident by construction).
 constexpr u32 QUEUE_STRIDE = 16;  // u32 per queue counter (64 B)
+// Format of KnnSchedule::order for a launch of `ngroups` groups (per = ceil(ngroups / 8) per queue): order[q] = entries of queue q,
+// q = 0 ... 7; queue q's entries start at order[ORDER_HEADER + ORDER_PARTS * q * per].  An entry is a group id (absolute), with
+// bits 28 ... 31 = 0 for the whole group or p + 1 for its lanes 8 p ... 8 p + 7 only.
+constexpr u32 ORDER_HEADER = 16, ORDER_PARTS = 8, ORDER_PART_SHIFT = 28, ORDER_GROUP_MASK = (1u << ORDER_PART_SHIFT) - 1u;
+inline u64 order_entries(u64 ngroups) { return ORDER_HEADER + ORDER_PARTS * 8ull * ((ngroups + 7) / 8); }
 
 template <int KCAP, bool SELF, int DIAG, bool MULTI = false, bool EPS_EACH = !PCPX_DEFER_EPS, int NZ = 0>
 __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 : KCAP <= 16 ? PCPX_MINW : PCPX_MINW32) void k_knn(
@@ -1341,7 +1366,9 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
         asm volatile("" : "+v"(lane_here));  // (or the mask of "lane == 0" is one more pair of scalar registers held across the search)
         if (lane_here == 0) gi = atomicAdd(&queue[q * QUEUE_STRIDE], 1u);
         gi = __builtin_amdgcn_readfirstlane(gi);
-        if (qbeg + gi >= qend) {
+        // (the queue's slots in curve order, or -- KnnSchedule::order -- the list a recorded launch suggests: order_entries)
+        const u32* const order = cold(&ka->sch.order);
+        if (order ? gi >= load_const(order + q) : qbeg + gi >= qend) {
             ++s;
             continue;
         }
@@ -1350,10 +1377,9 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
             tg = __builtin_amdgcn_s_memrealtime();
             tcg = __builtin_amdgcn_s_memtime();
         }
-        // (the launch's slots in curve order, or -- KnnSchedule::order -- in the order a recorded launch suggests: long groups first)
-        const u32* const order = cold(&ka->sch.order);
-        const u32 g = order ? load_const(order + qbeg + gi) : group_first + qbeg + gi;
-        knn_group<KCAP, SELF, DIAG, MULTI, EPS_EACH, NZ>(t, g, eps, eps_thr, stats, col, pub, lane, qbeg + gi);
+        const u32 entry = order ? load_const(order + ORDER_HEADER + ORDER_PARTS * qbeg + gi) : group_first + qbeg + gi;
+        const u32 g = entry & ORDER_GROUP_MASK;
+        knn_group<KCAP, SELF, DIAG, MULTI, EPS_EACH, NZ>(t, g, eps, eps_thr, stats, col, pub, lane, qbeg + gi, entry >> ORDER_PART_SHIFT);
         if (STATS) {
             if (lane == 0) atomicAdd(&stats[11], static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - tcg);
             ++n_done;
@@ -1430,10 +1456,27 @@ static float eps_box_threshold(const Index& ix, float eps)
 // place that go round the walk again), and a persistent launch ends when its last group does: one rank's eighth of a 10 M cloud is
 // 2.7 groups per resident wave, and a 3 x group handed out in the last round ends a whole group's time after everything else.
 // k_knn leaves every group's time behind (KnnSchedule::gtime); when the same question comes again on the same tree, the queues
-// hand their groups out in three classes -- above 7/4 of the queue's mean, above 9/8, the rest -- in curve order inside a class
-// (the queue still walks its eighth of the curve three times front to back: neighbours keep sharing the XCD's L2).
+// hand their groups out in three classes -- above 2 x the queue's mean, above 1.5 x, the rest -- in curve order inside a class
+// (a few per cent of the groups leave the curve order; the rest still walk the queue's eighth of the curve front to back, which
+// is what keeps the XCD's L2 warm).
+// And a LONG group is taken apart.  What makes a group long is seldom a straggler that goes round the walk again: on the clustered
+// cloud the longest groups have no later round at all -- 690 node expansions and 600 leaves in the first, nearly every leaf needed by
+// one or two lanes: 64 queries in a thin place whose search regions hardly overlap, so the wave-uniform walk does their 64 searches
+// one after the other (0.9 ms of dependent instructions; an eighth of the cloud takes 0.65 ms).  A class-0 group is handed out as
+// ORDER_PARTS entries of 8 lanes each: eight waves walk an eighth of the union each, at the price of seven more seed phases and
+// epilogues (a fifth of a mean group each, for less than 1 % of the groups).
 // One block per queue.
 constexpr u32 LPT_MIN_GROUPS = 512;
+#ifndef PCPX_LPT_SPLIT
+#define PCPX_LPT_SPLIT 1  // class-0 groups are handed out as ORDER_PARTS entries of 8 lanes each
+#endif
+#ifndef PCPX_LPT_HI_PCT
+#define PCPX_LPT_HI_PCT 200ull   // class 0: groups that took more than twice their queue's mean ...
+#endif
+#ifndef PCPX_LPT_MID_PCT
+#define PCPX_LPT_MID_PCT 150ull  // ... class 1: more than 1.5 x.  (7/4 and 9/8 -- a third of a uniform cloud's groups out of curve order -- cost the
+                                 //  10 M uniform launch 4 %: the queue's walk along the curve is what keeps its XCD's L2 warm.)
+#endif
 __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gtime, u32 ngroups, u32 group_first, u32* __restrict__ order)
 {
     __shared__ unsigned long long sum_s;
@@ -1441,7 +1484,10 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
     const u32 t = threadIdx.x, lane = t & 63u, w = t >> 6;
     const u32 per = (ngroups + 7u) >> 3;
     const u32 qbeg = blockIdx.x * per, qend = qbeg + per < ngroups ? qbeg + per : ngroups;
-    if (qbeg >= qend) return;
+    if (qbeg >= qend) {
+        if (t == 0) order[blockIdx.x] = 0;
+        return;
+    }
     if (t == 0) sum_s = 0;
     if (t < 3) cnt_s[t] = 0;
     __syncthreads();
@@ -1452,7 +1498,7 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
     if (lane == 0) atomicAdd(&sum_s, mine);
     __syncthreads();
     const unsigned long long mean = sum_s / (qend - qbeg);
-    const unsigned long long hi = mean * 7ull / 4ull, mid = mean * 9ull / 8ull;
+    const unsigned long long hi = mean * PCPX_LPT_HI_PCT / 100ull, mid = mean * PCPX_LPT_MID_PCT / 100ull;
     auto cls = [&](u32 v) -> u32 { return v > hi ? 0u : v > mid ? 1u : 2u; };
     u32 c[3] = {0, 0, 0};
     for (u32 i = qbeg + t; i < qend; i += 1024u) ++c[cls(gtime[i])];
@@ -1468,6 +1514,7 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
         base_s[0] = 0;
         base_s[1] = cnt_s[0];
         base_s[2] = cnt_s[0] + cnt_s[1];
+        order[blockIdx.x] = (PCPX_LPT_SPLIT ? ORDER_PARTS : 1u) * cnt_s[0] + cnt_s[1] + cnt_s[2];
     }
     __syncthreads();
     for (u32 i0 = qbeg; i0 < qend; i0 += 1024u) {
@@ -1485,7 +1532,13 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
         if (in) {
             u32 before = 0;
             for (u32 ww = 0; ww < w; ++ww) before += wave_s[b][ww];
-            order[qbeg + base_s[b] + before + below] = group_first + i;
+            const u32 at = ORDER_HEADER + ORDER_PARTS * qbeg;
+            if (b == 0 && PCPX_LPT_SPLIT) {
+#pragma unroll
+                for (u32 part = 0; part < ORDER_PARTS; ++part) order[at + ORDER_PARTS * (base_s[0] + before + below) + part] = (group_first + i) | ((part + 1u) << ORDER_PART_SHIFT);
+            } else {
+                order[at + (PCPX_LPT_SPLIT ? ORDER_PARTS - 1u : 0u) * cnt_s[0] + base_s[b] + before + below] = group_first + i;
+            }
         }
         __syncthreads();
         if (t < 3) {
@@ -1507,7 +1560,7 @@ static int sched_reserve(Index& ix, u64 groups)
     sc = Index::Sched{};
     const u64 cap = groups + groups / 8 + 64;
     if (hipMalloc(reinterpret_cast<void**>(&sc.d_gtime), cap * sizeof(u32)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&sc.d_order), cap * sizeof(u32)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&sc.d_order), order_entries(cap) * sizeof(u32)) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(sc.d_gtime);
         (void)hipFree(sc.d_order);
@@ -1557,7 +1610,12 @@ static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcoun
 __global__ void k_sample_order(u32 nsamples, u32 stride, u32* __restrict__ order)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nsamples) order[i] = i * stride + stride / 2u;
+    const u32 per = (nsamples + 7u) >> 3;
+    if (i < 8u) {
+        const u32 qbeg = i * per, qend = qbeg + per < nsamples ? qbeg + per : nsamples;
+        order[i] = qend > qbeg ? qend - qbeg : 0u;
+    }
+    if (i < nsamples) order[ORDER_HEADER + ORDER_PARTS * (i / per * per) + i % per] = i * stride + stride / 2u;
 }
 template <int KCAP, int NZ>
 static int launch_knn_cost_form(Index& ix, u32 nsamples, u32 k, float eps, float thr, const u32* d_order, u32* d_events)

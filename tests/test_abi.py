@@ -73,9 +73,10 @@ def test_shard_cuts_by_cost_are_balanced_and_exhaustive(lib, pkg):
     ev[: ns // 4, 0] *= 3  # the first quarter of the curve is three times as expensive
     ev[:, 2] = rng.integers(40, 90, ns)
     ev[:, 3] = (rng.integers(10, 40, ns) << 16) | rng.integers(50, 120, ns)
+    ev[:, 1] |= rng.integers(0, 5, ns).astype(np.uint32) << 24  # (diagnostic high bits: not part of the cost)
     cuts = pkg.shard_cuts_by_cost(n, world, stride, ev)
     assert cuts[0] == 0 and cuts[-1] == n and all(c % 64 == 0 for c in cuts[:-1]) and cuts == sorted(cuts)
-    cost = 6000 + 112 * ev[:, 0].astype(np.int64) + 108 * ev[:, 1] + 38 * ev[:, 2] + 11 * (ev[:, 3] & 0xFFFF) + 140 * (ev[:, 3] >> 16)
+    cost = 6000 + 112 * ev[:, 0].astype(np.int64) + 108 * (ev[:, 1] & 0xFFFFFF) + 38 * (ev[:, 2] & 0xFFFFF) + 11 * (ev[:, 3] & 0xFFFF) + 140 * (ev[:, 3] >> 16)
     per_group = np.repeat(cost, stride)
     per_group = np.concatenate([per_group, np.full(groups - len(per_group), cost[-1])])
     shard_cost = [per_group[cuts[r] // 64:(cuts[r + 1] + 63) // 64].sum() for r in range(world)]

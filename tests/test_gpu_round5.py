@@ -108,7 +108,7 @@ def test_gather_form_and_recorded_order_change_nothing(pkg, kind, n, k):
         ix.normals_knn_self_dev(k, 1e-5, n2.data_ptr(), i2.data_ptr(), c2.data_ptr(), first=first, count=count)
         ix.synchronize()
         assert torch.equal(i2, pidx) and torch.equal(c2, pcnt) and torch.equal(n2, pnrm), trip
-        assert int((c2 >= 0).sum()) == count
+        assert count <= int((c2 >= 0).sum()) < count + 64  # (a slice is answered to the end of its last group)
     # a rebuild forgets the recorded order (the groups are other groups)
     ix.rebuild_dev(d_pts.data_ptr(), n // 2)
     m = n // 2
