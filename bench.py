@@ -275,6 +275,22 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         torch.cuda.synchronize()
         range_pos_ms = (time.perf_counter() - t0) * 1e3 / 3
 
+    # ... and the LISTS of the same ranges (the reference's range_search returns the points, linked_octree_node.hpp:581-614): counts ->
+    # 64-bit scan -> fill, device resident (pcpx_range_lists_self_dev); ~42 indices per list at r = 0.01
+    range_lists_ms = range_lists_total = None
+    if side and name == "uniform_10m_k15" and world == 1:
+        d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        total = ix.range_lists_self_dev(0.01, d_off.data_ptr())
+        d_lists = torch.empty(total, dtype=torch.int32, device=dev)
+        ix.range_lists_self_dev(0.01, d_off.data_ptr(), d_lists.data_ptr(), total)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ix.range_lists_self_dev(0.01, d_off.data_ptr(), d_lists.data_ptr(), total)
+        torch.cuda.synchronize()
+        range_lists_ms, range_lists_total = (time.perf_counter() - t0) * 1e3 / 3, total
+        del d_lists, d_off
+
     # the step with rows and normals written at curve positions (pcpx_knn_self_curve_order_dev) instead of input indices
     rows_pos_ms = None
     if side and not streaming and world == 1:
@@ -286,7 +302,7 @@ def run_workload(pkg, torch, dist, name, rank, world, steps, warmup, want_profil
         torch.cuda.synchronize()
         rows_pos_ms = (time.perf_counter() - t0) * 1e3 / 5
 
-    res = {"n": n, "k": k, "elapsed": elapsed, "range_ms": range_ms, "range_pos_ms": range_pos_ms, "rows_pos_ms": rows_pos_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
+    res = {"n": n, "k": k, "elapsed": elapsed, "range_lists_ms": range_lists_ms, "range_lists_total": range_lists_total, "range_ms": range_ms, "range_pos_ms": range_pos_ms, "rows_pos_ms": rows_pos_ms, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
            "mqps": n * steps / elapsed / 1e6, "first_build_ms": first_build_ms, "rebuild_ms": rebuild_ms,
            "profile": prof, "shard": (first, count), "pts": pts, "complete": complete,
            "min_count": int(d_cnt.min().item()) if world == 1 else None, "grid": grid,
@@ -610,6 +626,11 @@ def main():
         extra["config3_range_count_r0.01_mqps"] = round(n / main_res["range_ms"] / 1e3, 1)
     if main_res.get("range_pos_ms"):
         extra["config3_range_count_r0.01_curve_order_ms"] = round(main_res["range_pos_ms"], 3)
+    if main_res.get("range_lists_ms"):
+        extra["config3_range_lists_r0.01"] = {"ms": round(main_res["range_lists_ms"], 3), "indices": main_res["range_lists_total"],
+                                              "what": "pcpx_range_lists_self_dev: counts + 64-bit scan + fill of every point's list, device resident",
+                                              "Mlists_per_s": round(n / main_res["range_lists_ms"] / 1e3, 1),
+                                              "output_GBps": round(4 * main_res["range_lists_total"] / main_res["range_lists_ms"] / 1e6, 1)}
     if main_res.get("rows_pos_ms"):
         extra["step_rows_at_curve_positions_ms"] = round(main_res["rows_pos_ms"], 4)
         extra["step_rows_at_curve_positions_mqps"] = round(n / main_res["rows_pos_ms"] / 1e3, 1)

@@ -189,6 +189,14 @@ int pcpx_range_count_self_dev(pcpx_index* idx, float radius, uint64_t sorted_fir
  * (examples/filter_point_cloud_noise_by_density.cpp:81-90 thresholds them) does not care about their order. */
 int pcpx_range_count_self_curve_order_dev(pcpx_index* idx, float radius, uint64_t sorted_first, uint64_t sorted_count,
                                           uint32_t* d_out_count);
+/* range_search around EVERY indexed point, lists, device resident (additive; the reference returns one std::vector per call,
+ * include/pcp/octree/linked_octree.hpp:264-276): d_out_offsets has n + 1 entries (n = input points; list of input point i =
+ * d_out_idx[offsets[i] .. offsets[i + 1]), a point outside the voxel grid has none), each list in tree order.  Counts, a 64-bit
+ * exclusive scan and the fill run on the handle's stream; the call waits once, for the total, which it returns in *out_total.
+ * PCPX_ERR_CAPACITY (offsets filled, *out_total set) if idx_capacity indices do not hold them or d_out_idx is NULL: allocate and
+ * call again.  Enqueues the fill and returns. */
+int pcpx_range_lists_self_dev(pcpx_index* idx, float radius, uint64_t* d_out_offsets, uint32_t* d_out_idx, uint64_t idx_capacity,
+                              uint64_t* out_total);
 /* Lists, CSR: out_offsets has nq+1 entries; out_idx receives offsets[nq] indices.  If idx_capacity is
  * too small (or out_idx is NULL) the offsets are still filled and PCPX_ERR_CAPACITY is returned, so
  * the caller can allocate offsets[nq] entries and call again. */

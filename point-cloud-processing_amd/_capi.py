@@ -84,6 +84,7 @@ SIGNATURES = {
     "pcpx_range_count_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
     "pcpx_range_count_self_dev": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pcpx_range_count_self_curve_order_dev": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pcpx_range_lists_self_dev": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "pcpx_range_sphere_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p,
                                           C.c_void_p, C.c_uint64]),
     "pcpx_range_aabb_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),

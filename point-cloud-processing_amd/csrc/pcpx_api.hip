@@ -1078,6 +1078,45 @@ int pcpx_range_count_self_curve_order_dev(pcpx_index* h, float radius, uint64_t 
     return launch_range_count(*ix, qv, true, gf, gc, radius, nullptr, d_out_count);
 }
 
+int pcpx_range_lists_self_dev(pcpx_index* h, float radius, uint64_t* d_out_offsets, uint32_t* d_out_idx, uint64_t idx_capacity,
+                              uint64_t* out_total)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    DeviceScope dscope;
+    int st = dscope.use(ix);
+    if (st != PCPX_OK) return st;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    PCPX_WHOLE_CLOUD_ONLY(ix, "pcpx_range_lists_self_dev");
+    if (!d_out_offsets || !out_total) return PCPX_ERR_INVALID;
+    *out_total = 0;
+    const u64 rows = ix->n_in;
+    if (rows == 0) {
+        PCPX_HIP(hipMemsetAsync(d_out_offsets, 0, sizeof(u64), ix->stream));
+        PCPX_HIP(hipStreamSynchronize(ix->stream));
+        return PCPX_OK;
+    }
+    // scratch of the handle: the counts by input row and the scan's tile sums
+    const size_t cnt_bytes = (rows * sizeof(u32) + 255) / 256 * 256, sums = (rows / 1024 + 2) * sizeof(u64);
+    if ((st = ensure_scratch(*ix, cnt_bytes + sums)) != PCPX_OK) return st;
+    u32* d_cnt = static_cast<u32*>(ix->d_scratch);
+    u64* d_sums = reinterpret_cast<u64*>(static_cast<char*>(ix->d_scratch) + cnt_bytes);
+    if (ix->n != ix->n_in) PCPX_HIP(hipMemsetAsync(d_cnt, 0, rows * sizeof(u32), ix->stream));  // (points outside the grid: empty lists)
+    const u64 groups = (ix->n + GROUP - 1) / GROUP;
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix->n)};
+    if ((st = launch_range_count(*ix, qv, true, 0, groups, radius, nullptr, d_cnt)) != PCPX_OK) return st;
+    if ((st = launch_range_offsets(*ix, d_cnt, rows, d_sums, d_out_offsets)) != PCPX_OK) return st;
+    u64 total = 0;
+    PCPX_HIP(hipMemcpyAsync(&total, d_out_offsets + rows, sizeof(u64), hipMemcpyDeviceToHost, ix->stream));
+    PCPX_HIP(hipStreamSynchronize(ix->stream));
+    *out_total = total;
+    if (total == 0) return PCPX_OK;
+    if (!d_out_idx || idx_capacity < total) {
+        set_error("pcpx_range_lists_self_dev: need room for %llu indices", static_cast<unsigned long long>(total));
+        return PCPX_ERR_CAPACITY;
+    }
+    return launch_range_fill_self(*ix, 0, groups, radius, d_out_offsets, d_out_idx);
+}
+
 int pcpx_range_count_self(pcpx_index* h, float radius, uint32_t* out_count)
 {
     Index* ix = reinterpret_cast<Index*>(h);

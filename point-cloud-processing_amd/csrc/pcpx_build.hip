@@ -19,11 +19,16 @@ namespace {
 #ifndef PCPX_BUILD_ADAPTIVE_MARGIN
 #define PCPX_BUILD_ADAPTIVE_MARGIN 6  // PCPX_BUILD_COARSE_ORDER: bits of curve resolution kept beyond log2 of a top-digit bucket's size
 #endif
+#ifndef PCPX_BUILD_FINISH
+#define PCPX_BUILD_FINISH 1  // 1: the sort stops after two bucketed passes where that leaves short runs and k_finish orders them in LDS (round 5); 0: every pass
+#endif
 #ifndef PCPX_BUILD_RECORDS
 #define PCPX_BUILD_RECORDS 1  // 1: the sort's first pass moves a {x, y, z, id} record per point into its top-digit bucket and the leaf
                               // fill gathers from there; 0: the leaf fill gathers the coordinates from the input-order copy
 #endif
-constexpr size_t SCALARS = 16;  // u32 words of Index::d_scalars: [0, 6) encoded box, [6] points outside the grid, [7] sort failure, [8, 14) box
+constexpr size_t SCALARS = 32;  // u32 words of Index::d_scalars: [0, 6) encoded box, [6] points outside the grid, [7] sort failure, [8, 14) box,
+                                //   [16, 24) buckets whose runs the finish kernel could not order (REDO_WORD0), [24, 32) the buckets to sort fully (FORCE_WORD0)
+constexpr u32 REDO_WORD0 = 16, FORCE_WORD0 = 24;
 
 // order-preserving float <-> uint encoding for atomic min/max
 __device__ __forceinline__ u32 enc_f(float f)
@@ -135,6 +140,7 @@ __global__ void k_build_begin(u32* __restrict__ scalars)
     if (t < 3) scalars[t] = enc_f(std::numeric_limits<float>::max());
     else if (t < 6) scalars[t] = enc_f(std::numeric_limits<float>::lowest());
     else if (t < 8) scalars[t] = 0u;  // [6] points outside the grid, [7] the sort's failure flag
+    else if (t >= REDO_WORD0 && t < REDO_WORD0 + 8u) scalars[t] = 0u;
 }
 
 // Sort word (pcpx_curve.h) of every point: curve key of a point inside the grid, the all-ones key for a point outside it
@@ -288,25 +294,158 @@ constexpr int FILL_BLOCK = 256;
 constexpr int FILL_PER_THREAD = PCPX_FILL_PER_THREAD;
 constexpr int FILL_SLOTS = FILL_BLOCK * FILL_PER_THREAD;  // 1024
 constexpr int FILL_LEAVES = FILL_SLOTS / LEAF;            // 128
-__global__ __launch_bounds__(FILL_BLOCK) void k_fill_leaves(const float4* __restrict__ rec, const float* __restrict__ xyz,
-                                                            const u64* __restrict__ sorted_codes, int idx_bits, u32 n, TreeShape ts,
-                                                            u32 nblocks, Leaf* __restrict__ leaves, u32* __restrict__ perm,
-                                                            NodeBox* __restrict__ nodes)
+
+// The tree's shape from the number of inserted points, on the device: the kernels below read that number where the build left it
+// (Index::d_scalars: input points minus the points outside the grid), so the host need not wait for it between the sort and them.
+struct BuildCount {
+    const u32* scalars;  // Index::d_scalars, or nullptr: `known` is the number (a rank-local build: the host has it)
+    u32 n_in, known;
+    __device__ u32 valid() const { return scalars ? n_in - scalars[6] : known; }
+};
+__host__ __device__ inline int depth_of(u32 nleaves)
+{
+    int d = 0;
+    while ((1ull << (2 * d)) < nleaves) ++d;
+    return d;
+}
+__host__ __device__ inline TreeShape shape_of(u32 nvalid)
+{
+    const u32 nleaves = (nvalid + LEAF - 1) / LEAF;
+    return TreeShape{nleaves, depth_of(nleaves)};
+}
+// blocks of k_finish a tree of this shape needs: its leaf slots, and the (padding) nodes of the three levels above that a block owns
+__host__ __device__ inline u32 finish_blocks(const TreeShape& ts)
+{
+    if (ts.nleaves == 0) return 0;
+    const u32 nslots = ts.nwrite(ts.depth) * LEAF;
+    u32 fblocks = (nslots + FILL_SLOTS - 1) / FILL_SLOTS;
+    for (int j = 1; j <= 3 && j <= ts.depth; ++j) {  // a block owns 128 >> 2j nodes of level depth - j
+        const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
+        const u32 need = (ts.nwrite(ts.depth - j) + per_block - 1) / per_block;
+        if (need > fblocks) fblocks = need;
+    }
+    return fblocks;
+}
+
+// k_finish = the leaf fill, and in front of it the LAST STEP OF THE SORT (round 5).  The radix sort now stops early where it can
+// (SortPayload::finish): a bucket whose words are few per 24-bit cell is sorted on bits [40, 64) only, which leaves RUNS of words
+// that agree on those bits -- a handful each -- in arbitrary... no: in input order.  A block takes the FILL_SLOTS words of its tile
+// and FIN_MARGIN on either side into LDS, finds the runs (neighbours that agree above their bucket's shift), and every word counts
+// the words of its run that are smaller: that is its place.  Two global radix passes (16 B/point each) and their look-back chains
+// become ~50 LDS reads per word.  A run longer than FIN_MARGIN -- a cell far denser than its bucket's fullest 16-bit cell
+// suggested -- cannot be ordered here: the block notes the bucket in `redo` and the host repeats the sort with that bucket taking
+// every pass (the handle remembers it).  Buckets that took every pass have nothing to order: their runs are ties on all sorted
+// bits, which the stable passes left in input order.  The fully sorted words go to `sorted_out` (prepare_queries searches them).
+constexpr int FIN_MARGIN = 64;
+constexpr int FIN_WINDOW = FILL_SLOTS + 2 * FIN_MARGIN;  // words of the window; + one word on either side to see whether its ends start runs
+struct FinishArgs {
+    const u64* words;              // prefix-sorted words, or nullptr: `sorted_out` holds fully sorted words already (nothing to order)
+    u64* sorted_out;
+    const u32* bucket_first_pass;  // per top digit: the first bucketed pass the bucket took (1: all of them)
+    int first_bit;                 // lowest sorted bit of a bucket that took every pass
+    u32* redo;                     // bitmap, 8 words
+};
+
+__global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict__ rec, const float* __restrict__ xyz, FinishArgs fa, int idx_bits,
+                                                       BuildCount bc, Leaf* __restrict__ leaves, u32* __restrict__ perm, NodeBox* __restrict__ nodes)
 {
     __shared__ __attribute__((aligned(16))) NodeBox lvl0[FILL_LEAVES];      // leaf boxes of the block
     __shared__ __attribute__((aligned(16))) NodeBox lvl1[FILL_LEAVES / 4];
     __shared__ __attribute__((aligned(16))) NodeBox lvl2[FILL_LEAVES / 16];
     __shared__ __attribute__((aligned(16))) u32 rec_stage[FILL_BLOCK / 64][FILL_PER_THREAD][64 * 4];  // per wave and trip: 8 leaf records
+    __shared__ u64 cov[FIN_WINDOW + 2];            // cov[1 + s] = word at position lo - FIN_MARGIN + s
+    __shared__ unsigned char starts[FIN_WINDOW + 2];  // starts[j]: a run starts at cov[j] (or cov[j] is no word at all)
+    __shared__ unsigned char shift_of[256];        // per bucket: the words are ordered on bits [shift_of, 64)
+    const u32 n = bc.valid();
+    const TreeShape ts = shape_of(n);
+    const u32 nblocks = finish_blocks(ts);
     const u32 per = gridDim.x >> 3;  // the grid is a multiple of 8
     const u32 vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if (vb >= nblocks) return;  // (the grid is rounded up to a multiple of 8; a block may exist only for the padding nodes it owns)
+    if (vb >= nblocks) return;  // (the grid is sized for the input's point count; a block may exist only for the padding nodes it owns)
     const u32 p0 = vb * FILL_SLOTS + threadIdx.x;
     const u64 low = (1ull << idx_bits) - 1ull;
     u64 at[FILL_PER_THREAD];
+    if (fa.words) {
+        constexpr u64 NO_WORD = ~0ull;
+        shift_of[threadIdx.x] = static_cast<unsigned char>(fa.first_bit + 8 * (static_cast<int>(fa.bucket_first_pass[threadIdx.x]) - 1));
+        const long long base = static_cast<long long>(vb) * FILL_SLOTS - FIN_MARGIN - 1;  // position of cov[0]
+        for (u32 j = threadIdx.x; j < FIN_WINDOW + 2; j += FILL_BLOCK) {
+            const long long g = base + j;
+            cov[j] = (g >= 0 && g < static_cast<long long>(n)) ? fa.words[g] : NO_WORD;
+        }
+        __syncthreads();
+        for (u32 j = threadIdx.x; j < FIN_WINDOW + 2; j += FILL_BLOCK) {
+            const long long g = base + j;
+            const bool word_here = g >= 0 && g < static_cast<long long>(n);
+            bool st = true;  // (no word, or the first word of the order: a run cannot reach across)
+            if (word_here && j > 0 && g > 0) {
+                const u64 w = cov[j], before = cov[j - 1];
+                const int sh = shift_of[static_cast<u32>(w >> 56)];
+                st = (w >> sh) != (before >> sh);
+            }
+            starts[j] = st ? 1 : 0;
+        }
+        __syncthreads();
+        // every word of the window: where its run starts and ends (if both are in sight), and how many of the run are smaller
+        constexpr int PER = (FIN_WINDOW + FILL_BLOCK - 1) / FILL_BLOCK;
+        u64 mine[PER];
+        u32 dest[PER];
+        u32 redo_bucket = ~0u;
 #pragma unroll
-    for (int u = 0; u < FILL_PER_THREAD; ++u) {
-        const u32 p = p0 + u * FILL_BLOCK;
-        at[u] = sorted_codes[p < n ? p : (n ? n - 1u : 0u)] & low;
+        for (int u = 0; u < PER; ++u) {
+            const u32 j = 1u + threadIdx.x + u * FILL_BLOCK;  // cov[1 ... FIN_WINDOW] are the window
+            dest[u] = j;
+            mine[u] = NO_WORD;
+            if (j > FIN_WINDOW) continue;
+            const u64 w = cov[j];
+            mine[u] = w;
+            const long long g = base + j;
+            if (!(g >= 0 && g < static_cast<long long>(n))) continue;
+            const u32 bucket = static_cast<u32>(w >> 56);
+            if (shift_of[bucket] <= fa.first_bit) continue;  // took every pass: in order already
+            const bool in_tile = j > FIN_MARGIN && j <= FIN_MARGIN + FILL_SLOTS;
+            u32 a = j, smaller = 0, steps = 0;
+            bool whole = true;
+            while (!starts[a]) {  // (starts[0] is set whenever cov[0] is no word; otherwise reaching 0 means the run began out of sight)
+                if (a == 0u || ++steps > FIN_MARGIN) {
+                    whole = false;
+                    break;
+                }
+                --a;
+                smaller += cov[a] < w ? 1u : 0u;
+            }
+            if (whole && a == 0u) whole = false;  // (cov[0] itself: a word of the neighbour's, its run's start unknown)
+            u32 b = j + 1u;
+            while (whole && b <= FIN_WINDOW + 1u && !starts[b]) {
+                if (b == FIN_WINDOW + 1u || ++steps > FIN_MARGIN) {
+                    whole = false;
+                    break;
+                }
+                smaller += cov[b] < w ? 1u : 0u;
+                ++b;
+            }
+            if (whole) dest[u] = a + smaller;
+            else if (in_tile) redo_bucket = bucket;
+        }
+        if (redo_bucket != ~0u) atomicOr(&fa.redo[redo_bucket >> 5], 1u << (redo_bucket & 31u));
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (1u + threadIdx.x + u * FILL_BLOCK <= FIN_WINDOW) cov[dest[u]] = mine[u];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < FILL_PER_THREAD; ++u) {
+            const u32 p = p0 + u * FILL_BLOCK;
+            const u64 w = cov[1 + FIN_MARGIN + threadIdx.x + u * FILL_BLOCK];
+            if (p < n) fa.sorted_out[p] = w;
+            at[u] = p < n ? (w & low) : 0ull;  // (a padding slot gathers record 0 and writes nothing)
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < FILL_PER_THREAD; ++u) {
+            const u32 p = p0 + u * FILL_BLOCK;
+            at[u] = p < n ? (fa.sorted_out[p] & low) : 0ull;
+        }
     }
     float x[FILL_PER_THREAD], y[FILL_PER_THREAD], z[FILL_PER_THREAD];
     u32 id[FILL_PER_THREAD];
@@ -392,9 +531,26 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_fill_leaves(const float4* __rest
 // the 256 + 64 + 16 + 4 + 1 nodes above them (as many of those levels as exist: `levels`), the lower ones through LDS.
 // (round 2: one launch per level, then a single workgroup walking the top six levels: 76 us at 10 M points)
 constexpr int UPPER_BLOCK = 256;
-__global__ __launch_bounds__(UPPER_BLOCK) void k_upper_levels(NodeBox* __restrict__ nodes, TreeShape ts, int c, int levels)
+// blocks a launch over the levels below level c needs
+__host__ __device__ inline u32 upper_blocks(const TreeShape& ts, int c, int levels)
+{
+    u32 ublocks = 1;
+    for (int j = 1; j <= levels; ++j) {
+        const u32 per_block = static_cast<u32>(UPPER_BLOCK) >> (2 * (j - 1));
+        const u32 need = (ts.nwrite(c - j) + per_block - 1) / per_block;
+        if (need > ublocks) ublocks = need;
+    }
+    return ublocks;
+}
+// `stage` 0: the five levels above the three k_finish made, 1: the next five, ... (the shape is read on the device: BuildCount)
+__global__ __launch_bounds__(UPPER_BLOCK) void k_upper_levels(NodeBox* __restrict__ nodes, BuildCount bc, int stage)
 {
     __shared__ NodeBox buf[2][UPPER_BLOCK];
+    const TreeShape ts = shape_of(bc.valid());
+    const int c = ts.depth - 3 - 5 * stage;
+    if (c <= 0 || ts.nleaves == 0) return;
+    const int levels = c < 5 ? c : 5;
+    if (blockIdx.x >= upper_blocks(ts, c, levels)) return;
     const NodeBox* child = nodes + TreeShape::level_start(c) + static_cast<u64>(blockIdx.x) * (UPPER_BLOCK * 4);
     u32 width = UPPER_BLOCK;  // nodes of this block at the level being computed
     for (int j = 1; j <= levels; ++j, width >>= 2) {
@@ -611,50 +767,45 @@ int build_box_and_codes(Index& ix, const float* d_xyz_src, u64 n, const pcpx_bui
 // The implicit tree over the sorted words d_codes[1][0 .. nvalid) (their low idx_bits name the points' records in d_rec):
 // leaf records, leaf boxes and the three levels above them in one pass, then up to five levels per launch: real nodes only
 // (+ the padding siblings of the last group of four of a level, the only padding a query can read).
-int build_tree_from_sorted(Index& ix, u32 nvalid)
+// `n_at_most` points at most (the grids are sized for it); how many there are is read on the device (count_on_device: input points
+// minus the points outside the grid, Index::d_scalars[6]) or is n_at_most itself.  The words are those of the last sort of this
+// handle (Index::finish_words: prefix-sorted, ordered here; or nullptr: d_codes[1] is sorted).  build_tree_set_shape gives the
+// handle its tree once the host knows the count.
+int build_tree_from_sorted(Index& ix, u32 n_at_most, bool count_on_device)
 {
     hipStream_t s = ix.stream;
-    ix.n = nvalid;
     ix.sched.state = 0;        // (what an earlier tree's launches recorded says nothing about this one's groups)
     ix.pos_of_valid = false;
-    u32 nleaves = (nvalid + LEAF - 1) / LEAF;
-    ix.nleaves = nleaves;
-    int depth = depth_for(nleaves);
-    if (depth > MAXDEPTH) {
+    const TreeShape ts = shape_of(n_at_most);
+    if (ts.depth > MAXDEPTH) {
         set_error("pcpx: tree deeper than %d levels", MAXDEPTH);
         return PCPX_ERR_UNSUPPORTED;
     }
-    ix.depth = depth;
-    ix.leaf0 = static_cast<u32>(level_start(depth));
-    if (level_start(depth + 1) > ix.nodes_cap) {
+    if (level_start(ts.depth + 1) > ix.nodes_cap) {
         set_error("pcpx: internal error, node capacity");
         return PCPX_ERR_INVALID;
     }
-    if (nleaves == 0) return PCPX_OK;
-    const TreeShape ts{nleaves, depth};
-    const u32 nslots = ts.nwrite(depth) * LEAF;
-    u32 fblocks = (nslots + FILL_SLOTS - 1) / FILL_SLOTS;
-    for (int j = 1; j <= 3 && j <= depth; ++j) {  // a block owns 128 >> 2j nodes of level depth - j
-        const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
-        const u32 need = (ts.nwrite(depth - j) + per_block - 1) / per_block;
-        if (need > fblocks) fblocks = need;
-    }
-    const u32 fgrid = (fblocks + 7u) & ~7u;
+    if (ts.nleaves == 0) return PCPX_OK;
+    const BuildCount bc{count_on_device ? ix.d_scalars : nullptr, static_cast<u32>(ix.n_in), n_at_most};
+    const u32 fgrid = (finish_blocks(ts) + 7u) & ~7u;
     const bool from_rec = PCPX_BUILD_RECORDS || ix.shard.on;
-    k_fill_leaves<<<fgrid, FILL_BLOCK, 0, s>>>(from_rec ? reinterpret_cast<const float4*>(ix.d_rec) : nullptr, ix.d_xyz, ix.d_codes[1], ix.idx_bits,
-                                                nvalid, ts, fblocks, ix.d_leaves, ix.d_perm, ix.d_nodes);
-    for (int c = depth - 3; c > 0;) {
+    const FinishArgs fa{ix.finish_words, ix.d_codes[1], ix.finish_first_pass, SORT_FIRST_BIT, ix.d_scalars + REDO_WORD0};
+    k_finish<<<fgrid, FILL_BLOCK, 0, s>>>(from_rec ? reinterpret_cast<const float4*>(ix.d_rec) : nullptr, ix.d_xyz, fa, ix.idx_bits, bc, ix.d_leaves,
+                                          ix.d_perm, ix.d_nodes);
+    int stage = 0;
+    for (int c = ts.depth - 3; c > 0; c -= 5, ++stage) {
         const int levels = c < 5 ? c : 5;
-        u32 ublocks = 1;
-        for (int j = 1; j <= levels; ++j) {
-            const u32 per_block = static_cast<u32>(UPPER_BLOCK) >> (2 * (j - 1));
-            const u32 need = (ts.nwrite(c - j) + per_block - 1) / per_block;
-            if (need > ublocks) ublocks = need;
-        }
-        k_upper_levels<<<ublocks, UPPER_BLOCK, 0, s>>>(ix.d_nodes, ts, c, levels);
-        c -= levels;
+        k_upper_levels<<<upper_blocks(ts, c, levels), UPPER_BLOCK, 0, s>>>(ix.d_nodes, bc, stage);
     }
     return check_hip(hipGetLastError(), "tree kernels", __FILE__, __LINE__);
+}
+void build_tree_set_shape(Index& ix, u32 nvalid)
+{
+    const TreeShape ts = shape_of(nvalid);
+    ix.n = nvalid;
+    ix.nleaves = ts.nleaves;
+    ix.depth = ts.depth;
+    ix.leaf0 = static_cast<u32>(level_start(ts.depth));
 }
 
 // d_xyz_src: device pointer to n x 3 floats (copied into the index: the reference containers copy
@@ -683,28 +834,21 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
     ix.n_in = n;
     const bool copy_cloud = n > 0 && d_xyz_src != ix.d_xyz;  // (the copy rides on k_codes' sweep over the coordinates)
     if ((st = build_box_and_codes(ix, d_xyz_src, n, params, copy_cloud, sort_tile_hist_buffer(ix.d_sort_tmp, n), nullptr)) != PCPX_OK) return st;
-    u32 nvalid = 0;
-    if (n > 0) {
-        size_t tb = ix.sort_tmp_bytes;
-        SortPayload pl;
-        pl.xyz = PCPX_BUILD_RECORDS ? d_xyz_src : nullptr;
-        pl.rec = ix.d_rec;
-        pl.idx_bits = ix.idx_bits;
-        pl.tile_hist_ready = sort_tile_hist_buffer(ix.d_sort_tmp, n);
-        pl.failed_flag = ix.d_scalars + 7;
-        const bool coarse = params && (params->flags & PCPX_BUILD_COARSE_ORDER);
-        pl.adaptive_margin_bits = coarse ? PCPX_BUILD_ADAPTIVE_MARGIN : 0;
-        ix.sorted_from_bit = coarse ? 40 : SORT_FIRST_BIT;
-        st = sort_keys_u64(ix.d_sort_tmp, tb, ix.d_codes[0], ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
-        if (st != PCPX_OK) return st;
-    }
-    float hb[8];
-    PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, 8 * sizeof(u32), hipMemcpyDeviceToHost, s));
-    PCPX_HIP(hipStreamSynchronize(s));
-    {
-        u32 outside = 0, sort_failed = 0;
-        std::memcpy(&outside, &hb[0], sizeof(u32));
-        std::memcpy(&sort_failed, &hb[1], sizeof(u32));
+    // Sort, leaves, boxes: everything is enqueued before the host looks at anything -- how many points are inside the grid is read on
+    // the device (BuildCount) -- and ONE read-back ends the build: points outside, the sort's failure flag, the box, and the buckets
+    // whose runs the finish kernel could not order.  Those (a cell far denser than its surroundings) take every radix pass from now on:
+    // the build is repeated once with them forced, and the handle remembers them for its later rebuilds.
+    const bool coarse = params && (params->flags & PCPX_BUILD_COARSE_ORDER);
+    (void)coarse;  // (round 5: every build sorts only as finely as its buckets ask for, and exactly; the flag is accepted and changes nothing)
+    for (int attempt = 0;; ++attempt) {
+        if (n > 0) {
+            if ((st = sort_for_build(ix, ix.d_codes[0], n, PCPX_BUILD_RECORDS ? d_xyz_src : nullptr, nullptr, sort_tile_hist_buffer(ix.d_sort_tmp, n))) != PCPX_OK) return st;
+            if ((st = build_tree_from_sorted(ix, static_cast<u32>(n), true)) != PCPX_OK) return st;
+        }
+        u32 hb[SCALARS - 6];
+        PCPX_HIP(hipMemcpyAsync(hb, ix.d_scalars + 6, sizeof(hb), hipMemcpyDeviceToHost, s));
+        PCPX_HIP(hipStreamSynchronize(s));
+        const u32 outside = hb[0], sort_failed = hb[1];
         std::memcpy(ix.bbox, &hb[2], 6 * sizeof(float));
         if (n > 0 && sort_failed) {
             ix.n = ix.n_in = 0;
@@ -712,9 +856,48 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
             set_error("pcpx: internal error, the radix sort's look-back gave up");
             return PCPX_ERR_DEVICE;
         }
-        nvalid = static_cast<u32>(n) - outside;
+        bool redo = false;
+        for (u32 w = 0; w < 8; ++w) {
+            const u32 r = hb[REDO_WORD0 - 6 + w];
+            redo = redo || (r & ~ix.full_buckets[w]) != 0u;
+            ix.full_buckets[w] |= r;
+        }
+        if (redo && attempt == 0 && n > 0) {
+            ++ix.build_redos;
+            // (the tile counts of the top digit were scanned in place by the sort: the keys are made again, which also clears the flags)
+            if ((st = build_box_and_codes(ix, d_xyz_src, n, params, false, sort_tile_hist_buffer(ix.d_sort_tmp, n), nullptr)) != PCPX_OK) return st;
+            continue;
+        }
+        build_tree_set_shape(ix, static_cast<u32>(n) - outside);
+        return PCPX_OK;
     }
-    return build_tree_from_sorted(ix, nvalid);
+}
+
+// The build's sort: d_words (n words: key bits | element index) -> prefix-sorted words + the records at the positions the words' low
+// bits name, in finish mode (SortPayload::finish; Index::finish_words then says where the words are for build_tree_from_sorted).
+int sort_for_build(Index& ix, const u64* d_words, u64 n, const float* d_xyz_src, const float4* d_rec_in, u32* tile_hist_ready)
+{
+    hipStream_t s = ix.stream;
+    bool any_forced = false;
+    for (u32 w = 0; w < 8; ++w) any_forced = any_forced || ix.full_buckets[w] != 0u;
+    if (any_forced) PCPX_HIP(hipMemcpyAsync(ix.d_scalars + FORCE_WORD0, ix.full_buckets, sizeof(ix.full_buckets), hipMemcpyHostToDevice, s));
+    size_t tb = ix.sort_tmp_bytes;
+    SortPayload pl;
+    SortPayload::FinishOut fo;
+    pl.xyz = d_xyz_src;
+    pl.rec_in = d_rec_in;
+    pl.rec = ix.d_rec;
+    pl.idx_bits = ix.idx_bits;
+    pl.tile_hist_ready = tile_hist_ready;
+    pl.failed_flag = ix.d_scalars + 7;
+    pl.finish = PCPX_BUILD_FINISH != 0;
+    pl.force_full = any_forced ? ix.d_scalars + FORCE_WORD0 : nullptr;
+    pl.finish_out = &fo;
+    ix.sorted_from_bit = SORT_FIRST_BIT;
+    const int st = sort_keys_u64(ix.d_sort_tmp, tb, d_words, ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
+    ix.finish_words = fo.words;
+    ix.finish_first_pass = fo.bucket_first_pass;
+    return st;
 }
 
 }  // namespace pcpx

@@ -198,6 +198,10 @@ struct Index {
     float4* d_rec = nullptr;               // {x, y, z, input index} per point, grouped by the sort word's top digit (the leaf fill's source)
     int idx_bits = 1;                      // low bits of a sort word that hold the input index
     int sorted_from_bit = 24;              // the sorted words are ordered on their bits [sorted_from_bit, 64) everywhere
+    const u64* finish_words = nullptr;     // the last sort's prefix-sorted words (in d_sort_tmp) for build_tree_from_sorted, or nullptr: d_codes[1] is sorted
+    const u32* finish_first_pass = nullptr;  // ... and its per-bucket table
+    u32 full_buckets[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // top-digit buckets that take every radix pass (a build found a run it could not order in LDS)
+    u32 build_redos = 0;                   // builds that were repeated because of that (diagnostic)
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     Leaf* d_leaves = nullptr;
@@ -331,7 +335,10 @@ int build_grow_cloud_arrays(Index& ix, u64 n, bool want_copy);           // d_xy
 int build_grow_tree_arrays(Index& ix, u64 m);                            // d_codes[1], d_perm, d_rec, d_leaves, d_nodes, d_sort_tmp for m points
 int build_box_and_codes(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params, bool copy_cloud, u32* d_tile_hist,
                         u32* d_hist12);
-int build_tree_from_sorted(Index& ix, u32 nvalid);                       // leaf records, boxes, levels from d_codes[1] / d_rec
+int build_tree_from_sorted(Index& ix, u32 n_at_most, bool count_on_device);  // leaf records, boxes, levels from the sorted words / d_rec
+void build_tree_set_shape(Index& ix, u32 nvalid);
+int sort_for_build(Index& ix, const u64* d_words, u64 n, const float* d_xyz_src, const float4* d_rec_in, u32* tile_hist_ready);
+constexpr u32 BUILD_REDO_WORD0 = 16;  // Index::d_scalars[16 .. 24): buckets whose runs the finish kernel could not order
 void free_shard(Index& ix);
 // shard.hip
 int build_shard_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_params* params);
@@ -358,7 +365,22 @@ struct SortPayload {
                                           //   of its lower digits only, at least two: every word is then ordered on bits [40, 64), and on as many
                                           //   bits below as separate the words of its own bucket with `margin` bits to spare.  0: the full sort.
     u32* failed_flag = nullptr;           // device word (zeroed by the caller) to set if the look-back ever gives up; default: inside tmp
+    // The index build's short cut (round 5).  finish = true: a bucket is sorted on its top TWO lower digits only (bits [40, 64) of
+    // the words) when that is likely to leave RUNS -- words that agree on those bits -- of a handful of words: at most SORT_RUN_TARGET
+    // words per 24-bit cell on average over the bucket and over its fullest 16-bit cell (k_sort_seg_plan, from the digit counts the
+    // sort has anyway); other buckets -- and those the caller names in force_full, and the last one, where the words of points outside
+    // the grid go -- take all passes as before.  The caller orders the runs itself (pcpx_build.hip: k_finish sorts them in LDS, in the
+    // kernel that writes the leaves) and reports the buckets whose runs turned out longer than it can handle, which the next attempt
+    // names in force_full.  The words come back PREFIX-sorted in the sort's temporary buffer (`finish_out`), not in kout -- the finish
+    // kernel's output is what kout's buffer is for -- with the bucket table beside them.
+    bool finish = false;
+    const u32* force_full = nullptr;      // finish: device bitmap, 8 words; bit b: bucket b takes every pass
+    struct FinishOut {
+        const u64* words = nullptr;           // n words, ordered on bits [first_bit + 8 (first_pass[b] - 1), 64) inside bucket b
+        const u32* bucket_first_pass = nullptr;  // 256 entries (device)
+    }* finish_out = nullptr;
 };
+constexpr u32 SORT_RUN_TARGET = 16;     // (a run the finish kernel can order is at most 64 words: four times the average it plans for)
 int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n, hipStream_t s, int first_bit = 0,
                   const SortPayload* payload = nullptr);
 const u32* sort_failure_flag(void* tmp);
@@ -384,6 +406,8 @@ int launch_range_count(Index& ix, const QueryView& qv, bool self, u64 group_firs
                        const float* d_radii, u32* d_out_cnt);
 int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float* d_radii, const u64* d_offsets,
                       u32* d_out_idx);
+int launch_range_offsets(Index& ix, const u32* d_cnt, u64 n_rows, u64* d_tile_sum, u64* d_offsets);
+int launch_range_fill_self(Index& ix, u64 group_first, u64 group_count, float radius, const u64* d_offsets, u32* d_out_idx);
 int launch_range_one(Index& ix, bool aabb, const float* range, u32 cap, u32* out_idx, u32* out_cnt, u32* done_flag, u32 epoch);
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt);
 int launch_aabb_fill(Index& ix, const float* d_boxes6, u64 nb, const u64* d_offsets, u32* d_out_idx);

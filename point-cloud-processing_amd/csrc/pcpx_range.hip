@@ -11,6 +11,9 @@
 
 // Wave priority by phase, as in k_knn (pcpx_query.hip): the dense leaf's 88 vector instructions run at a lower priority than the walk
 // and the packed leaves (2.238 -> 2.212 ms per 10 M counts; the dense leaf raised instead: 2.25)
+#ifndef PCPX_RANGE_PACKED_FILL
+#define PCPX_RANGE_PACKED_FILL 1  // the list form takes the packed leaf too (0: lane-per-range leaves, rounds 1-4)
+#endif
 #ifndef PCPX_RANGE_PRIO_BASE
 #define PCPX_RANGE_PRIO_BASE 1
 #endif
@@ -105,7 +108,11 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
     // leaf in the lane-per-range form.  Same arithmetic (d = p - c, three roundings; sphere.hpp:27-35).  A slot that holds no
     // centre holds r^2 = -1 (k_range sets the row so, a needing lane sets its slot back): the lanes of a step beyond the leaf's
     // needing lanes count nothing, without a lane mask per step (the scalar unit is as loaded as the vector units here).
-    constexpr bool packed_leaves = PCPX_RANGE_PACKED_LEAVES > 0 && !FILL;
+    // The list form (round 5) does the same: the needing lanes also publish where their list stands (offset + what they have so far),
+    // and a lane whose point is inside writes the point's index at that place plus the number of set bits below its own in its
+    // group's byte of the step's ballot -- the order of a list is the order of the lane-per-range form: walk order, then point
+    // order inside a leaf.
+    constexpr bool packed_leaves = PCPX_RANGE_PACKED_LEAVES > 0 && (!FILL || PCPX_RANGE_PACKED_FILL);
     static_assert(PCPX_RANGE_PACKED_LEAVES <= 32, "one row of LDS per wave");
     auto packed_leaf = [&](const Leaf* record, const u64 who, const u32 how_many) {
         u32 lane_here = lane;
@@ -113,15 +120,26 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
         const u32 j = lane_here & 7u, i = lane_here >> 3;
         const float* rec = reinterpret_cast<const float*>(record);
         const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        u32 idj = 0;
+        if (FILL) idj = reinterpret_cast<const u32*>(record)[3 * LEAF + j];
+        u64* const pub_at = reinterpret_cast<u64*>(pub + 32);  // (list form: the row's second part)
         const u32 rank = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(who >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(who), 0u));
         const bool mine = __builtin_amdgcn_inverse_ballot_w64(who);
-        if (mine) pub[rank] = make_float4(qx, qy, qz, r2);
+        if (mine) {
+            pub[rank] = make_float4(qx, qy, qz, r2);
+            if (FILL) pub_at[rank] = wpos + cnt;
+        }
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
         const u32 my_byte = (rank & 7u) << 3;
         for (u32 s = 0; s < how_many; s += 8u) {
             const float4 q = pub[s + i];
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
-            const u64 inside = __builtin_amdgcn_ballot_w64(sq3(dx, dy, dz) <= q.w);  // (a NaN padding point fails; so does every point against an empty slot)
+            const bool in_here = sq3(dx, dy, dz) <= q.w;  // (a NaN padding point fails; so does every point against an empty slot)
+            const u64 inside = __builtin_amdgcn_ballot_w64(in_here);
+            if (FILL && in_here) {
+                const u32 group_byte = static_cast<u32>(inside >> (lane_here & 56u)) & 0xFFu;  // the eight points against published range s + i
+                out_idx[pub_at[s + i] + static_cast<u32>(__builtin_popcount(group_byte & ((1u << j) - 1u)))] = idj;
+            }
             if (mine && rank - s < 8u) cnt += static_cast<u32>(__builtin_popcount(static_cast<u32>(inside >> my_byte) & 0xFFu));
         }
         __builtin_amdgcn_wave_barrier();
@@ -168,11 +186,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range(TreeView t, Quer
                                                                const float* __restrict__ radii, u32* __restrict__ out_cnt,
                                                                const u64* __restrict__ offsets, u32* __restrict__ out_idx)
 {
-    __shared__ float4 published[WAVES_PER_BLOCK][FILL ? 1 : 32];  // packed_leaf's row, one per wave
+    __shared__ float4 published[WAVES_PER_BLOCK][FILL ? 48 : 32];  // packed_leaf's row, one per wave (list form: + 32 list positions)
     const u32 lane = threadIdx.x & 63u;
     const u32 g = group_first + virtual_block() * WAVES_PER_BLOCK + wave_in_block();
     if (g >= group_end) return;
-    if (!FILL && lane < 32u) published[wave_in_block()][lane].w = -1.f;  // packed_leaf's invariant: a slot that holds no centre holds r^2 = -1
+    if (lane < 32u) published[wave_in_block()][lane].w = -1.f;  // packed_leaf's invariant: a slot that holds no centre holds r^2 = -1
     range_group<SELF, FILL>(t, qv, g, radius, radii, out_cnt, offsets, out_idx, published[wave_in_block()], lane);
 }
 
@@ -213,14 +231,72 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
             cnt += in ? 1u : 0u;
         }
     };
-    Walker wk;
+    // The boxes of a wave need not lie near each other, so a leaf is needed by one or two of them as a rule: such a leaf is looked
+    // at EIGHT NEEDING BOXES x EIGHT POINTS at a time, as in k_range (round 5; until then every visited leaf cost all 64 lanes its
+    // eight containment tests).  The needing lanes publish their box -- and, list form, where their list stands -- by their rank
+    // among the needing lanes; an unused slot holds an inverted box.
+    __shared__ float4 pub_lo_s[WAVES_PER_BLOCK][PCPX_RANGE_PACKED_LEAVES > 0 ? 32 : 1], pub_hi_s[WAVES_PER_BLOCK][PCPX_RANGE_PACKED_LEAVES > 0 ? 32 : 1];
+    __shared__ u64 pub_at_s[WAVES_PER_BLOCK][(PCPX_RANGE_PACKED_LEAVES > 0 && FILL) ? 32 : 1];
+    constexpr bool packed_leaves = PCPX_RANGE_PACKED_LEAVES > 0 && PCPX_RANGE_PACKED_FILL;
+    float4* const pub_lo = pub_lo_s[wave_in_block()];
+    float4* const pub_hi = pub_hi_s[wave_in_block()];
+    u64* const pub_at = pub_at_s[wave_in_block()];
+    if (packed_leaves && lane < 32u) {
+        pub_lo[lane] = make_float4(1.f, 1.f, 1.f, 0.f);
+        pub_hi[lane] = make_float4(-1.f, -1.f, -1.f, 0.f);
+    }
+    auto packed_leaf = [&](const Leaf* record, const u64 who, const u32 how_many) {
+        const u32 j = lane & 7u, i = lane >> 3;
+        const float* rec = reinterpret_cast<const float*>(record);
+        const float x = rec[j], y = rec[LEAF + j], z = rec[2 * LEAF + j];
+        u32 idj = 0;
+        if (FILL) idj = reinterpret_cast<const u32*>(record)[3 * LEAF + j];
+        const u32 rank = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(who >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(who), 0u));
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(who);
+        if (mine) {
+            pub_lo[rank] = make_float4(b0, b1, b2, 0.f);
+            pub_hi[rank] = make_float4(b3, b4, b5, 0.f);
+            if (FILL) pub_at[rank] = wpos + cnt;
+        }
+        __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
+        const u32 my_byte = (rank & 7u) << 3;
+        for (u32 s = 0; s < how_many; s += 8u) {
+            const float4 lo = pub_lo[s + i], hi = pub_hi[s + i];
+            const bool in_here = (x >= lo.x) & (y >= lo.y) & (z >= lo.z) & (x <= hi.x) & (y <= hi.y) & (z <= hi.z);  // (NaN padding fails)
+            const u64 inside = __builtin_amdgcn_ballot_w64(in_here);
+            if (FILL && in_here) {
+                const u32 group_byte = static_cast<u32>(inside >> (lane & 56u)) & 0xFFu;
+                out_idx[pub_at[s + i] + static_cast<u32>(__builtin_popcount(group_byte & ((1u << j) - 1u)))] = idj;
+            }
+            if (mine && rank - s < 8u) cnt += static_cast<u32>(__builtin_popcount(static_cast<u32>(inside >> my_byte) & 0xFFu));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mine) {
+            pub_lo[rank] = make_float4(1.f, 1.f, 1.f, 0.f);
+            pub_hi[rank] = make_float4(-1.f, -1.f, -1.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    WalkerT<true, packed_leaves> wk;
     u32 nexp = 0;
     if (wk.start(t, need, nexp)) leaf_points(0u);
-    while (!wk.done()) {  // one pop per trip: a node is expanded, a leaf looked at
+    while (!wk.done()) {  // one pop per trip: a node is expanded; a last-level node looks at its needed leaves itself
         u32 loc;
         const int h = wk.pop(loc);
-        if (h != 0) {
+        if (h > 1 || (!packed_leaves && h == 1)) {
             wk.expand(t, h, loc, need);
+        } else if (h == 1) {
+            const u32 needed = wk.leaves_of(t, loc, need);
+            const Leaf* records = t.leaves + (loc << LOGW);
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                if ((needed >> c) & 1u) {
+                    u32 how_many = GROUP;
+                    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
+                    if (how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c, wk.leaf_need[c], how_many);
+                    else leaf_points((loc << LOGW) + c);
+                }
+            }
         } else {
             wk.at_leaf(loc);
             leaf_points(loc);
@@ -360,6 +436,108 @@ int launch_range_fill(Index& ix, const QueryView& qv, float radius, const float*
     k_range<false, true><<<grid_for_groups(groups), 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, 0u, static_cast<u32>(groups), radius,
                                                                            d_radii, nullptr, d_offsets, d_out_idx);
     return check_hip(hipGetLastError(), "k_range fill launch", __FILE__, __LINE__);
+}
+
+// ---- lists of every indexed point's range, device resident: counts by input row -> offsets (exclusive scan, 64-bit) -> fill ----
+namespace {
+constexpr u32 SCAN_TILE = 1024;
+// exclusive scan of n counts into 64-bit offsets (n + 1 of them): tile sums, their scan by one block, the tiles
+__global__ __launch_bounds__(256) void k_offsets_tile_sums(const u32* __restrict__ cnt, u32 n, u64* __restrict__ tile_sum)
+{
+    __shared__ u64 w[4];
+    const u32 base = blockIdx.x * SCAN_TILE;
+    u64 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_TILE / 256; ++j) {
+        const u32 i = base + j * 256 + threadIdx.x;
+        v += i < n ? cnt[i] : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63u) == 0) w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+__global__ __launch_bounds__(1024) void k_offsets_scan_sums(u64* __restrict__ tile_sum, u32 ntiles, u64* __restrict__ total_out)
+{
+    __shared__ u64 wsum[16];
+    __shared__ u64 carry_s;
+    const u32 t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < ntiles; base += 1024) {
+        const u32 i = base + t;
+        const u64 v = i < ntiles ? tile_sum[i] : 0ull;
+        u64 incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 up = __shfl_up(incl, off);
+            if (lane >= static_cast<u32>(off)) incl += up;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        u64 before = carry_s, total = 0;
+        for (u32 j = 0; j < 16; ++j) {
+            before += j < w ? wsum[j] : 0ull;
+            total += wsum[j];
+        }
+        if (i < ntiles) tile_sum[i] = before + incl - v;
+        __syncthreads();
+        if (t == 0) carry_s += total;
+        __syncthreads();
+    }
+    if (t == 0) *total_out = carry_s;
+}
+__global__ __launch_bounds__(256) void k_offsets_tiles(const u32* __restrict__ cnt, u32 n, const u64* __restrict__ tile_base, u64* __restrict__ offsets)
+{
+    __shared__ u32 w[4];
+    const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * (SCAN_TILE / 256);
+    u32 c[SCAN_TILE / 256], s = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_TILE / 256; ++j) {
+        c[j] = base + j < n ? cnt[base + j] : 0u;
+        s += c[j];
+    }
+    const u32 lane = threadIdx.x & 63u;
+    u32 incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 up = __shfl_up(incl, off);
+        if (lane >= static_cast<u32>(off)) incl += up;
+    }
+    if (lane == 63) w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 before = 0;
+    for (u32 j = 0; j < (threadIdx.x >> 6); ++j) before += w[j];
+    u64 at = tile_base[blockIdx.x] + before + incl - s;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_TILE / 256; ++j) {
+        if (base + j < n) offsets[base + j] = at;
+        at += c[j];
+    }
+}
+}  // namespace
+
+// d_offsets: n_rows + 1 entries (rows = input indices; a point that is not indexed has an empty list); d_total: one u64 (device).
+// d_cnt: n_rows counts (scratch of the caller); d_tile_sum: ceil(n_rows / 1024) + 1 u64 (scratch).
+int launch_range_offsets(Index& ix, const u32* d_cnt, u64 n_rows, u64* d_tile_sum, u64* d_offsets)
+{
+    if (n_rows == 0) return PCPX_OK;
+    const u32 n = static_cast<u32>(n_rows), ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    k_offsets_tile_sums<<<ntiles, 256, 0, ix.stream>>>(d_cnt, n, d_tile_sum);
+    k_offsets_scan_sums<<<1, 1024, 0, ix.stream>>>(d_tile_sum, ntiles, d_offsets + n_rows);
+    k_offsets_tiles<<<ntiles, 256, 0, ix.stream>>>(d_cnt, n, d_tile_sum, d_offsets);
+    return check_hip(hipGetLastError(), "range offset kernels", __FILE__, __LINE__);
+}
+int launch_range_fill_self(Index& ix, u64 group_first, u64 group_count, float radius, const u64* d_offsets, u32* d_out_idx)
+{
+    if (group_count == 0) return PCPX_OK;
+    QueryView qv{nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<u32>(ix.n)};
+    ProfileScope prof(ix, PCPX_K_RANGE);
+    k_range<true, true><<<grid_for_groups(group_count), 64 * WAVES_PER_BLOCK, 0, ix.stream>>>(ix.view(), qv, static_cast<u32>(group_first),
+                                                                                 static_cast<u32>(group_first + group_count), radius, nullptr, nullptr,
+                                                                                 d_offsets, d_out_idx);
+    return check_hip(hipGetLastError(), "k_range self fill launch", __FILE__, __LINE__);
 }
 
 int launch_aabb_count(Index& ix, const float* d_boxes6, u64 nb, u32* d_out_cnt)

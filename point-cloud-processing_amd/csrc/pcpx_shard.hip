@@ -547,32 +547,42 @@ int shard_local_build(Index& ix)
         return st;
     }
     ix.n_in = n;  // (build_grow_tree_arrays empties the handle when it grows)
-    if (m > 0) {
-        // records travel through the leaf buffer: the sort's first pass has consumed them before the leaf fill writes it
-        float4* rec_in = reinterpret_cast<float4*>(ix.d_leaves);
-        k_shard_compact<<<cblocks, CMP_BLOCK, 0, s>>>(ix.d_codes[0], sh.cloud, static_cast<u32>(n), ix.idx_bits, sh.d_sel, ntiles, sh.d_tile_cnt,
-                                                      sh.d_words, rec_in);
-        PCPX_HIP(hipGetLastError());
-        size_t tb = ix.sort_tmp_bytes;
-        SortPayload pl;
-        pl.rec_in = rec_in;
-        pl.rec = ix.d_rec;
-        pl.idx_bits = ix.idx_bits;
-        pl.failed_flag = ix.d_scalars + 7;
-        ix.sorted_from_bit = SORT_FIRST_BIT;
-        if ((st = sort_keys_u64(ix.d_sort_tmp, tb, sh.d_words, ix.d_codes[1], m, s, SORT_FIRST_BIT, &pl)) != PCPX_OK) return st;
-    }
-    k_shard_locate<<<1, 64, 0, s>>>(ix.d_codes[1], sh.d_plan);
-    u32 sc[8];
-    PCPX_HIP(hipMemcpyAsync(sc, ix.d_scalars + 6, sizeof(sc), hipMemcpyDeviceToHost, s));
-    PCPX_HIP(hipMemcpyAsync(plan, sh.d_plan, sizeof(plan), hipMemcpyDeviceToHost, s));
-    PCPX_HIP(hipStreamSynchronize(s));
-    std::memcpy(ix.bbox, &sc[2], 6 * sizeof(float));
-    if (m > 0 && sc[1]) {
-        ix.n = 0;
-        ix.nleaves = 0;
-        set_error("pcpx: internal error, the radix sort's look-back gave up");
-        return PCPX_ERR_DEVICE;
+    for (int attempt = 0;; ++attempt) {
+        if (m > 0) {
+            // records travel through the leaf buffer: the sort's first pass has consumed them before the leaf fill writes it
+            float4* rec_in = reinterpret_cast<float4*>(ix.d_leaves);
+            k_shard_compact<<<cblocks, CMP_BLOCK, 0, s>>>(ix.d_codes[0], sh.cloud, static_cast<u32>(n), ix.idx_bits, sh.d_sel, ntiles, sh.d_tile_cnt,
+                                                          sh.d_words, rec_in);
+            PCPX_HIP(hipGetLastError());
+            if ((st = sort_for_build(ix, sh.d_words, m, nullptr, rec_in, nullptr)) != PCPX_OK) return st;
+        } else {
+            ix.finish_words = nullptr;
+        }
+        // (the words are ordered on their top 16 bits at least wherever they are: enough for the core's cells)
+        k_shard_locate<<<1, 64, 0, s>>>(ix.finish_words ? ix.finish_words : ix.d_codes[1], sh.d_plan);
+        if ((st = build_tree_from_sorted(ix, m, false)) != PCPX_OK) return st;
+        u32 sc[8], redo[8];
+        PCPX_HIP(hipMemcpyAsync(sc, ix.d_scalars + 6, sizeof(sc), hipMemcpyDeviceToHost, s));
+        PCPX_HIP(hipMemcpyAsync(redo, ix.d_scalars + BUILD_REDO_WORD0, sizeof(redo), hipMemcpyDeviceToHost, s));
+        PCPX_HIP(hipMemcpyAsync(plan, sh.d_plan, sizeof(plan), hipMemcpyDeviceToHost, s));
+        PCPX_HIP(hipStreamSynchronize(s));
+        std::memcpy(ix.bbox, &sc[2], 6 * sizeof(float));
+        if (m > 0 && sc[1]) {
+            ix.n = 0;
+            ix.nleaves = 0;
+            set_error("pcpx: internal error, the radix sort's look-back gave up");
+            return PCPX_ERR_DEVICE;
+        }
+        bool again = false;
+        for (u32 w = 0; w < 8; ++w) {
+            again = again || (redo[w] & ~ix.full_buckets[w]) != 0u;
+            ix.full_buckets[w] |= redo[w];
+        }
+        if (again && attempt == 0 && m > 0) {  // a run the finish kernel could not order: once more, with its bucket taking every pass
+            ++ix.build_redos;
+            continue;
+        }
+        break;
     }
     if (plan[P_LCORE] != plan[P_CORE]) {
         ix.n = 0;
@@ -580,7 +590,7 @@ int shard_local_build(Index& ix)
         set_error("pcpx: internal error, the rank-local index holds %u of the core's %u points", plan[P_LCORE], plan[P_CORE]);
         return PCPX_ERR_DEVICE;
     }
-    if ((st = build_tree_from_sorted(ix, m)) != PCPX_OK) return st;
+    build_tree_set_shape(ix, m);
     sh.n_glob = new_n_glob;
     sh.g_first = new_g_first;
     sh.g_count = new_g_count;

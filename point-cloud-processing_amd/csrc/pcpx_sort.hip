@@ -245,6 +245,32 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_setup(const u32* __rest
     if (threadIdx.x == 0) seg->tile_first[RADIX] = tiles;
 }
 
+// finish mode (SortPayload::finish), after the top-digit pass and the per-bucket digit counts: which buckets may stop after their top
+// two lower digits.  A bucket of c words whose fullest 16-bit cell (= its largest count of the digit at bits [48, 56)) holds m words
+// has c / 65536 words per 24-bit cell on average and m / 256 in that cell's: both at most SORT_RUN_TARGET, or the bucket takes all
+// its passes.  first_pass is 1 or low - 1: the same parity (low = 4), which is why the top-digit pass could put every bucket into
+// the same buffer before this was known.  One block; thread = bucket.
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_plan(const u32* __restrict__ seg_hist, SegTable* __restrict__ seg, int low,
+                                                              const u32* __restrict__ force_full)
+{
+    __shared__ u32 wtot[SORT_WAVES];
+    const u32 b = threadIdx.x;
+    const u32 c = seg->start[b + 1] - seg->start[b];
+    const u32* top_digit = seg_hist + (static_cast<size_t>(b) * (MAX_PASSES - 1) + (low - 1)) * RADIX;
+    u32 fullest = 0;
+    for (int d = 0; d < RADIX; ++d) fullest = max(fullest, top_digit[d]);
+    const bool forced = force_full && ((force_full[b >> 5] >> (b & 31u)) & 1u) != 0u;
+    const bool short_runs = !forced && b != RADIX - 1 && (c >> 16) <= SORT_RUN_TARGET && (fullest >> 8) <= SORT_RUN_TARGET;
+    const u32 first = short_runs ? static_cast<u32>(low - 1) : 1u;
+    seg->first_pass[b] = first;
+    for (int q = 1; q <= low; ++q) {
+        u32 tiles = 0;
+        const u32 f = block_exclusive_scan(static_cast<u32>(q) >= first ? (c + SORT_TILE - 1) / SORT_TILE : 0u, wtot, tiles);
+        seg->pass_tile_first[q - 1][b] = f;
+        if (b == 0) seg->pass_tile_first[q - 1][RADIX] = tiles;
+    }
+}
+
 // status word: bits [0,40) count, [40,42) state (1 = this tile's own count, 2 = running total up to and including this
 // tile), [44,48) pass tag (pass + 1; 0 = never written since the array was cleared)
 constexpr u64 ST_LOCAL = 1ull << 40, ST_PREFIX = 2ull << 40, ST_STATE = 3ull << 40, ST_COUNT = (1ull << 40) - 1ull;
@@ -633,7 +659,8 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     }
     const u32* top = top_hist;
     u32* failed = payload && payload->failed_flag ? payload->failed_flag : ctl + 8;
-    const int margin = (payload && low >= 3) ? payload->adaptive_margin_bits : 0;
+    const bool finish = payload && payload->finish && low == 4;  // (the parity argument of k_sort_seg_plan)
+    const int margin = (payload && low >= 3 && !finish) ? payload->adaptive_margin_bits : 0;
     k_sort_seg_setup<<<1, SORT_BLOCK, 0, s>>>(top, seg, low, margin);
 
     // persistent grids: as many blocks as are resident at once (4 per CU: LDS and registers), never more than tiles
@@ -653,7 +680,8 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
     const u32 grid_top = static_cast<u32>(ntiles);  // (one tile per block: no chain, nothing to keep resident)
     const u32 grid_seg = static_cast<u32>(L.ntiles_max < resident ? L.ntiles_max : resident);
     // ping-pong between tmp and out so that the LAST pass writes out
-    auto dst_of = [&](int j) { return ((passes - 1 - j) & 1) == 0 ? kout : kt; };
+    // (finish mode: the last pass writes the temporary buffer -- kout's buffer is for what the caller's finish kernel makes of it)
+    auto dst_of = [&](int j) { return (((passes - 1 - j) & 1) == 0) != finish ? kout : kt; };
     SortPayloadArgs pl{nullptr, nullptr, 0, nullptr};
     u64* kdst = dst_of(0);
     u64* kodd = dst_of(1);  // (a bucket whose first bucketed pass is pass q is read there from dst_of(q - 1))
@@ -671,12 +699,17 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
         tpb = tpb < 2 ? 2 : tpb > 32 ? 32 : tpb;
         const u32 hblocks = static_cast<u32>((L.ntiles_max + tpb - 1) / tpb);
         k_sort_seg_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kdst, kodd, seg, first_bit, low, tpb, seg_hist);
+        if (finish) k_sort_seg_plan<<<1, SORT_BLOCK, 0, s>>>(seg_hist, seg, low, payload->force_full);
         const u64* ksrc = kdst;
         for (int p = 0; p < low; ++p) {
             kdst = dst_of(p + 1);
             k_sort_pass<true, false><<<grid_seg, SORT_BLOCK, 0, s>>>(ksrc, kdst, nullptr, n32, 0u, first_bit + 8 * p, p + 1, seg_hist + p * RADIX, nullptr, seg, status, ctl, failed, pl);
             ksrc = kdst;
         }
+    }
+    if (payload && payload->finish_out) {
+        payload->finish_out->words = finish ? dst_of(passes - 1) : nullptr;
+        payload->finish_out->bucket_first_pass = seg->first_pass;
     }
     return check_hip(hipGetLastError(), "radix sort kernels", __FILE__, __LINE__);
 }

@@ -352,6 +352,15 @@ class Index:
         """Counts at curve positions (d_cnt[p] = count around the p-th point of the index's order; perm_dev gives the order)."""
         check(self._lib.pcpx_range_count_self_curve_order_dev(self._h, radius, first, count, C.c_void_p(d_cnt)))
 
+    def range_lists_self_dev(self, radius, d_offsets, d_idx=None, capacity=0):
+        """pcpx_range_lists_self_dev: CSR lists of every indexed point's sphere range, device resident.  Returns the total; with d_idx
+        None (or too small) only the offsets are filled -- allocate `total` indices and call again."""
+        total = C.c_uint64(0)
+        st = self._lib.pcpx_range_lists_self_dev(self._h, radius, C.c_void_p(d_offsets), C.c_void_p(d_idx) if d_idx else None, capacity, C.byref(total))
+        if st != _capi.PCPX_OK and not (st == _capi.PCPX_ERR_CAPACITY and (not d_idx or capacity < total.value)):
+            check(st)
+        return int(total.value)
+
     def synchronize(self):
         check(self._lib.pcpx_index_synchronize(self._h))
 

@@ -221,3 +221,46 @@ def test_one_rank_local_handle_asked_growing_radii_then_knn(pkg):
         assert int(sel.sum()) == count and torch.equal(sidx[sel], idx[sel]) and torch.equal(sd2[sel], d2[sel])
         sh.close()
     ix.close()
+
+
+@pytest.mark.parametrize("kind,n,radius", [("uniform", 200_000, 0.03), ("clustered", 300_000, 0.004), ("uniform", 3_000, 0.2)])
+def test_device_resident_range_lists_of_every_point(pkg, oracle, kind, n, radius):
+    """pcpx_range_lists_self_dev (counts -> 64-bit scan -> fill with the packed leaf form) against the brute-force oracle: every
+    list is the set of points within the radius (sphere.hpp:27-35, the centre included), lists of points outside the grid are
+    empty, offsets are the exclusive scan of the counts."""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    pts = np.concatenate([_cloud(pkg, kind, n), rng.uniform(-0.2, 1.2, (n // 50, 3)).astype(np.float32)])
+    m = len(pts)
+    grid = np.array([0, 0, 0, 1, 1, 1], np.float32)
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), m, voxel_grid=grid)
+    off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    total = ix.range_lists_self_dev(radius, off.data_ptr())
+    assert total > 0
+    idx = torch.full((total,), -1, dtype=torch.int32, device=dev)
+    assert ix.range_lists_self_dev(radius, off.data_ptr(), idx.data_ptr(), total) == total
+    ix.synchronize()
+    off_h, idx_h = off.cpu().numpy(), idx.cpu().numpy().view(np.uint32)
+    inside = np.all((pts >= 0) & (pts <= 1), axis=1)
+    counts = np.diff(off_h)
+    assert off_h[0] == 0 and off_h[-1] == total and (counts[~inside] == 0).all() and (counts[inside] >= 1).all()
+    want = oracle.range_count_bruteforce(pts[inside], pts[inside], radius, nthreads=16)
+    assert np.array_equal(counts[inside], want)
+    cnt_dev = torch.zeros(m, dtype=torch.int32, device=dev)
+    ix.range_count_self_dev(radius, cnt_dev.data_ptr())
+    ix.synchronize()
+    assert np.array_equal(cnt_dev.cpu().numpy()[inside], want)
+    # members: every listed point is within the radius of its centre (float arithmetic of the reference), no duplicates
+    sel = rng.choice(np.nonzero(inside)[0], 2000, replace=False)
+    for i in sel:
+        lst = idx_h[off_h[i]:off_h[i + 1]]
+        d = pts[lst] - pts[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert len(np.unique(lst)) == len(lst) and (d2 <= np.float32(radius) * np.float32(radius)).all() and i in lst
+    # the host-pointer list form for arbitrary centres gives the same sets
+    o2, i2 = ix.range_sphere(pts[sel[:200]], radius)
+    for q, i in enumerate(sel[:200]):
+        assert set(i2[o2[q]:o2[q + 1]].tolist()) == set(idx_h[off_h[i]:off_h[i + 1]].tolist())
+    ix.close()
