@@ -28,7 +28,7 @@ namespace {
 #endif
 constexpr size_t SCALARS = 32;  // u32 words of Index::d_scalars: [0, 6) encoded box, [6] points outside the grid, [7] sort failure, [8, 14) box,
                                 //   [16, 24) buckets whose runs the finish kernel could not order (REDO_WORD0), [24, 32) the buckets to sort fully (FORCE_WORD0)
-constexpr u32 REDO_WORD0 = 16, FORCE_WORD0 = 24;
+constexpr u32 REDO_WORD0 = 16, FORCE_WORD0 = 24, LOW_TILES_WORD = 15;  // ([15]: tiles of the sort's lowest pass, see sort_for_build)
 
 // order-preserving float <-> uint encoding for atomic min/max
 __device__ __forceinline__ u32 enc_f(float f)
@@ -335,12 +335,14 @@ __host__ __device__ inline u32 finish_blocks(const TreeShape& ts)
 // become ~50 LDS reads per word.  A run longer than FIN_MARGIN -- a cell far denser than its bucket's fullest 16-bit cell
 // suggested -- cannot be ordered here: the block notes the bucket in `redo` and the host repeats the sort with that bucket taking
 // every pass (the handle remembers it).  Buckets that took every pass have nothing to order: their runs are ties on all sorted
-// bits, which the stable passes left in input order.  The fully sorted words go to `sorted_out` (prepare_queries searches them).
+// bits, which the stable passes left in input order.  The ordered words themselves are not written back: what searches the sorted
+// words afterwards (prepare_queries' seeds, the rank-local build's core) needs them ordered on their top 24 bits only, which the
+// prefix-sorted words are (Index::sorted_codes).
 constexpr int FIN_MARGIN = 64;
 constexpr int FIN_WINDOW = FILL_SLOTS + 2 * FIN_MARGIN;  // words of the window; + one word on either side to see whether its ends start runs
 struct FinishArgs {
-    const u64* words;              // prefix-sorted words, or nullptr: `sorted_out` holds fully sorted words already (nothing to order)
-    u64* sorted_out;
+    const u64* words;              // prefix-sorted words, or nullptr: `sorted` holds fully sorted words (nothing to order)
+    const u64* sorted;
     const u32* bucket_first_pass;  // per top digit: the first bucketed pass the bucket took (1: all of them)
     int first_bit;                 // lowest sorted bit of a bucket that took every pass
     u32* redo;                     // bitmap, 8 words
@@ -352,10 +354,24 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
     __shared__ __attribute__((aligned(16))) NodeBox lvl0[FILL_LEAVES];      // leaf boxes of the block
     __shared__ __attribute__((aligned(16))) NodeBox lvl1[FILL_LEAVES / 4];
     __shared__ __attribute__((aligned(16))) NodeBox lvl2[FILL_LEAVES / 16];
-    __shared__ __attribute__((aligned(16))) u32 rec_stage[FILL_BLOCK / 64][FILL_PER_THREAD][64 * 4];  // per wave and trip: 8 leaf records
-    __shared__ u64 cov[FIN_WINDOW + 2];            // cov[1 + s] = word at position lo - FIN_MARGIN + s
-    __shared__ unsigned char starts[FIN_WINDOW + 2];  // starts[j]: a run starts at cov[j] (or cov[j] is no word at all)
-    __shared__ unsigned char shift_of[256];        // per bucket: the words are ordered on bits [shift_of, 64)
+    // (the window of words and its flags are dead when the leaf records are staged: one piece of LDS for both -- 21 KB per block, seven
+    //  blocks per CU, as before the window was there)
+    union alignas(16) Piece {
+        u32 rec_stage[FILL_BLOCK / 64][FILL_PER_THREAD][64 * 4];  // per wave and trip: 8 leaf records
+        struct {
+            u64 cov[FIN_WINDOW + 2];                 // cov[1 + s] = word at position lo - FIN_MARGIN + s
+            unsigned char starts[FIN_WINDOW + 2];    // starts[j]: a run starts at cov[j] (or cov[j] is no word at all)
+            unsigned char shift_of[256];             // per bucket: the words are ordered on bits [shift_of, 64)
+            unsigned short place[FIN_WINDOW + 2];    // where cov[j] belongs
+        } window;
+    };
+    __shared__ Piece piece;
+    __shared__ u32 any_partial_s;
+    auto& rec_stage = piece.rec_stage;
+    auto& cov = piece.window.cov;
+    auto& starts = piece.window.starts;
+    auto& shift_of = piece.window.shift_of;
+    auto& place = piece.window.place;
     const u32 n = bc.valid();
     const TreeShape ts = shape_of(n);
     const u32 nblocks = finish_blocks(ts);
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
     if (fa.words) {
         constexpr u64 NO_WORD = ~0ull;
         shift_of[threadIdx.x] = static_cast<unsigned char>(fa.first_bit + 8 * (static_cast<int>(fa.bucket_first_pass[threadIdx.x]) - 1));
+        if (threadIdx.x == 0) any_partial_s = 0;
         const long long base = static_cast<long long>(vb) * FILL_SLOTS - FIN_MARGIN - 1;  // position of cov[0]
         for (u32 j = threadIdx.x; j < FIN_WINDOW + 2; j += FILL_BLOCK) {
             const long long g = base + j;
@@ -382,23 +399,22 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
                 const u64 w = cov[j], before = cov[j - 1];
                 const int sh = shift_of[static_cast<u32>(w >> 56)];
                 st = (w >> sh) != (before >> sh);
+                if (sh > fa.first_bit && !st) any_partial_s = 1;  // (a run of two or more in a bucket that stopped early: something to order)
             }
             starts[j] = st ? 1 : 0;
         }
         __syncthreads();
-        // every word of the window: where its run starts and ends (if both are in sight), and how many of the run are smaller
+        if (__builtin_amdgcn_readfirstlane(any_partial_s) != 0u) {  // (block-uniform; clouds whose buckets all took every pass, and most tiles of sparse ones, skip this)
+        // every word of the window: where its run starts and ends (if both are in sight), and how many of the run are smaller -- its
+        // place, noted in LDS (one copy of the two scans: unrolled over a thread's words they cost 300 saved lane masks)
         constexpr int PER = (FIN_WINDOW + FILL_BLOCK - 1) / FILL_BLOCK;
-        u64 mine[PER];
-        u32 dest[PER];
         u32 redo_bucket = ~0u;
-#pragma unroll
+#pragma unroll 1
         for (int u = 0; u < PER; ++u) {
             const u32 j = 1u + threadIdx.x + u * FILL_BLOCK;  // cov[1 ... FIN_WINDOW] are the window
-            dest[u] = j;
-            mine[u] = NO_WORD;
-            if (j > FIN_WINDOW) continue;
+            if (j > FIN_WINDOW) break;
+            place[j] = static_cast<unsigned short>(j);
             const u64 w = cov[j];
-            mine[u] = w;
             const long long g = base + j;
             if (!(g >= 0 && g < static_cast<long long>(n))) continue;
             const u32 bucket = static_cast<u32>(w >> 56);
@@ -406,17 +422,19 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
             const bool in_tile = j > FIN_MARGIN && j <= FIN_MARGIN + FILL_SLOTS;
             u32 a = j, smaller = 0, steps = 0;
             bool whole = true;
-            while (!starts[a]) {  // (starts[0] is set whenever cov[0] is no word; otherwise reaching 0 means the run began out of sight)
-                if (a == 0u || ++steps > FIN_MARGIN) {
+#pragma nounroll  // (bounded by FIN_MARGIN, hipcc would write all 64 trips out, each with a saved lane mask of its own)
+            while (!starts[a]) {  // (starts[0] is always set: reaching it means the run began out of sight)
+                if (++steps > FIN_MARGIN) {
                     whole = false;
                     break;
                 }
                 --a;
                 smaller += cov[a] < w ? 1u : 0u;
             }
-            if (whole && a == 0u) whole = false;  // (cov[0] itself: a word of the neighbour's, its run's start unknown)
+            if (a == 0u) whole = false;
             u32 b = j + 1u;
-            while (whole && b <= FIN_WINDOW + 1u && !starts[b]) {
+#pragma nounroll
+            while (whole && !starts[b]) {  // (b <= FIN_WINDOW + 1 whenever this is evaluated)
                 if (b == FIN_WINDOW + 1u || ++steps > FIN_MARGIN) {
                     whole = false;
                     break;
@@ -424,27 +442,38 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
                 smaller += cov[b] < w ? 1u : 0u;
                 ++b;
             }
-            if (whole) dest[u] = a + smaller;
+            if (whole) place[j] = static_cast<unsigned short>(a + smaller);
             else if (in_tile) redo_bucket = bucket;
         }
         if (redo_bucket != ~0u) atomicOr(&fa.redo[redo_bucket >> 5], 1u << (redo_bucket & 31u));
+        __syncthreads();
+        u64 mine[PER];
+        u32 dest[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const u32 j = 1u + threadIdx.x + u * FILL_BLOCK;
+            const u32 jj = j <= FIN_WINDOW ? j : FIN_WINDOW;
+            mine[u] = cov[jj];
+            dest[u] = place[jj];
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u)
             if (1u + threadIdx.x + u * FILL_BLOCK <= FIN_WINDOW) cov[dest[u]] = mine[u];
         __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < FILL_PER_THREAD; ++u) {
             const u32 p = p0 + u * FILL_BLOCK;
             const u64 w = cov[1 + FIN_MARGIN + threadIdx.x + u * FILL_BLOCK];
-            if (p < n) fa.sorted_out[p] = w;
             at[u] = p < n ? (w & low) : 0ull;  // (a padding slot gathers record 0 and writes nothing)
         }
+        __syncthreads();  // (the window is dead: its LDS is the leaf records' stage from here on)
     } else {
 #pragma unroll
         for (int u = 0; u < FILL_PER_THREAD; ++u) {
             const u32 p = p0 + u * FILL_BLOCK;
-            at[u] = p < n ? (fa.sorted_out[p] & low) : 0ull;
+            at[u] = p < n ? (fa.sorted[p] & low) : 0ull;
         }
     }
     float x[FILL_PER_THREAD], y[FILL_PER_THREAD], z[FILL_PER_THREAD];
@@ -856,6 +885,7 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
             set_error("pcpx: internal error, the radix sort's look-back gave up");
             return PCPX_ERR_DEVICE;
         }
+        if (n > 0 && ix.finish_words) ix.low_pass_tiles = hb[LOW_TILES_WORD - 6];
         bool redo = false;
         for (u32 w = 0; w < 8; ++w) {
             const u32 r = hb[REDO_WORD0 - 6 + w];
@@ -893,10 +923,12 @@ int sort_for_build(Index& ix, const u64* d_words, u64 n, const float* d_xyz_src,
     pl.finish = PCPX_BUILD_FINISH != 0;
     pl.force_full = any_forced ? ix.d_scalars + FORCE_WORD0 : nullptr;
     pl.finish_out = &fo;
-    ix.sorted_from_bit = SORT_FIRST_BIT;
+    pl.low_pass_tiles_hint = ix.low_pass_tiles;
+    pl.low_pass_tiles_out = ix.d_scalars + LOW_TILES_WORD;
     const int st = sort_keys_u64(ix.d_sort_tmp, tb, d_words, ix.d_codes[1], n, s, SORT_FIRST_BIT, &pl);
     ix.finish_words = fo.words;
     ix.finish_first_pass = fo.bucket_first_pass;
+    ix.sorted_from_bit = fo.words ? 40 : SORT_FIRST_BIT;  // (Index::sorted_codes: the prefix-sorted words, ordered on bits [40, 64) everywhere)
     return st;
 }
 

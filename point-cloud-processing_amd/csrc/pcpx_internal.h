@@ -202,6 +202,7 @@ struct Index {
     const u32* finish_first_pass = nullptr;  // ... and its per-bucket table
     u32 full_buckets[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // top-digit buckets that take every radix pass (a build found a run it could not order in LDS)
     u32 build_redos = 0;                   // builds that were repeated because of that (diagnostic)
+    u32 low_pass_tiles = ~0u;              // tiles the sort's two lowest passes had in the last build (~0: no build yet): sizes their grids next time
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     Leaf* d_leaves = nullptr;
@@ -293,7 +294,9 @@ struct Index {
         u64 last_failed = 0, total_failed = 0, enlargements = 0;  // diagnostics
     } shard;
 
-    u64* sorted_codes() const { return d_codes[1]; }
+    // the words of the indexed points in curve order, ordered on their bits [sorted_from_bit, 64): the last sort's prefix-sorted words
+    // (they live in d_sort_tmp until the next build of this handle) or, when the sort ran every pass, d_codes[1]
+    const u64* sorted_codes() const { return finish_words ? finish_words : d_codes[1]; }
     u32* perm() const { return d_perm; }
     TreeView view() const { return TreeView{d_leaves, d_nodes, nleaves, static_cast<u32>(n), depth, leaf0}; }
 };
@@ -375,6 +378,8 @@ struct SortPayload {
     // kernel's output is what kout's buffer is for -- with the bucket table beside them.
     bool finish = false;
     const u32* force_full = nullptr;      // finish: device bitmap, 8 words; bit b: bucket b takes every pass
+    u32 low_pass_tiles_hint = ~0u;        // finish: tiles the two lowest passes had in this handle's last build (~0: unknown) ...
+    u32* low_pass_tiles_out = nullptr;    // ... and where this sort leaves its own count (device word)
     struct FinishOut {
         const u64* words = nullptr;           // n words, ordered on bits [first_bit + 8 (first_pass[b] - 1), 64) inside bucket b
         const u32* bucket_first_pass = nullptr;  // 256 entries (device)

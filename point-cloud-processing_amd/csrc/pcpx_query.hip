@@ -635,9 +635,11 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     const u32 p = p_here;
     const u32 nq = SELF ? t.n : ka->qv.nq;
     // (self queries: only the positions [pos_lo, pos_hi) the caller asked for -- a slice that starts or ends inside a group)
-    // (`part` = 0: the whole group; 1 ... ORDER_PARTS: only lanes 8 (part - 1) ... 8 part - 1 -- an eighth of a LONG group, whose other
-    //  eighths other waves answer at the same time: order_entries)
-    const bool valid = p < nq && (!SELF || p - pos_lo < pos_hi - pos_lo) && (part == 0u || ((p >> 3) & 7u) + 1u == part);  // (from p, which is opaque per group: from `lane` it is one more value kept from group to group)
+    // (`part` = 0: the whole group; 1 ... 8: only its lanes 8 (part - 1) ... 8 part - 1 -- an eighth of a LONG group, whose other eighths
+    //  other waves answer at the same time; 9 ... 12: a quarter, 13 / 14: a half -- the groups of a launch's last, partly filled round:
+    //  order_entries.  From p, which is opaque per group: from `lane` it is one more value kept from group to group.)
+    const bool mine_of_part = part <= 8u ? ((p >> 3) & 7u) + 1u == part : part <= 12u ? ((p >> 4) & 3u) + 9u == part : ((p >> 5) & 1u) + 13u == part;
+    const bool valid = p < nq && (!SELF || p - pos_lo < pos_hi - pos_lo) && (part == 0u || mine_of_part);
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (valid) {
         if (SELF) {
@@ -1470,6 +1472,11 @@ constexpr u32 LPT_MIN_GROUPS = 512;
 #ifndef PCPX_LPT_SPLIT
 #define PCPX_LPT_SPLIT 1  // class-0 groups are handed out as ORDER_PARTS entries of 8 lanes each
 #endif
+#ifndef PCPX_TAIL_SPLIT
+#define PCPX_TAIL_SPLIT 0  // 1: the groups of a launch's last round in pieces when that round is at most half full.  Measured (round 5,
+                           // tools/ab_sizes.py): SLOWER -- 1 M queries 2 130 -> 1 880 Mq/s, 0.5 M 1 520 -> 1 380, 2 M 2 475 -> 2 370: a piece of 16
+                           // lanes costs most of a group (its seed leaves, its walk's common part, its epilogue), not half of one
+#endif
 #ifndef PCPX_LPT_HI_PCT
 #define PCPX_LPT_HI_PCT 200ull   // class 0: groups that took more than twice their queue's mean ...
 #endif
@@ -1477,7 +1484,12 @@ constexpr u32 LPT_MIN_GROUPS = 512;
 #define PCPX_LPT_MID_PCT 150ull  // ... class 1: more than 1.5 x.  (7/4 and 9/8 -- a third of a uniform cloud's groups out of curve order -- cost the
                                  //  10 M uniform launch 4 %: the queue's walk along the curve is what keeps its XCD's L2 warm.)
 #endif
-__global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gtime, u32 ngroups, u32 group_first, u32* __restrict__ order)
+// tail_parts (0, 2, 4, 8) / tail_groups: the last tail_groups groups of every queue's list are handed out in tail_parts pieces each
+// -- the launch's last round, when it is at most 1 / tail_parts full: a persistent launch of G groups on W resident waves ends with
+// G mod W groups on as many waves while the others idle for a whole group's time (1 M queries: 2.2 rounds); in pieces they fill
+// the round, and a piece of 16 lanes takes about half a group's time.  gtime == nullptr: no recorded times, curve order.
+__global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gtime, u32 ngroups, u32 group_first, u32* __restrict__ order, u32 tail_parts,
+                                                     u32 tail_groups)
 {
     __shared__ unsigned long long sum_s;
     __shared__ u32 cnt_s[3], base_s[3], wave_s[3][16];
@@ -1492,16 +1504,21 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
     if (t < 3) cnt_s[t] = 0;
     __syncthreads();
     unsigned long long mine = 0;
-    for (u32 i = qbeg + t; i < qend; i += 1024u) mine += gtime[i];
+    if (gtime)
+        for (u32 i = qbeg + t; i < qend; i += 1024u) mine += gtime[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
     if (lane == 0) atomicAdd(&sum_s, mine);
     __syncthreads();
     const unsigned long long mean = sum_s / (qend - qbeg);
     const unsigned long long hi = mean * PCPX_LPT_HI_PCT / 100ull, mid = mean * PCPX_LPT_MID_PCT / 100ull;
-    auto cls = [&](u32 v) -> u32 { return v > hi ? 0u : v > mid ? 1u : 2u; };
+    auto cls = [&](u32 i) -> u32 {
+        if (!gtime) return 2u;
+        const u32 v = gtime[i];
+        return v > hi ? 0u : v > mid ? 1u : 2u;
+    };
     u32 c[3] = {0, 0, 0};
-    for (u32 i = qbeg + t; i < qend; i += 1024u) ++c[cls(gtime[i])];
+    for (u32 i = qbeg + t; i < qend; i += 1024u) ++c[cls(i)];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         u32 v = c[b];
@@ -1510,17 +1527,20 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
         if (lane == 0 && v) atomicAdd(&cnt_s[b], v);
     }
     __syncthreads();
+    const u32 whole2 = cnt_s[2] > tail_groups ? cnt_s[2] - tail_groups : 0u;  // class-2 groups handed out whole; the rest in tail_parts pieces
+    const u32 tail_n = tail_parts ? cnt_s[2] - whole2 : 0u;
+    __syncthreads();
     if (t == 0) {
         base_s[0] = 0;
         base_s[1] = cnt_s[0];
         base_s[2] = cnt_s[0] + cnt_s[1];
-        order[blockIdx.x] = (PCPX_LPT_SPLIT ? ORDER_PARTS : 1u) * cnt_s[0] + cnt_s[1] + cnt_s[2];
+        order[blockIdx.x] = (PCPX_LPT_SPLIT ? ORDER_PARTS : 1u) * cnt_s[0] + cnt_s[1] + (cnt_s[2] - tail_n) + tail_parts * tail_n;
     }
     __syncthreads();
     for (u32 i0 = qbeg; i0 < qend; i0 += 1024u) {
         const u32 i = i0 + t;
         const bool in = i < qend;
-        const u32 b = in ? cls(gtime[i]) : 3u;
+        const u32 b = in ? cls(i) : 3u;
         u32 below = 0;
 #pragma unroll
         for (u32 bb = 0; bb < 3; ++bb) {
@@ -1537,7 +1557,15 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
 #pragma unroll
                 for (u32 part = 0; part < ORDER_PARTS; ++part) order[at + ORDER_PARTS * (base_s[0] + before + below) + part] = (group_first + i) | ((part + 1u) << ORDER_PART_SHIFT);
             } else {
-                order[at + (PCPX_LPT_SPLIT ? ORDER_PARTS - 1u : 0u) * cnt_s[0] + base_s[b] + before + below] = group_first + i;
+                const u32 slot = (PCPX_LPT_SPLIT ? ORDER_PARTS - 1u : 0u) * cnt_s[0] + base_s[b] + before + below;  // (were every class-1 / -2 group whole)
+                const u32 i2 = base_s[b] + before + below - (cnt_s[0] + cnt_s[1]);                                 // class 2: its number in the class
+                if (b == 2 && tail_n != 0u && i2 >= cnt_s[2] - tail_n) {
+                    const u32 first_piece = slot - (i2 - (cnt_s[2] - tail_n)) + tail_parts * (i2 - (cnt_s[2] - tail_n));
+                    const u32 code0 = tail_parts == 8u ? 1u : tail_parts == 4u ? 9u : 13u;
+                    for (u32 part = 0; part < tail_parts; ++part) order[at + first_piece + part] = (group_first + i) | ((code0 + part) << ORDER_PART_SHIFT);
+                } else {
+                    order[at + slot] = group_first + i;
+                }
             }
         }
         __syncthreads();
@@ -1585,22 +1613,32 @@ static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcoun
     int st = prepare_queue(ix);
     if (st != PCPX_OK) return st;
     KnnSchedule sch;
-    if (SELF && ix.tuning.lpt && gcount >= LPT_MIN_GROUPS) {
-        Index::Sched& sc = ix.sched;
-        const bool same = sc.state != 0 && sc.gf == gfirst && sc.gc == gcount && sc.kcap == KCAP && sc.k == k;
-        if (same && sc.state == 1) {
-            k_make_order<<<8, 1024, 0, ix.stream>>>(sc.d_gtime, static_cast<u32>(gcount), gf, sc.d_order);
-            sc.state = 2;
-        }
-        if (same) {
-            sch.order = sc.d_order;
-        } else if (sched_reserve(ix, gcount) == PCPX_OK) {
-            sch.gtime = sc.d_gtime;
-            sc.gf = gfirst, sc.gc = gcount, sc.kcap = KCAP, sc.k = k, sc.state = 1;
-        }
-    }
     auto* fn = k_knn<KCAP, SELF, 0, false, EPS_EACH, NZ>;
     const u32 pgrid = persistent_grid(ix, reinterpret_cast<const void*>(fn), 64 * WPB, lds, gcount, WPB);
+    if (SELF && ix.tuning.lpt && gcount >= LPT_MIN_GROUPS) {
+        Index::Sched& sc = ix.sched;
+        // the launch's last round: G mod W groups, in 2 / 4 / 8 pieces each if that still fits the resident waves (k_make_order)
+        const u64 waves = static_cast<u64>(pgrid) * WPB, rest = gcount % waves;
+        u32 tail_parts = 0;
+        if (PCPX_TAIL_SPLIT && gcount > waves && rest != 0) tail_parts = 8 * rest <= waves ? 8u : 4 * rest <= waves ? 4u : 2 * rest <= waves ? 2u : 0u;
+        const u32 tail_groups = tail_parts ? static_cast<u32>((rest + 7) / 8) : 0u;  // (per queue)
+        const bool same = sc.state != 0 && sc.gf == gfirst && sc.gc == gcount && sc.kcap == KCAP && sc.k == k;
+        if (same && (sc.state == 1 || sc.state == 3)) {  // times recorded: the order by them (and the tail in pieces)
+            k_make_order<<<8, 1024, 0, ix.stream>>>(sc.d_gtime, static_cast<u32>(gcount), gf, sc.d_order, tail_parts, tail_groups);
+            sc.state = 2;
+        }
+        if (same && sc.state == 2) {
+            sch.order = sc.d_order;
+        } else if (sched_reserve(ix, gcount) == PCPX_OK) {  // a new question: record; curve order, the tail in pieces if it pays
+            sch.gtime = sc.d_gtime;
+            sc.gf = gfirst, sc.gc = gcount, sc.kcap = KCAP, sc.k = k, sc.state = 1;
+            if (tail_parts) {
+                k_make_order<<<8, 1024, 0, ix.stream>>>(nullptr, static_cast<u32>(gcount), gf, sc.d_order, tail_parts, tail_groups);
+                sch.order = sc.d_order;
+                sc.state = 3;  // (recorded with an order in use: a group handed out in pieces leaves one piece's time, which is what it is worth)
+            }
+        }
+    }
     ProfileScope prof(ix, PCPX_K_KNN);
     fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr, sch});
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);

@@ -561,12 +561,13 @@ int shard_local_build(Index& ix)
         // (the words are ordered on their top 16 bits at least wherever they are: enough for the core's cells)
         k_shard_locate<<<1, 64, 0, s>>>(ix.finish_words ? ix.finish_words : ix.d_codes[1], sh.d_plan);
         if ((st = build_tree_from_sorted(ix, m, false)) != PCPX_OK) return st;
-        u32 sc[8], redo[8];
+        u32 sc[10], redo[8];  // (sc[9] = d_scalars[15]: tiles of the sort's lowest pass)
         PCPX_HIP(hipMemcpyAsync(sc, ix.d_scalars + 6, sizeof(sc), hipMemcpyDeviceToHost, s));
         PCPX_HIP(hipMemcpyAsync(redo, ix.d_scalars + BUILD_REDO_WORD0, sizeof(redo), hipMemcpyDeviceToHost, s));
         PCPX_HIP(hipMemcpyAsync(plan, sh.d_plan, sizeof(plan), hipMemcpyDeviceToHost, s));
         PCPX_HIP(hipStreamSynchronize(s));
         std::memcpy(ix.bbox, &sc[2], 6 * sizeof(float));
+        if (m > 0 && ix.finish_words) ix.low_pass_tiles = sc[9];
         if (m > 0 && sc[1]) {
             ix.n = 0;
             ix.nleaves = 0;

@@ -250,15 +250,13 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_setup(const u32* __rest
 // has c / 65536 words per 24-bit cell on average and m / 256 in that cell's: both at most SORT_RUN_TARGET, or the bucket takes all
 // its passes.  first_pass is 1 or low - 1: the same parity (low = 4), which is why the top-digit pass could put every bucket into
 // the same buffer before this was known.  One block; thread = bucket.
-__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_plan(const u32* __restrict__ seg_hist, SegTable* __restrict__ seg, int low,
-                                                              const u32* __restrict__ force_full)
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_plan(const u32* __restrict__ fullest_of, SegTable* __restrict__ seg, int low,
+                                                              const u32* __restrict__ force_full, u32* __restrict__ low_pass_tiles)
 {
     __shared__ u32 wtot[SORT_WAVES];
     const u32 b = threadIdx.x;
     const u32 c = seg->start[b + 1] - seg->start[b];
-    const u32* top_digit = seg_hist + (static_cast<size_t>(b) * (MAX_PASSES - 1) + (low - 1)) * RADIX;
-    u32 fullest = 0;
-    for (int d = 0; d < RADIX; ++d) fullest = max(fullest, top_digit[d]);
+    const u32 fullest = fullest_of[b];  // (k_sort_seg_hist)
     const bool forced = force_full && ((force_full[b >> 5] >> (b & 31u)) & 1u) != 0u;
     const bool short_runs = !forced && b != RADIX - 1 && (c >> 16) <= SORT_RUN_TARGET && (fullest >> 8) <= SORT_RUN_TARGET;
     const u32 first = short_runs ? static_cast<u32>(low - 1) : 1u;
@@ -268,6 +266,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_plan(const u32* __restr
         const u32 f = block_exclusive_scan(static_cast<u32>(q) >= first ? (c + SORT_TILE - 1) / SORT_TILE : 0u, wtot, tiles);
         seg->pass_tile_first[q - 1][b] = f;
         if (b == 0) seg->pass_tile_first[q - 1][RADIX] = tiles;
+        if (b == 0 && q == 1 && low_pass_tiles) *low_pass_tiles = tiles;  // (what the lowest passes have to do: the next build of this handle sizes their grids by it)
     }
 }
 
@@ -313,6 +312,9 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
     // (The top-digit pass, SEG = false, has no chain: one tile per block, taken by block index.)
     const u32* my_tile_first = SEG ? seg->pass_tile_first[tag_pass - 1] : seg->tile_first;  // (tag_pass = the bucketed pass's number, 1-based)
     const u32 ntiles = SEG ? my_tile_first[RADIX] : tiles_arg;
+    // (a pass that few buckets take part in -- finish mode: the two lowest digits are for the buckets with long runs only -- has fewer
+    //  tiles than the grid has blocks: a block beyond them leaves before it has touched LDS or the ticket; the others take every tile)
+    if (SEG && blockIdx.x >= ntiles) return;
     if (threadIdx.x == 0) place_s[0] = SEG ? atomicAdd(&ticket[tag_pass], 1u) : blockIdx.x;
     for (;;) {
     // (the thread's index is made opaque per tile: otherwise every address formed from it is a loop invariant of the
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(SORT_BLOCK, SORT_ITEMS <= 8 ? 6 : SORT_ITEMS <= 16 
 // `tiles_per_block` consecutive tiles of the bucketed tile order and flushes its LDS counts whenever the bucket changes.
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restrict__ keys_even, const u64* __restrict__ keys_odd,
                                                               const SegTable* __restrict__ seg, int first_bit, int passes, u32 tiles_per_block,
-                                                              u32* __restrict__ hist)
+                                                              u32* __restrict__ hist, u32* __restrict__ fullest)
 {
     __shared__ u32 h[MAX_PASSES - 1][RADIX];
     __shared__ u32 place_s[2];
@@ -547,7 +549,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restr
         __syncthreads();
         for (int p = 0; p < passes; ++p) {
             const u32 c = h[p][threadIdx.x];
-            if (c) atomicAdd(&hist[(static_cast<size_t>(bucket) * (MAX_PASSES - 1) + p) * RADIX + threadIdx.x], c);
+            if (c) {
+                const u32 before = atomicAdd(&hist[(static_cast<size_t>(bucket) * (MAX_PASSES - 1) + p) * RADIX + threadIdx.x], c);
+                // (finish mode: the bucket's largest count of its top lower digit -- the add that completes a count sees the total)
+                if (fullest && p == passes - 1) atomicMax(&fullest[bucket], before + c);
+            }
             h[p][threadIdx.x] = 0;
         }
     };
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_seg_hist(const u64* __restr
 }
 
 struct TmpLayout {
-    size_t o_top, o_ctl, o_seg, o_seghist, o_status, o_tilehist, o_chunks, o_k, total;
+    size_t o_top, o_ctl, o_seg, o_seghist, o_fullest, o_status, o_tilehist, o_chunks, o_k, total;
     u64 ntiles_max;
 };
 TmpLayout tmp_layout(u64 n)
@@ -597,7 +603,8 @@ TmpLayout tmp_layout(u64 n)
     t.o_ctl = t.o_top + al(RADIX * sizeof(u32));
     t.o_seg = t.o_ctl + al(64 * sizeof(u32));
     t.o_seghist = t.o_seg + al(sizeof(SegTable));
-    t.o_status = t.o_seghist + al(static_cast<size_t>(RADIX) * (MAX_PASSES - 1) * RADIX * sizeof(u32));
+    t.o_fullest = t.o_seghist + al(static_cast<size_t>(RADIX) * (MAX_PASSES - 1) * RADIX * sizeof(u32));
+    t.o_status = t.o_fullest + al(RADIX * sizeof(u32));
     t.o_tilehist = t.o_status + al(t.ntiles_max * RADIX * sizeof(u64));
     t.o_chunks = t.o_tilehist + al(t.ntiles_max * RADIX * sizeof(u32));
     t.o_k = t.o_chunks + al(static_cast<size_t>(SCAN_CHUNKS_MAX) * RADIX * sizeof(u32));
@@ -698,12 +705,21 @@ int sort_keys_u64(void* tmp, size_t& tmp_bytes, const u64* kin, u64* kout, u64 n
         u32 tpb = static_cast<u32>(L.ntiles_max / 2048);  // tiles per block: enough blocks to fill the chip, few flushes of the counts
         tpb = tpb < 2 ? 2 : tpb > 32 ? 32 : tpb;
         const u32 hblocks = static_cast<u32>((L.ntiles_max + tpb - 1) / tpb);
-        k_sort_seg_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kdst, kodd, seg, first_bit, low, tpb, seg_hist);
-        if (finish) k_sort_seg_plan<<<1, SORT_BLOCK, 0, s>>>(seg_hist, seg, low, payload->force_full);
+        u32* fullest = reinterpret_cast<u32*>(base + L.o_fullest);  // (cleared with the rest above)
+        k_sort_seg_hist<<<hblocks, SORT_BLOCK, 0, s>>>(kdst, kodd, seg, first_bit, low, tpb, seg_hist, finish ? fullest : nullptr);
+        if (finish) k_sort_seg_plan<<<1, SORT_BLOCK, 0, s>>>(fullest, seg, low, payload->force_full, payload->low_pass_tiles_out);
         const u64* ksrc = kdst;
         for (int p = 0; p < low; ++p) {
             kdst = dst_of(p + 1);
-            k_sort_pass<true, false><<<grid_seg, SORT_BLOCK, 0, s>>>(ksrc, kdst, nullptr, n32, 0u, first_bit + 8 * p, p + 1, seg_hist + p * RADIX, nullptr, seg, status, ctl, failed, pl);
+            // (finish mode: the two lowest passes are for the buckets with long runs only -- none in a uniform cloud -- and a grid of a
+            //  thousand blocks costs 13 us to start and end even when no block finds a tile: the caller says how many tiles the last
+            //  build of this handle had there, and the grid follows with room to spare; too few blocks are slower, never wrong)
+            u32 grid_here = grid_seg;
+            if (finish && p < low - 2 && payload->low_pass_tiles_hint != ~0u) {
+                const u64 want = 2ull * payload->low_pass_tiles_hint + 64;
+                if (want < grid_here) grid_here = static_cast<u32>(want);
+            }
+            k_sort_pass<true, false><<<grid_here, SORT_BLOCK, 0, s>>>(ksrc, kdst, nullptr, n32, 0u, first_bit + 8 * p, p + 1, seg_hist + p * RADIX, nullptr, seg, status, ctl, failed, pl);
             ksrc = kdst;
         }
     }
