@@ -48,6 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+PROFILE_TAG = "r05"  # the committed counter files this run quotes (profiles/<tag>_hbm_traffic.json, <tag>_issue.json)
 
 WORKLOADS = {
     # name: (generator, n, seed, k)
@@ -645,21 +646,43 @@ def main():
         # write + 12 B normal write per query (84 B at k = 15); the fused k_knn launch does exactly that
         bytes_per_q = 12 + 4 * k + (0 if args.workload in STREAMING else 12)
         achieved = q_per_launch * bytes_per_q / avg_s
-        roofline = {"bound": "hbm", "limiter": "instructions issued per wave, the scalar ones first: ~33 000 per 64 queries at 7 waves per SIMD (profiles/r04_pmc_summary.json, profiles/experiments/README.md round 4)", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
+        roofline = {"bound": "hbm", "kernel": "k_knn", "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6), "traffic": None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": launches,
                     "algorithmic_bytes_per_query": bytes_per_q, "queries_per_launch": q_per_launch,
-                    "note": "fused kNN+normals kernel: a tree search, bounded by instruction issue (per wave; the scalar side first), not by HBM (DESIGN.md "
-                            "'Roofline'); achieved = algorithmic bytes / HIP-event time of the launch on its stream, measured in this "
-                            "run; traffic = PMC HBM bytes per launch from the committed rocprofv3 --pmc passes of this command "
-                            "(profiles/r04_hbm_traffic.json), null when that file is not for this workload"}
-        traffic_file = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+                    "note": "`bound`, `achieved`, `peak`, `frac` are the contract's HBM figures: algorithmic bytes / HIP-event time of the launch on its "
+                            "stream, measured in this run.  The kernel is a tree search and is NOT bounded by HBM: what binds it is instruction issue, "
+                            "and how full that is is in `issue` (DESIGN.md section 5).  traffic = PMC HBM bytes per launch from the committed rocprofv3 "
+                            "--pmc passes of this command (profiles/%s_hbm_traffic.json), null when that file is not for this workload" % PROFILE_TAG}
+        # What binds the kernel: the scalar issue slot of every SIMD (one scalar-class instruction per 4.1 cycles whatever the number of
+        # resident waves, profiles/r03_valu_issue_rates.txt) and, close behind, the vector pipe.  Instruction counts per launch from the
+        # committed counter passes of this command; the cycles are this run's launch time at the counter run's clock.
+        issue_file = os.path.join(ROOT, "profiles", PROFILE_TAG + "_issue.json")
+        if os.path.exists(issue_file) and world == 1:
+            try:
+                iss = json.load(open(issue_file))
+                if iss.get("workload") == args.workload:
+                    cyc = avg_s * iss["shader_clock_hz"]
+                    simds = iss["simds"]
+                    sc = iss["scalar_class_instructions_per_launch"] / simds * iss["cycles_per_scalar_instruction"] / cyc
+                    vlo = iss["valu_instructions_per_launch"] / simds * iss["cycles_per_valu_instruction_range"][0] / cyc
+                    vhi = iss["valu_instructions_per_launch"] / simds * iss["cycles_per_valu_instruction_range"][1] / cyc
+                    roofline["issue"] = {"bound": "scalar issue slots (SALU + SMEM + branches + s_waitcnt / s_nop), one per SIMD per ~4.1 cycles",
+                                         "scalar_issue_frac": round(sc, 3), "valu_issue_frac_range": [round(vlo, 3), round(vhi, 3)],
+                                         "scalar_class_instructions_per_launch": iss["scalar_class_instructions_per_launch"],
+                                         "valu_instructions_per_launch": iss["valu_instructions_per_launch"],
+                                         "instructions_per_query": round(iss["instructions_per_launch"] / q_per_launch, 1),
+                                         "source": "profiles/%s_issue.json (counters of the committed --pmc passes; launch time of THIS run; issue costs "
+                                                   "measured by tools/valu_rate.hip)" % PROFILE_TAG}
+            except Exception:
+                pass
+        traffic_file = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
                 if tr.get("workload") == args.workload and world == 1:
                     roofline["traffic"] = tr.get("k_knn_hbm_bytes_per_launch")
-                    roofline["traffic_source"] = "profiles/r04_hbm_traffic.json (separate --pmc passes, not this run)"
+                    roofline["traffic_source"] = "profiles/%s_hbm_traffic.json (separate --pmc passes, not this run)" % PROFILE_TAG
                     roofline["hbm_measured_GBps"] = round(roofline["traffic"] / avg_s / 1e9, 1)
                     roofline["hbm_measured_frac"] = round(roofline["traffic"] / avg_s / HBM_PEAK, 5)
             except Exception:

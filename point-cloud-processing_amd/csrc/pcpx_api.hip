@@ -989,10 +989,7 @@ int pcpx_knn_batch(pcpx_index* h, const float* q_xyz, uint64_t nq, uint32_t k, f
         char* stage = static_cast<char*>(ix->pinned.p);
         volatile u32* done = reinterpret_cast<volatile u32*>(stage + o_done);
         if (fresh) *done = 0u;
-        if (!ix->d_queue) {  // the work-queue counters' allocation also holds the latency path's completion counter (word 15 of queue 7)
-            PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix->d_queue), 8 * 16 * sizeof(u32)));
-            PCPX_HIP(hipMemsetAsync(ix->d_queue, 0, 8 * 16 * sizeof(u32), ix->stream));
-        }
+        if ((st = ensure_queue(*ix)) != PCPX_OK) return st;  // the work-queue counters' allocation also holds the latency path's completion counter (word 15 of queue 7 of the first set)
         u32* done_count = ix->d_queue + 8 * 16 - 1;
         std::memcpy(stage + o_q, q_xyz, nq * 3 * sizeof(float));
         const u32 epoch = ++ix->few_epoch ? ix->few_epoch : ++ix->few_epoch;  // never 0

@@ -221,7 +221,11 @@ struct Index {
     bool profiling = false;
     std::vector<Interval> intervals;
 
-    u32* d_queue = nullptr;  // work-queue counters of the persistent query kernels
+    u32* d_queue = nullptr;  // work-queue counters of the persistent query kernels: two sets of 8 (64 bytes apart each); a launch uses one and
+                             // zeroes the other for the launch after it (no memset dispatch between launches: prepare_queue)
+    u32 queue_set = 0;       // the set the next launch uses
+    u32* queue_now = nullptr;    // prepare_queue: this launch's set ...
+    u32* queue_clear = nullptr;  // ... and the one it leaves zeroed
     u64* d_multi = nullptr;  // k > 32: per-query pass keys + pass bounds
     size_t multi_bytes = 0;
 
@@ -433,7 +437,8 @@ int launch_wlop_median(Index& cloud, const QueryView& samples, float h, const vo
 int launch_wlop_repulsion(Index& samples, float h, float mu, const void* d_records_wi, const float* d_median, float* d_out);
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
 int launch_invert_perm(const u32* d_perm, u64 n, u32* d_position_of, hipStream_t s);
-int prepare_queue(Index& ix);  // zeroes the work-queue counters of the persistent kernels (stream-ordered)
+int ensure_queue(Index& ix);   // the counters' allocation (zeroed)
+int prepare_queue(Index& ix);  // which set of work-queue counters the next persistent launch uses (Index::queue_now) and which it zeroes (queue_clear)
 
 }  // namespace pcpx
 

@@ -564,6 +564,7 @@ struct KnnArgs {
     u32* queue;
     unsigned long long* stats;
     KnnSchedule sch;
+    u32* queue_clear;  // the other set of queue counters: zeroed by this launch for the next one
 };
 typedef const __attribute__((address_space(4))) KnnArgs* knn_args_ptr;
 __device__ __forceinline__ knn_args_ptr knn_args_here()
@@ -1344,6 +1345,7 @@ __global__ __launch_bounds__(64 * knn_wpb(KCAP, MULTI), KCAP <= 8 ? PCPX_MINW8 :
     u64* col = rows + lane;
     float* pub = reinterpret_cast<float*>(rows + BUF * 64);  // packed_leaf's rows (pack_rows), behind the buffer's
     if (pack_rows(MULTI, KCAP) > 0 && lane < static_cast<u32>(PCPX_PACKED_LEAVES)) pub[4u * lane + 3u] = -1.f;  // its invariant: a slot that holds no query holds tau = -1
+    if (blockIdx.x == 0 && wib == 0 && lane < 8u) a.queue_clear[lane * QUEUE_STRIDE] = 0u;  // (the next launch's counters: prepare_queue)
     if (PCPX_COMPACT_BY8 && !MULTI && (KCAP <= 16 || PCPX_BY8_K32)) {  // the chunked compaction's invariant: empty slots hold PAD_KEY
         const u64 pad = pad_key_here();
 #pragma unroll
@@ -1420,13 +1422,24 @@ u32 persistent_grid(Index& ix, const void* fn, int block, size_t lds, u64 groups
 
 }  // namespace
 
-// zeroed work-queue counters for one persistent launch (stream-ordered)
+// Work-queue counters of the persistent launches: TWO sets.  A launch takes its groups from one and its first wave zeroes the other,
+// which the next launch of the handle uses (launches of a handle are stream-ordered): no memset dispatch in front of every launch.
+// (Round 4 tried one set, cleared by the last wave out: that wave is found with one more atomic per wave, and was slower.)
+int ensure_queue(Index& ix)
+{
+    if (ix.d_queue) return PCPX_OK;
+    PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix.d_queue), 2 * 8 * QUEUE_STRIDE * sizeof(u32)));
+    PCPX_HIP(hipMemsetAsync(ix.d_queue, 0, 2 * 8 * QUEUE_STRIDE * sizeof(u32), ix.stream));
+    ix.queue_set = 0;
+    return PCPX_OK;
+}
 int prepare_queue(Index& ix)
 {
-    if (!ix.d_queue) PCPX_HIP(hipMalloc(reinterpret_cast<void**>(&ix.d_queue), 8 * QUEUE_STRIDE * sizeof(u32)));
-    // (measured, round 4: the last wave out clearing the counters instead of this memset -- one dispatch per launch instead of two --
-    //  is SLOWER, 1.72 against 1.84 Gq/s at 1 M queries and 2.46 against 2.48 at 10 M: profiles/experiments/README.md)
-    PCPX_HIP(hipMemsetAsync(ix.d_queue, 0, 8 * QUEUE_STRIDE * sizeof(u32), ix.stream));
+    const int st = ensure_queue(ix);
+    if (st != PCPX_OK) return st;
+    ix.queue_now = ix.d_queue + ix.queue_set * 8 * QUEUE_STRIDE;
+    ix.queue_set ^= 1u;
+    ix.queue_clear = ix.d_queue + ix.queue_set * 8 * QUEUE_STRIDE;
     return PCPX_OK;
 }
 
@@ -1640,7 +1653,7 @@ static int launch_knn_form(Index& ix, const QueryView& qv, u64 gfirst, u64 gcoun
         }
     }
     ProfileScope prof(ix, PCPX_K_KNN);
-    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.d_queue, nullptr, sch});
+    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, k, eps, thr, o, MultiPass{}, ix.queue_now, nullptr, sch, ix.queue_clear});
     return check_hip(hipGetLastError(), "k_knn launch", __FILE__, __LINE__);
 }
 
@@ -1669,7 +1682,7 @@ static int launch_knn_cost_form(Index& ix, u32 nsamples, u32 k, float eps, float
     KnnSchedule sch;
     sch.order = d_order;
     sch.events = d_events;
-    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, 0u, nsamples, k, eps, thr, KnnOutputs{}, MultiPass{}, ix.d_queue, nullptr, sch});
+    fn<<<pgrid, 64 * WPB, lds, ix.stream>>>(KnnArgs{ix.view(), qv, 0u, nsamples, k, eps, thr, KnnOutputs{}, MultiPass{}, ix.queue_now, nullptr, sch, ix.queue_clear});
     return check_hip(hipGetLastError(), "k_knn cost sample launch", __FILE__, __LINE__);
 }
 
@@ -1781,8 +1794,8 @@ static int launch_knn_multipass(Index& ix, const QueryView& qv, bool self, u64 g
         KnnOutputs range_only;  // (a pass writes keys, not rows; it still answers the asked positions only)
         range_only.pos_lo = o.pos_lo;
         range_only.pos_hi = o.pos_hi;
-        if (self) k_knn<KCAP, true, 0, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr, KnnSchedule{}});
-        else k_knn<KCAP, false, 0, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.d_queue, nullptr, KnnSchedule{}});
+        if (self) k_knn<KCAP, true, 0, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.queue_now, nullptr, KnnSchedule{}, ix.queue_clear});
+        else k_knn<KCAP, false, 0, true><<<pgrid, 64 * WAVES_PER_BLOCK, lds, ix.stream>>>(KnnArgs{ix.view(), qv, gf, ge, kp, eps, -1.f, range_only, mp, ix.queue_now, nullptr, KnnSchedule{}, ix.queue_clear});
     }
     const u32 n32 = static_cast<u32>(nslots);
     if (self) k_assemble<true><<<(n32 + 255) / 256, 256, 0, ix.stream>>>(ix.view(), qv, gf * GROUP, n32, k, stride, keys, o);
@@ -1885,7 +1898,7 @@ int launch_knn_stats(Index& ix, u32 k, float eps, unsigned long long* d_stats, c
     if (thr < 0.f) thr = std::numeric_limits<float>::infinity();
     k_knn<KCAP, true, 1><<<pgrid, 64 * WPB, lds, ix.stream>>>(
         KnnArgs{ix.view(), qv, 0u, static_cast<u32>(groups), k, sanitize_eps(eps), thr,
-                KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.d_queue, d_stats, KnnSchedule{}});
+                KnnOutputs{nullptr, nullptr, const_cast<float*>(d_known_d2), nullptr, nullptr, nullptr}, MultiPass{}, ix.queue_now, d_stats, KnnSchedule{}, ix.queue_clear});
     return check_hip(hipGetLastError(), "k_knn stats launch", __FILE__, __LINE__);
 }
 

@@ -4,7 +4,7 @@ usage: tools/collect_profiles.py r01"""
 import glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -68,12 +68,12 @@ pmc = os.path.join(src, "pmc", "pmc_summary.json")
 if os.path.exists(pmc):
     shutil.copyfile(pmc, os.path.join(dst, tag + "_pmc_summary.json"))
     allk = json.load(open(pmc))
-    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,false,false") or k == "k_knn"), {})
+    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,") or k == "k_knn"), {})
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"]["avg_per_dispatch"], d["WRITE_SIZE"]["avg_per_dispatch"]
         json.dump({
             "workload": "uniform_10m_k15",
-            "kernel": "k_knn<16,true,false,false> (fused kNN k=15 + PCA normals, 10 M queries per launch, persistent grid)",
+            "kernel": "k_knn<16,true,0,false,false,1> (fused kNN k=15 + PCA normals, 10 M queries per launch, persistent grid)",
             "command": "tools/pmc_passes.sh: rocprofv3 --kernel-trace --pmc <one counter group per pass> --output-format csv -- "
                        "python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 (FETCH_SIZE in pass 3, WRITE_SIZE in pass 4)",
             "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
@@ -84,10 +84,39 @@ if os.path.exists(pmc):
             "k_knn_hbm_bytes_per_launch": int((2 * f + w) * 1024),
             "k_knn_hbm_bytes_per_launch_uncorrected": int((f + w) * 1024),
             "algorithmic_bytes_per_launch": 84 * 10_000_000}, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
+if os.path.exists(pmc):
+    # what bench.py's roofline.issue is made from: instruction counts per launch by issue class, and the shader clock under this load
+    # (GRBM_GUI_ACTIVE counts every XCD's busy cycles: / 8; the launch's duration from the trace of the same command)
+    allk = json.load(open(pmc))
+    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,")), {})
+    c = lambda name: d[name]["avg_per_dispatch"] if name in d else 0.0
+    if c("SQ_INSTS"):
+        other = max(0.0, c("SQ_INSTS") - c("SQ_INSTS_VALU") - c("SQ_INSTS_SALU") - c("SQ_INSTS_SMEM") - c("SQ_INSTS_LDS") - c("SQ_INSTS_BRANCH"))
+        clock = 2.4e9
+        stats_csv = os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv")
+        if c("GRBM_GUI_ACTIVE") and os.path.exists(stats_csv):
+            import csv
+            for row in csv.DictReader(open(stats_csv)):
+                if "k_knn<16, true," in row["Name"] or "k_knn<16,true," in row["Name"].replace(" ", ""):
+                    clock = c("GRBM_GUI_ACTIVE") / 8.0 / (float(row["AverageNs"]) * 1e-9)
+                    break
+        json.dump({"workload": "uniform_10m_k15", "kernel": "k_knn<16,true,0,false,false,1>", "simds": 1024,
+                   "instructions_per_launch": c("SQ_INSTS"), "valu_instructions_per_launch": c("SQ_INSTS_VALU"),
+                   "scalar_class_instructions_per_launch": c("SQ_INSTS_SALU") + c("SQ_INSTS_SMEM") + c("SQ_INSTS_BRANCH") + other,
+                   "scalar_class": {"salu": c("SQ_INSTS_SALU"), "smem": c("SQ_INSTS_SMEM"), "branch": c("SQ_INSTS_BRANCH"),
+                                    "other (s_waitcnt, s_nop, s_setprio, vector memory)": other},
+                   "lds_instructions_per_launch": c("SQ_INSTS_LDS"),
+                   "cycles_per_scalar_instruction": 4.1, "cycles_per_valu_instruction_range": [2.4, 4.3],
+                   "issue_cost_source": "profiles/r03_valu_issue_rates.txt (tools/valu_rate.hip: s_add_u32 4.04-4.21 cycles per SIMD at 1-5 waves; v_add / v_mul / "
+                                        "v_or 2.2-2.7 at >= 2 waves, three-operand / compare / f64 / packed 4.1-4.5)",
+                   "shader_clock_hz": clock, "shader_clock_source": "GRBM_GUI_ACTIVE / 8 per launch over the launch's average duration in "
+                                                                     "profiles/%s_rocprofv3_kernel_stats.csv (2.4e9 if either is missing)" % tag,
+                   "command": "tools/pmc_passes.sh (rocprofv3 --kernel-trace --pmc, one counter group per pass) -- python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1"},
+                  open(os.path.join(dst, tag + "_issue.json"), "w"), indent=1)
 pos = os.path.join(src, "pmc_pos", "pmc_summary.json")
 if os.path.exists(pos):
     allk = json.load(open(pos))
-    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,false,false") or k == "k_knn"), {})
+    d = next((v for k, v in allk.items() if k.startswith("k_knn<16,true,") or k == "k_knn"), {})
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"]["avg_per_dispatch"], d["WRITE_SIZE"]["avg_per_dispatch"]
         json.dump({"workload": "uniform_10m_k15, rows and normals at curve positions (pcpx_knn_self_curve_order_dev)",

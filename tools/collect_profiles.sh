@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects every measurement DESIGN.md quotes, on the GPU box, into gpurun_out/<tag>/ :
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04 [part]'      part: all (default) | knn (= knn1 + knn2) | knn1 | knn2 | build | host
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r05 [part]'      part: all (default) | knn (= knn1 + knn2) | knn1 | knn2 | build | host
 #   (all of it does not fit one 20-minute call: knn1, knn2, host, build are four)
-# then, back in the container:  python3 tools/collect_profiles.py r04   (copies the summaries into profiles/)
+# then, back in the container:  python3 tools/collect_profiles.py r05   (copies the summaries into profiles/)
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 part=${2:-all}
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -17,12 +17,13 @@ echo "pmc done"
 PMC_PASSES=5 bash tools/pmc_passes.sh "$out/pmc_pos" --steps 3 --warmup 1 --rows-at-curve-positions > "$out/pmc_pos.txt" 2>&1 || { echo "pmc (curve positions) failed"; tail -5 "$out/pmc_pos.txt"; }
 # (the HBM traffic file bench.py quotes under roofline.traffic is made from these passes before the bench line is taken)
 python3 tools/collect_profiles.py "$tag" > /dev/null 2>&1
-# 2. the bench line (default workload, CPU baseline included; --with-1m adds the configs[1] side figure)
-timeout -k 10 400 python3 bench.py --with-1m > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; }
-echo "bench done"
-# 3. the default command (python3 bench.py) under rocprofv3 --kernel-trace --stats
+# 2. the default command (python3 bench.py) under rocprofv3 --kernel-trace --stats
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py > "$out/bench_under_rocprofv3.json" 2> "$out/trace.err" || { echo "trace failed"; tail -5 "$out/trace.err"; }
 echo "trace done"
+python3 tools/collect_profiles.py "$tag" > /dev/null 2>&1  # (the shader clock of the issue figure comes from this trace)
+# 3. the bench line (default workload, CPU baseline included; --with-1m adds the configs[1] side figure)
+timeout -k 10 400 python3 bench.py --with-1m > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; }
+echo "bench done"
 # 4. traversal statistics + per-phase clocks (diagnostic build of the kernel)
 timeout -k 10 200 python3 tools/knn_stats.py 1e7 uniform 15 > "$out/stats_uniform.json" 2>> "$out/stats.err" &&
 timeout -k 10 200 python3 tools/knn_stats.py 1e7 clustered 15 > "$out/stats_clustered.json" 2>> "$out/stats.err" || echo "stats failed"

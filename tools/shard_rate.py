@@ -23,7 +23,9 @@ pts = pkg.synthetic.uniform_cloud(n, 43) if kind == "uniform" else pkg.synthetic
 grid = np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32)
 d_pts = torch.from_numpy(pts).to(dev)
 cs = torch.cuda.current_stream().cuda_stream
-d_idx = torch.empty((n, k), dtype=torch.int32, device=dev)
+kcap = 8 if k <= 8 else 16 if k <= 16 else 32
+pitch = kcap if k in (kcap - 1, kcap) else 0  # (rows of 16 entries for k = 15: one aligned 64-byte piece each, bench.py: row_pitch)
+d_idx = torch.empty((n, pitch or k), dtype=torch.int32, device=dev)
 d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
 d_nrm = None if stream else torch.empty((n, 3), dtype=torch.float32, device=dev)
 res = {"kind": kind, "n": n, "k": k, "step": "rebuild + kNN rows" if stream else "kNN rows + normals",
@@ -31,22 +33,36 @@ res = {"kind": kind, "n": n, "k": k, "step": "rebuild + kNN rows" if stream else
        "projection": "one GPU running each rank's share in turn; not a measurement on N GPUs"}
 reps = 5 if n > 20_000_000 else 20
 
+by_work = not stream and "count" not in sys.argv[1:]  # static index: shards of equal estimated work (pcpx_shard_cuts_by_cost)
+res["cut"] = "equal estimated work" if by_work else "equal query counts"
+events = None
+if by_work:
+    whole = pkg.Index.from_device(d_pts.data_ptr(), n, device=0, stream=cs, voxel_grid=grid)
+    events = whole.knn_group_costs(k, 1e-5, 16)
+    whole.close()
 for world in (1, 2, 4, 8):
-    per_rank, trees, build_ms = [], [], []
+    per_rank, trees, build_ms, firsts = [], [], [], []
+    cuts = pkg.shard_cuts_by_cost(n, world, 16, events) if by_work else [pkg.shard_range(n, r, world)[0] for r in range(world)] + [n]
     for rank in range(world):
         local = world > 1 and not replicated
-        kw = dict(voxel_grid=grid, shard=(rank, world) if local else None, k_hint=k, borrow=local,
-                  coarse_order=stream and not local)
+        first, count = cuts[rank], cuts[rank + 1] - cuts[rank]
+        kw = dict(voxel_grid=grid, shard=(rank, world) if local else None, k_hint=k, borrow=local)
+        if local and by_work:
+            kw["shard_range"] = (first, count)
         ix = pkg.Index.from_device(d_pts.data_ptr(), n, device=0, stream=cs, **kw)
-        first, count = pkg.shard_range(n, rank, world)
 
         def step():
             if stream:
                 ix.rebuild_dev(d_pts.data_ptr(), n, **kw)
-                ix.knn_self_dev(k, 1e-5, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
+                ix.knn_self_strided_dev(k, 1e-5, pitch, d_idx.data_ptr(), d_cnt.data_ptr(), None, first, count)
             else:
-                ix.normals_knn_self_dev(k, 1e-5, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
+                ix.normals_knn_self_strided_dev(k, 1e-5, pitch, d_nrm.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(), first, count)
 
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        firsts.append((time.perf_counter() - t0) * 1e3)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -64,6 +80,7 @@ for world in (1, 2, 4, 8):
             trees.append(ix.shard_info()["local_points"])
         ix.close()
     r = {"queries_per_rank": n // world, "ms_slowest_rank": round(max(per_rank), 4), "ms_mean_rank": round(sum(per_rank) / world, 4),
+         "ms_first_step_slowest_rank (coverage check + recording)": round(max(firsts), 4),
          "index_build_ms_slowest": round(max(build_ms), 4), "index_build_ms_mean": round(sum(build_ms) / world, 4)}
     if trees:
         r["local_tree_points_max"] = max(trees)

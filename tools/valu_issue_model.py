@@ -33,7 +33,7 @@ groups = bench["config"]["queries"] / 64
 clock_hz, simds = 2.4e9, 1024
 available = bench["roofline"]["avg_launch_ms"] * 1e-3 * clock_hz * simds / groups
 total = sum(parts.values())
-out = {"kernel": "k_knn<16,true,false,false,false,1>", "workload": bench["config"]["workload"],
+out = {"kernel": "k_knn<16,true,0,false,false,1>", "workload": bench["config"]["workload"],
        "valu_issue_cycles_per_group": {k: round(v) for k, v in parts.items()}, "valu_issue_cycles_per_group_total": round(total),
        "simd_cycles_available_per_group": round(available), "valu_issue_frac": round(total / available, 3),
        "note": "issue costs were measured on streams of one instruction each; a value near 1 says the pipe is saturated, not that the model is exact",
@@ -41,7 +41,7 @@ out = {"kernel": "k_knn<16,true,false,false,false,1>", "workload": bench["config
                        "issue_cost_cycles": {"simple_vop2": SIMPLE, "three_operand": THREE_OP, "compare": CMP, "f64_min_max": F64, "scalar": SCALAR}}}
 try:
     pmc = json.load(open(P("pmc_summary.json")))
-    k = next(v for name, v in pmc.items() if name.startswith("k_knn<16,true,false,false"))
+    k = next(v for name, v in pmc.items() if name.startswith("k_knn<16,true,"))
     c = lambda n: k[n]["avg_per_dispatch"] if n in k else 0.0
     other = max(0.0, c("SQ_INSTS") - c("SQ_INSTS_VALU") - c("SQ_INSTS_SALU") - c("SQ_INSTS_SMEM") - c("SQ_INSTS_LDS") - c("SQ_INSTS_BRANCH")) if c("SQ_INSTS") else 0.0
     scalar = c("SQ_INSTS_SALU") + c("SQ_INSTS_SMEM") + c("SQ_INSTS_BRANCH") + other
