@@ -96,7 +96,9 @@ class device_array_t
 struct device_rows_t
 {
     std::uint32_t k = 0;
-    device_array_t<std::uint32_t> idx;    // rows x k
+    std::uint32_t pitch = 0;              // entries between rows of idx: k rounded up to 8 / 16 / 32 when that is k or k + 1 (a row is then
+                                          // one aligned piece written with 16-byte stores: pcpx_knn_self_strided_dev), else k
+    device_array_t<std::uint32_t> idx;    // rows x pitch; row i = idx[i * pitch .. i * pitch + count[i])
     device_array_t<std::uint32_t> count;  // rows
     device_array_t<float> normals;        // rows x 3 (empty unless normals were requested)
 };
@@ -165,15 +167,18 @@ class device_index_t
     device_rows_t knn_self_device(std::uint32_t k, float eps, std::uint64_t rows, bool with_normals, int device = 0) const
     {
         device_rows_t r;
-        r.k     = k;
-        r.idx   = device_array_t<std::uint32_t>(static_cast<std::size_t>(rows) * k, device);
+        r.k = k;
+        std::uint32_t const cap = k <= 8u ? 8u : k <= 16u ? 16u : 32u;
+        r.pitch = (k <= 32u && k + 1u >= cap) ? cap : k;
+        r.idx   = device_array_t<std::uint32_t>(static_cast<std::size_t>(rows) * r.pitch, device);
         r.count = device_array_t<std::uint32_t>(static_cast<std::size_t>(rows), device);
+        std::uint32_t const stride = r.pitch == k ? 0u : r.pitch;
         if (with_normals)
         {
             r.normals = device_array_t<float>(static_cast<std::size_t>(rows) * 3, device);
-            check(pcpx_normals_knn_self_dev(h_, k, eps, 0, UINT64_MAX, r.normals.data(), r.idx.data(), r.count.data()), "pcpx_normals_knn_self_dev");
+            check(pcpx_normals_knn_self_strided_dev(h_, k, eps, 0, UINT64_MAX, stride, r.normals.data(), r.idx.data(), r.count.data()), "pcpx_normals_knn_self_strided_dev");
         }
-        else check(pcpx_knn_self_dev(h_, k, eps, 0, UINT64_MAX, r.idx.data(), r.count.data(), nullptr), "pcpx_knn_self_dev");
+        else check(pcpx_knn_self_strided_dev(h_, k, eps, 0, UINT64_MAX, stride, r.idx.data(), r.count.data(), nullptr), "pcpx_knn_self_strided_dev");
         check(pcpx_index_synchronize(h_), "pcpx_index_synchronize");
         return r;
     }

@@ -108,9 +108,30 @@ using coord_buffer_t = std::vector<float, default_init_allocator<float>>;
 // ranges shorter than this are walked on the calling thread
 constexpr std::size_t parallel_capture_threshold = 32768;
 
+// THREAD SAFETY OF THE PROPERTY MAP.  The reference's constructors walk the range on the calling thread
+// (include/pcp/octree/linked_octree.hpp:103-121); here a range of parallel_capture_threshold elements or more is walked by several
+// threads, each on a contiguous piece, so the CoordinateMap / PointViewMap and the element's copy constructor are called
+// CONCURRENTLY for different elements.  A pure map (the usual lambda returning the element's coordinates) is fine; a map that
+// caches, counts or logs through unsynchronised shared state is not.  Opt out: define PCP_CAPTURE_THREADS to 1 before including
+// the headers, or set the environment variable PCPX_CAPTURE_THREADS=1 (any positive number caps the thread count).
+#ifndef PCP_CAPTURE_THREADS
+#define PCP_CAPTURE_THREADS 0  // 0: by range size and std::thread::hardware_concurrency()
+#endif
+inline unsigned capture_thread_limit()
+{
+    static unsigned const limit = [] {
+        if (PCP_CAPTURE_THREADS > 0) return static_cast<unsigned>(PCP_CAPTURE_THREADS);
+        char const* e = std::getenv("PCPX_CAPTURE_THREADS");
+        long const v = e ? std::strtol(e, nullptr, 10) : 0;
+        return v > 0 ? static_cast<unsigned>(v) : 0u;
+    }();
+    return limit;
+}
+
 inline unsigned capture_threads(std::size_t n)
 {
     unsigned hw = std::thread::hardware_concurrency();
+    if (capture_thread_limit() != 0 && (hw == 0 || hw > capture_thread_limit())) hw = capture_thread_limit();
     if (hw == 0) hw = 1;
     if (hw > 32) hw = 32;
     std::size_t const by_size = n / (parallel_capture_threshold / 2);

@@ -85,7 +85,8 @@ typedef struct pcpx_index pcpx_index; /* opaque: device buffers + stream */
                               return exactly what the whole-cloud index returns: every query's k-th distance is checked      \
                               against the cells the handle holds, and a query whose search ball leaves them is answered      \
                               again after the handle has taken the missing cells in (it keeps them: a static index pays     \
-                              once).  Because of that check these calls synchronise the stream before they return.          \
+                              once).  Because of that check these calls synchronise the stream before they return -- except  \
+                              when the same question (k, eps, slice) was checked on this tree before: then they only enqueue.\
                               pcpx_index_size / _bbox describe the whole cloud.  Entry points that need the whole cloud      \
                               indexed (arbitrary query batches, range lists, host-pointer forms) fail with                   \
                               PCPX_ERR_UNSUPPORTED on such a handle.  No collective is involved: ranks agree on the grid     \
@@ -329,7 +330,9 @@ int pcpx_device_upload(void* d_dst, const void* src, uint64_t bytes, int device,
 int pcpx_device_download(void* dst, const void* d_src, uint64_t bytes, int device, void* stream); /* synchronous */
 /* Destroying an index keeps its device blocks for the next index of the same device (a drop-in caller constructs containers in a
  * loop, benchmark/spatial_data_structures_benchmark.cpp:108-148, and hipMalloc / hipFree cost more than a small build): at most
- * PCPX_DEVICE_CACHE_MB (environment; default 2048, 0 = keep nothing) of idle blocks per device.  This gives them all back. */
+ * PCPX_DEVICE_CACHE_MB (environment; default 2048, 0 = keep nothing) of idle blocks per device, and beyond 256 MB never more
+ * than a quarter of the device memory that is free at that moment.  A process that shares the GPU with another allocator (PyTorch
+ * ...) calls this after it has destroyed its indexes: it gives the idle blocks back. */
 int pcpx_device_trim(int device);
 
 /* ---- multi-GPU: one process per GPU ------------------------------------------------------------ */

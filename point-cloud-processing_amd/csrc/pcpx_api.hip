@@ -193,7 +193,15 @@ void index_block_free(void* p)
     size_t idle_here = 0;
     for (auto const& b : c.idle)
         if (b.device == dev) idle_here += b.bytes;
-    if (idle_here + bytes <= c.cap_bytes()) c.idle.push_back(IndexBlocks::Idle{p, bytes, dev});
+    bool keep = idle_here + bytes <= c.cap_bytes();
+    if (keep && idle_here + bytes > (size_t(256) << 20)) {
+        // beyond a quarter of a gigabyte the cache also yields to whoever else lives on the device (a co-resident framework sees idle
+        // blocks as used memory): never more than a quarter of what is free now
+        size_t free_now = 0, total = 0;
+        if (hipMemGetInfo(&free_now, &total) == hipSuccess) keep = idle_here + bytes <= free_now / 4;
+        else (void)hipGetLastError();
+    }
+    if (keep) c.idle.push_back(IndexBlocks::Idle{p, bytes, dev});
     else (void)hipFree(p);
 }
 

@@ -723,6 +723,10 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     float lo_d2 = -1.f;    // wave-uniform; later rounds accept only d2 > lo_d2
     constexpr bool fast = PCPX_ASM_ACCEPT && !MULTI;  // keeps only the write address `wa`; the other accept paths only `cnt`
 
+    // (diagnostic build: the dense forms count a key where it is accepted, the packed form where it is folded -- fold() then counts EVERY
+    //  key of the column, so with packed leaves in the kernel the dense forms' own counts are left out: `count_at_accept`)
+    constexpr bool packed_keys_counted_at_folds = STATS && pack_rows(MULTI, KCAP) > 0 && PCPX_ASM_ACCEPT && !MULTI && !EPS_EACH;
+    constexpr bool count_at_accept = STATS && !packed_keys_counted_at_folds;
     // fold the buffered keys into the best-list (one copy of the selection network per call site)
     // `later`: the group is in a walk round after its first.  Such a group is a LONG one -- a few of its lanes sit in a sparse place and go
     // round again with 4x the radius^2, up to a dozen times, while the rest of the launch moves on: on the clustered cloud the longest
@@ -732,6 +736,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     auto fold = [&](bool in_seed_phase, bool later = false) {
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
         if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
+        if (STATS && packed_keys_counted_at_folds) st_app += static_cast<u32>(cnt);  // (the packed leaves' keys: see the leaf loop)
         if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE && !later) __builtin_amdgcn_s_setprio(PCPX_PRIO_FOLD);
         if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF, NZ>(best, col, cnt, eps_filter);
         else compact<KCAP, BUF>(best, col, cnt);
@@ -781,7 +786,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             for (int j = 0; j < LEAF; ++j) {
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
-                if (STATS) st_app += (d2 <= tau) ? 1u : 0u;
+                if (count_at_accept) st_app += (d2 <= tau) ? 1u : 0u;
                 append_if_within(d2, tau, posv, wa, saved);  // NaN padding points fail d2 <= tau
             }
         } else if (fast && eps_filter.on) {
@@ -791,7 +796,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             for (int j = 0; j < LEAF; ++j) {
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
-                if (STATS) st_app += (d2 <= tau && d2 > lo_d2) ? 1u : 0u;
+                if (count_at_accept) st_app += (d2 <= tau && d2 > lo_d2) ? 1u : 0u;
                 append_if_within_shell(d2, tau, lo_d2, posv, wa, saved);
             }
         } else if (fast && !shell) {
@@ -801,7 +806,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             for (int j = 0; j < LEAF; ++j) {
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
-                if (STATS) st_app += (d2 <= tau && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
+                if (count_at_accept) st_app += (d2 <= tau && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
                 append_if(d2, tau, dx, dy, dz, eps, posv, wa, saved);  // NaN padding points fail d2 <= tau
             }
         } else if (fast) {  // later rounds: only the shell (lo_d2, tau]
@@ -811,7 +816,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             for (int j = 0; j < LEAF; ++j) {
                 float dx = lf.x[j] - qx, dy = lf.y[j] - qy, dz = lf.z[j] - qz;
                 float d2 = sq3(dx, dy, dz);
-                if (STATS) st_app += (d2 <= tau && d2 > lo_d2 && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
+                if (count_at_accept) st_app += (d2 <= tau && d2 > lo_d2 && fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= eps) ? 1u : 0u;
                 append_if_shell(d2, tau, lo_d2, dx, dy, dz, eps, posv, wa, saved);
             }
         } else {
@@ -827,7 +832,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                 int slot = acc ? cnt : BUF;
                 col[slot * 64] = key;
                 cnt += acc ? 1 : 0;
-                if (STATS) st_app += acc ? 1u : 0u;
+                if (count_at_accept) st_app += acc ? 1u : 0u;
             }
         }
         if (PCPX_PRIO_DENSE != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
@@ -1029,7 +1034,10 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                         }
                         if (packed_form) {
                             if (COST) ++st_sparse;
-                            if (STATS) ++st_leaves, ++st_sparse, st_owners += how_many, st_app += (wa - wa_was) >> 9;  // ([14], [15]: the packed leaves and their needing lanes)
+                            // ([14], [15]: the packed leaves and their needing lanes.  The keys they took are counted where they are folded:
+                            //  a column's address goes back to its first row at every fold, so "address now - address before" is not a count -- round 4's
+                            //  `appended` figure was that difference and came out as 1.7e14)
+                            if (STATS) ++st_leaves, ++st_sparse, st_owners += how_many;
                         } else {
                             candidates(loc, rounds != 0u);
                         }

@@ -357,7 +357,8 @@ static void device_resident_scenarios()
     pcp::gpu::device_rows_t const dev = ix.knn_self_device(k, 1e-5f, cloud.size(), /*with_normals*/ true);
     auto const host_rows = ix.knn_self(k, 1e-5f, cloud.size());
     auto const host_nrm  = ix.normals_self(k, 1e-5f, cloud.size());
-    REQUIRE(dev.idx.size() == cloud.size() * k && dev.normals.size() == cloud.size() * 3);
+    REQUIRE(dev.pitch == 16u);  // (k = 15: rows of 16 entries, one aligned 64-byte piece each)
+    REQUIRE(dev.idx.size() == cloud.size() * dev.pitch && dev.normals.size() == cloud.size() * 3);
     auto const idx = dev.idx.download();
     auto const cnt = dev.count.download(100, 50);
     auto const nrm = dev.normals.download(3 * 777, 3);
@@ -365,7 +366,7 @@ static void device_resident_scenarios()
     REQUIRE(host_rows.position_of.size() == cloud.size());
     bool same_rows = true;
     for (std::size_t i = 0; i < cloud.size(); ++i)
-        same_rows = same_rows && std::equal(idx.begin() + static_cast<std::ptrdiff_t>(i * k), idx.begin() + static_cast<std::ptrdiff_t>((i + 1) * k), host_rows.row(i));
+        same_rows = same_rows && std::equal(idx.begin() + static_cast<std::ptrdiff_t>(i * dev.pitch), idx.begin() + static_cast<std::ptrdiff_t>(i * dev.pitch + k), host_rows.row(i));
     REQUIRE(same_rows);
     for (std::size_t i = 0; i < cnt.size(); ++i) REQUIRE(cnt[i] == host_rows.size_of_row(100 + i));
     REQUIRE(nrm[0] == host_nrm[3 * 777] && nrm[1] == host_nrm[3 * 777 + 1] && nrm[2] == host_nrm[3 * 777 + 2]);

@@ -55,7 +55,7 @@ def _curve_order(pts, grid):
     return np.argsort(words, kind="stable"), words
 
 
-def _worker(rank, world, port, n, k, out_dir):
+def _worker(rank, world, port, n, k, out_dir, by_work=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -68,7 +68,21 @@ def _worker(rank, world, port, n, k, out_dir):
     local = torch.from_numpy(O.bbox(pts[lo:hi]))
     grid = mg.global_grid(local, dist, world).numpy()
     order, _ = _curve_order(pts, grid)
-    first, count = mg.query_shard(n, rank, world)
+    if by_work:
+        # shards of equal estimated WORK (pcpx_shard_cuts_by_cost).  On the GPU the table is pcpx_knn_group_costs_dev's event counts;
+        # here every rank derives a table from its replica of the cloud by the same deterministic rule (the spatial extent of every
+        # fourth query group of the curve order, as integers) -- the protocol is what is tested: same table on every rank without any
+        # exchange, hence the same cuts, hence disjoint shards that cover the cloud
+        stride, groups = 4, (n + 63) // 64
+        ev = np.zeros((groups // stride, 4), np.uint32)
+        for i in range(len(ev)):
+            g = i * stride + stride // 2
+            p = pts[order[64 * g:64 * g + 64]]
+            ev[i, 0] = int(np.float64(p.max(0) - p.min(0)).sum() * 1e4)
+        cuts = pkg.shard_cuts_by_cost(n, world, stride, ev)
+        first, count = cuts[rank], cuts[rank + 1] - cuts[rank]
+    else:
+        first, count = mg.query_shard(n, rank, world)
     assert first % 64 == 0
     rows = order[first:first + count]
     idx, cnt = O.knn_bruteforce(pts, pts[rows], k)
@@ -77,9 +91,10 @@ def _worker(rank, world, port, n, k, out_dir):
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo(tmp_path, oracle, pkg):
+@pytest.mark.parametrize("by_work", [False, True])
+def test_world_size_2_gloo(tmp_path, oracle, pkg, by_work):
     n, k, world = 3000, 15, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path), by_work), nprocs=world, join=True)
     r = [np.load(tmp_path / ("rank%d.npz" % i)) for i in range(world)]
     pts = pkg.synthetic.clustered_cloud(n, seed=44)
     assert np.array_equal(r[0]["grid"], r[1]["grid"])
