@@ -1017,7 +1017,6 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                         // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
                         // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
                         const bool packed_form = how_many <= packed_limit;
-                        const u32 wa_was = wa;
                         u64 todo = who;  // (the lanes the leaf is still to be looked at for)
                         for (bool again = false;; again = true) {  // (one call site of the fold: one copy of the selection network)
                             if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false, rounds != 0u);
