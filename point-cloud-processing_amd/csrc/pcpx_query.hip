@@ -176,12 +176,6 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_PRIO_PACKED
 #define PCPX_PRIO_PACKED 2  // the packed leaf (three dependent LDS round trips on top of its loads) one step above the rest: +0.8 % (five rounds)
 #endif
-#ifndef PCPX_PRIO_LATER
-#define PCPX_PRIO_LATER 3  // a group from its second walk round on (see knn_group: fold)
-#endif
-#ifndef PCPX_SHELL_PACKED
-#define PCPX_SHELL_PACKED 1  // the packed leaf form in the later walk rounds too (few lanes are still searching there)
-#endif
 #ifndef PCPX_PRIO_WALK
 #define PCPX_PRIO_WALK PCPX_PRIO_BASE
 #endif
@@ -728,19 +722,14 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     constexpr bool packed_keys_counted_at_folds = STATS && pack_rows(MULTI, KCAP) > 0 && PCPX_ASM_ACCEPT && !MULTI && !EPS_EACH;
     constexpr bool count_at_accept = STATS && !packed_keys_counted_at_folds;
     // fold the buffered keys into the best-list (one copy of the selection network per call site)
-    // `later`: the group is in a walk round after its first.  Such a group is a LONG one -- a few of its lanes sit in a sparse place and go
-    // round again with 4x the radius^2, up to a dozen times, while the rest of the launch moves on: on the clustered cloud the longest
-    // group takes 6x the mean, 0.9 ms of one wave's dependent instructions under the contention of the six other waves of its SIMD,
-    // and a short launch (one rank's eighth: 0.65 ms) cannot end before it does.  From its second round on a group therefore runs at
-    // PCPX_PRIO_LATER, above everything else on its SIMD, and its folds are not lowered: the chain then moves at a lone wave's pace.
-    auto fold = [&](bool in_seed_phase, bool later = false) {
+    auto fold = [&](bool in_seed_phase) {
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
         if (fast) cnt = static_cast<int>((wa - col_addr) >> 9);
         if (STATS && packed_keys_counted_at_folds) st_app += static_cast<u32>(cnt);  // (the packed leaves' keys: see the leaf loop)
-        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE && !later) __builtin_amdgcn_s_setprio(PCPX_PRIO_FOLD);
+        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_FOLD);
         if (PCPX_COMPACT_BY8 && (KCAP <= 16 || (PCPX_BY8_K32 && !MULTI))) compact_by8<KCAP, BUF, NZ>(best, col, cnt, eps_filter);
         else compact<KCAP, BUF>(best, col, cnt);
-        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE && !later) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
+        if (PCPX_PRIO_FOLD != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         float nt = __uint_as_float(static_cast<u32>(best[KCAP - 1] >> 32));
         tau = active ? fminf(nt, cap) : -1.f;
         if (STATS) tau = fminf(tau, tau_known);
@@ -755,9 +744,9 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         }
     };
     // before a leaf: fold if some lane could not take LEAF more keys; at the end of a phase: if any lane holds a key
-    auto fold_if_needed = [&](bool before_leaf, bool in_seed_phase, bool later = false) {
+    auto fold_if_needed = [&](bool before_leaf, bool in_seed_phase) {
         if (!fast) wa = col_addr + (static_cast<u32>(cnt) << 9);
-        if (any_lane(wa >= (before_leaf ? wa_full : lds_row0 + 512u))) fold(in_seed_phase, later);
+        if (any_lane(wa >= (before_leaf ? wa_full : lds_row0 + 512u))) fold(in_seed_phase);
     };
 
     // candidates of one leaf: SMEM broadcast, branch-free accept; `shell`: a later walk round
@@ -904,13 +893,10 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     // the publish row instead; the needing lane sees from the address it reads back that keys were lost, takes its column back
     // to where it was before the leaf (the rows written since hold PAD_KEY again), and the leaf is looked at once more for
     // those lanes after a fold.  Returns the lanes that want that (0: done).
-    // SHELL (a tag): a later walk round -- only the new shell lo_d2 < d2 is accepted, and the wave keeps its raised priority.
-    // (one copy for both: a second inlined copy for the later rounds cost the k <= 16 kernel 20 B of scratch.  lo_d2 = -1 in the first
-    //  round, so its test passes there; the two priority steps are jumped over in the later rounds: two scalar instructions each)
-    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many, const bool shell) -> u64 {
+    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) -> u64 {
         float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
         u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
-        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE && !shell) __builtin_amdgcn_s_setprio(PCPX_PRIO_PACKED);
+        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_PACKED);
         u32 lane_here = lane;
         asm volatile("" : "+v"(lane_here));  // (or everything below that depends on the lane alone sits in registers from group to group)
         const u32 j = lane_here & 7u, i = lane_here >> 3;
@@ -928,7 +914,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             const float4 q = pub_q[s + i];
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
             const float d2 = sq3(dx, dy, dz);
-            if (d2 <= q.w && d2 > lo_d2) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
+            if (d2 <= q.w) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
                 u32 one_row = 512u;
                 asm volatile("" : "+v"(one_row));  // (a v_mov here, not a register held from group to group)
                 u32 at = atomicAdd(pub_wa + s + i, one_row);
@@ -943,7 +929,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             reinterpret_cast<float*>(pub_q + r)[3] = -1.f;
         }
         __builtin_amdgcn_wave_barrier();
-        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE && !shell) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
+        if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
         if (packed_free == 0) {
             wa = now;
             return 0ull;
@@ -1001,7 +987,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                 if (loc - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
                     if (!packed_leaves) {
-                        fold_if_needed(true, false, rounds != 0u);
+                        fold_if_needed(true, false);
                         candidates(loc, rounds != 0u);
                     } else {
                         const u32 c = loc & (W - 1u);
@@ -1019,10 +1005,10 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                         const bool packed_form = how_many <= packed_limit;
                         u64 todo = who;  // (the lanes the leaf is still to be looked at for)
                         for (bool again = false;; again = true) {  // (one call site of the fold: one copy of the selection network)
-                            if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false, rounds != 0u);
+                            if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false);
                             if (!packed_form) break;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            todo = packed_leaf(loc, todo, how_many, rounds != 0u);
+                            todo = packed_leaf(loc, todo, how_many);
                             if (COST) st_steps += (how_many + 7u) >> 3;
                             if (STATS) {
                                 asm volatile("" ::"v"(wa));
@@ -1046,7 +1032,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             }
         }
         if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
-        fold_if_needed(false, false, rounds != 0u);
+        fold_if_needed(false, false);
         if (!(cap < inf)) break;
         // a capped round ended: lanes whose k-th distance is within the cap are exact; the others go round again with 4x the
         // radius^2, accepting only the new shell (lo_d2, cap]
@@ -1068,8 +1054,9 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         // after 12 rounds
         const float grown = cap * PCPX_CAP_GROW;
         ++rounds;
-        if (!PCPX_SHELL_PACKED) packed_limit = 0;  // (the later rounds want lo_d2 < d2 as well: packed_leaf tests it)
-        if (PCPX_PRIO_LATER != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_LATER);
+        packed_limit = 0;  // (the later rounds want lo_d2 < d2 as well: lane-per-query leaves.  Measured, round 5: the packed form there with a shell
+                           //  test, and a raised priority for a group from its second round on -- neither moved the longest groups nor the rate:
+                           //  what makes a group long is not a straggler's later rounds, see k_make_order)
         cap = (grown > cap && grown < diag2 * 4.f && rounds < 12u) ? grown : inf;
         active = failed;
         tau = active ? fminf(kth, cap) : -1.f;
