@@ -28,7 +28,8 @@ for name, out in (("stats_uniform.json", "knn_phase_stats_uniform.json"), ("stat
                   ("pmc_range_pos/range_under_prof.json", "range_count_10m_curve_positions.json"),
                   ("valu_issue_rates.txt", "valu_issue_rates.txt"), ("pmc_latency/latency_kernel_stats.txt", "latency_kernel_stats.txt"),
                   ("pmc_latency/latency_under_prof.json", "latency_under_rocprofv3.json"), ("filter_bench.json", "filter_bench.json"),
-                  ("fuzz_filters.json", "fuzz_filters.json")):
+                  ("fuzz_filters.json", "fuzz_filters.json"), ("range_lists.json", "range_lists_10m.json"),
+                  ("sizes.json", "knn_rate_by_cloud_size.json"), ("outliers_clustered.json", "longest_groups_clustered.json")):
     if os.path.exists(os.path.join(src, name)):
         cp(name, out)
 # (bench.py starts one child process for the host-pointer ABI side measurement; rocprofv3 writes a file per process: the

@@ -39,6 +39,10 @@ timeout -k 10 300 python3 tools/shard_rate.py > "$out/shard_rate.json" 2>> "$out
 timeout -k 10 300 python3 tools/shard_rate.py clustered 1e7 15 > "$out/shard_rate_clustered.json" 2>> "$out/bench.err" || echo "shard clustered failed"
 timeout -k 10 400 python3 tools/shard_rate.py uniform 5e7 32 stream > "$out/shard_rate_c5.json" 2>> "$out/bench.err" || echo "shard c5 failed"
 timeout -k 10 300 python3 tools/batch_query_rate.py > "$out/batch_query_rate.json" 2>> "$out/bench.err" || echo "batch failed"
+# round 5: lists of every point's range (counts + scan + fill) and 1 M boxes; the step at several cloud sizes; the longest query groups
+timeout -k 10 300 python3 tools/range_lists_rate.py > "$out/range_lists.json" 2>> "$out/bench.err" || echo "range lists failed"
+timeout -k 10 300 python3 tools/ab_sizes.py 15 > "$out/sizes.json" 2>> "$out/bench.err" || echo "sizes failed"
+timeout -k 10 300 python3 tools/outliers.py clustered 1e7 15 > "$out/outliers_clustered.json" 2>> "$out/bench.err" || echo "outliers failed"
 # configs[2]'s kernel: per-kernel time and counters
 bash tools/pmc_range.sh "$out/pmc_range" > "$out/pmc_range.txt" 2>&1 || echo "pmc range failed"
 RANGE_FORM=curve bash tools/pmc_range.sh "$out/pmc_range_pos" > "$out/pmc_range_pos.txt" 2>&1 || echo "pmc range (curve positions) failed"
