@@ -410,7 +410,8 @@ int pcpx_debug_eps_test_mode(pcpx_index* idx, int mode);
 /* Switches of the handle that change how work is done, never what comes out (the tests run both sides of each):
  * "long_groups_first" (default 1): a self-kNN launch that repeats the previous one's question on the same tree hands its query
  * groups out by the times that launch recorded, the longest first; "gather_outputs" (default 0: measured slower): input-order
- * normals and counts are written at curve positions and permuted by a gather instead of being scattered from the search kernel. */
+ * normals and counts are written at curve positions and permuted by a gather instead of being scattered from the search kernel;
+ * "gather_counts" (default 0: measured slower as well): the same for pcpx_range_count_self_dev's counts. */
 int pcpx_debug_set(pcpx_index* idx, const char* name, int64_t value);
 /* What the handle's last recorded self-kNN launch took per query group (shader-clock ticks / 64, search only; host array of
  * *out_groups entries, the launch's groups in curve order; 0 groups: nothing recorded).  PCPX_ERR_CAPACITY reports the size. */

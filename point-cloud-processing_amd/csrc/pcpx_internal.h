@@ -256,6 +256,9 @@ struct Index {
     bool pos_of_valid = false;
     struct Tuning {
         int lpt = 1;              // long groups first on repeated self-kNN launches
+        int gather_counts = 0;    // input-order radius counts through the gather-form permute: measured SLOWER too (10 M counts: 1.92-2.08 ms straight,
+                                  // 2.13 through the permute -- the kernel at curve positions takes 1.89 and the gather 0.24: ten million random 4-byte
+                                  // reads are ten million cache lines); a switch, like `gather`
         int gather = 0;           // input-order normals + counts through the gather-form permute (measured round 5: 1-3 % SLOWER than the
                                   // direct scattered stores on the 10 M clouds -- the search kernel is not bound by them; kept as a switch)
     } tuning;
@@ -406,6 +409,7 @@ int launch_knn(Index& ix, const QueryView& qv, bool self, u64 group_first, u64 g
                const KnnOutputs& o);
 // event counts of sampled groups (every `stride`-th group of the curve order, from group stride / 2 on): d_events = 4 words per sample
 int launch_knn_cost_sample(Index& ix, u32 k, float eps, u32 stride, u32* d_events, u32* out_samples);
+int launch_gather_u32(Index& ix, const u32* d_at_position, const u32* d_pos_of, u64 n_rows, u32 pos_lo, u32 pos_hi, u32* d_out);
 int launch_gather_nc4(Index& ix, const float4* d_nc4, const u32* d_pos_of, u64 n_rows, u32 pos_lo, u32 pos_hi, float* d_normals, u32* d_cnt);
 // (q_host: the queries where the host can read them, or nullptr -- a single query is then passed in the kernel arguments)
 int launch_knn_few(Index& ix, const float* q_aos, const float* q_host, u32 nq, u32 k, float eps, u32* out_idx, u32* out_cnt, float* out_d2,

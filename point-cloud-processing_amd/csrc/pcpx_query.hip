@@ -1867,6 +1867,20 @@ __global__ __launch_bounds__(256) void k_gather_nc4(const float4* __restrict__ n
     normals[3ull * i + 2] = v.z;
     if (cnt) cnt[i] = __float_as_uint(v.w);
 }
+__global__ __launch_bounds__(256) void k_gather_u32(const u32* __restrict__ at_position, const u32* __restrict__ pos_of, u32 n_rows, u32 pos_lo, u32 pos_hi,
+                                                     u32* __restrict__ out)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const u32 p = pos_of[i];
+    if (p - pos_lo < pos_hi - pos_lo) out[i] = at_position[p];  // (0xFFFFFFFF: not indexed)
+}
+int launch_gather_u32(Index& ix, const u32* d_at_position, const u32* d_pos_of, u64 n_rows, u32 pos_lo, u32 pos_hi, u32* d_out)
+{
+    if (n_rows == 0) return PCPX_OK;
+    k_gather_u32<<<static_cast<u32>((n_rows + 255) / 256), 256, 0, ix.stream>>>(d_at_position, d_pos_of, static_cast<u32>(n_rows), pos_lo, pos_hi, d_out);
+    return check_hip(hipGetLastError(), "k_gather_u32 launch", __FILE__, __LINE__);
+}
 int launch_gather_nc4(Index& ix, const float4* d_nc4, const u32* d_pos_of, u64 n_rows, u32 pos_lo, u32 pos_hi, float* d_normals, u32* d_cnt)
 {
     if (n_rows == 0) return PCPX_OK;

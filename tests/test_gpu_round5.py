@@ -248,10 +248,21 @@ def test_device_resident_range_lists_of_every_point(pkg, oracle, kind, n, radius
     assert off_h[0] == 0 and off_h[-1] == total and (counts[~inside] == 0).all() and (counts[inside] >= 1).all()
     want = oracle.range_count_bruteforce(pts[inside], pts[inside], radius, nthreads=16)
     assert np.array_equal(counts[inside], want)
-    cnt_dev = torch.zeros(m, dtype=torch.int32, device=dev)
-    ix.range_count_self_dev(radius, cnt_dev.data_ptr())
-    ix.synchronize()
-    assert np.array_equal(cnt_dev.cpu().numpy()[inside], want)
+    for gather in (1, 0):  # input-order counts through the gather-form permute and straight from the kernel; a slice as well
+        ix.debug_set("gather_counts", gather)
+        cnt_dev = torch.full((m,), -7, dtype=torch.int32, device=dev)
+        ix.range_count_self_dev(radius, cnt_dev.data_ptr())
+        ix.synchronize()
+        got = cnt_dev.cpu().numpy()
+        assert np.array_equal(got[inside], want) and (got[~inside] == -7).all()
+        part = torch.full((m,), -7, dtype=torch.int32, device=dev)
+        first, count = (ix.size() // 4) // 64 * 64, ix.size() // 3
+        ix.range_count_self_dev(radius, part.data_ptr(), first, count)
+        ix.synchronize()
+        part = part.cpu().numpy()
+        answered = part != -7
+        assert count <= answered.sum() < count + 64 and np.array_equal(part[answered], got[answered])
+    ix.debug_set("gather_counts", 1)
     # members: every listed point is within the radius of its centre (float arithmetic of the reference), no duplicates
     sel = rng.choice(np.nonzero(inside)[0], 2000, replace=False)
     for i in sel:
