@@ -240,6 +240,20 @@ __device__ __forceinline__ float leaf_max(float v)
     return v;
 }
 
+// ... and over the UNIT_POINTS lanes of a unit (two leaves: one more step, the other half of the row of sixteen)
+__device__ __forceinline__ float unit_min(float v)
+{
+    v = leaf_min(v);
+    if (UNIT_LEAVES == 2) v = fminf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x128, 0xF, 0xF, true)));  // row_ror:8
+    return v;
+}
+__device__ __forceinline__ float unit_max(float v)
+{
+    v = leaf_max(v);
+    if (UNIT_LEAVES == 2) v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x128, 0xF, 0xF, true)));
+    return v;
+}
+
 // node i of a level = union of its 4 children (padding children are skipped; no real child: a padding node)
 __device__ __forceinline__ NodeBox union_of_children(const NodeBox* __restrict__ child4)
 {
@@ -294,6 +308,8 @@ constexpr int FILL_BLOCK = 256;
 constexpr int FILL_PER_THREAD = PCPX_FILL_PER_THREAD;
 constexpr int FILL_SLOTS = FILL_BLOCK * FILL_PER_THREAD;  // 1024
 constexpr int FILL_LEAVES = FILL_SLOTS / LEAF;            // 128
+constexpr int FILL_UNITS = FILL_LEAVES / UNIT_LEAVES;     // bottom-level boxes a block makes
+static_assert(FILL_UNITS >= 64, "a block makes the three levels above its units");
 
 // The tree's shape from the number of inserted points, on the device: the kernels below read that number where the build left it
 // (Index::d_scalars: input points minus the points outside the grid), so the host need not wait for it between the sort and them.
@@ -308,19 +324,20 @@ __host__ __device__ inline int depth_of(u32 nleaves)
     while ((1ull << (2 * d)) < nleaves) ++d;
     return d;
 }
+// (TreeShape::nleaves is the number of nodes of the bottom level: UNITS of UNIT_LEAVES leaves)
 __host__ __device__ inline TreeShape shape_of(u32 nvalid)
 {
-    const u32 nleaves = (nvalid + LEAF - 1) / LEAF;
-    return TreeShape{nleaves, depth_of(nleaves)};
+    const u32 nunits = (nvalid + UNIT_POINTS - 1) / UNIT_POINTS;
+    return TreeShape{nunits, depth_of(nunits)};
 }
 // blocks of k_finish a tree of this shape needs: its leaf slots, and the (padding) nodes of the three levels above that a block owns
 __host__ __device__ inline u32 finish_blocks(const TreeShape& ts)
 {
     if (ts.nleaves == 0) return 0;
-    const u32 nslots = ts.nwrite(ts.depth) * LEAF;
+    const u32 nslots = ts.nwrite(ts.depth) * UNIT_POINTS;
     u32 fblocks = (nslots + FILL_SLOTS - 1) / FILL_SLOTS;
-    for (int j = 1; j <= 3 && j <= ts.depth; ++j) {  // a block owns 128 >> 2j nodes of level depth - j
-        const u32 per_block = static_cast<u32>(FILL_LEAVES) >> (2 * j);
+    for (int j = 1; j <= 3 && j <= ts.depth; ++j) {  // a block owns FILL_UNITS >> 2j nodes of level depth - j
+        const u32 per_block = static_cast<u32>(FILL_UNITS) >> (2 * j);
         const u32 need = (ts.nwrite(ts.depth - j) + per_block - 1) / per_block;
         if (need > fblocks) fblocks = need;
     }
@@ -351,9 +368,9 @@ struct FinishArgs {
 __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict__ rec, const float* __restrict__ xyz, FinishArgs fa, int idx_bits,
                                                        BuildCount bc, Leaf* __restrict__ leaves, u32* __restrict__ perm, NodeBox* __restrict__ nodes)
 {
-    __shared__ __attribute__((aligned(16))) NodeBox lvl0[FILL_LEAVES];      // leaf boxes of the block
-    __shared__ __attribute__((aligned(16))) NodeBox lvl1[FILL_LEAVES / 4];
-    __shared__ __attribute__((aligned(16))) NodeBox lvl2[FILL_LEAVES / 16];
+    __shared__ __attribute__((aligned(16))) NodeBox lvl0[FILL_UNITS];      // unit boxes of the block
+    __shared__ __attribute__((aligned(16))) NodeBox lvl1[FILL_UNITS / 4];
+    __shared__ __attribute__((aligned(16))) NodeBox lvl2[FILL_UNITS / 16];
     // (the window of words and its flags are dead when the leaf records are staged: one piece of LDS for both -- 21 KB per block, seven
     //  blocks per CU, as before the window was there)
     union alignas(16) Piece {
@@ -374,6 +391,7 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
     auto& place = piece.window.place;
     const u32 n = bc.valid();
     const TreeShape ts = shape_of(n);
+    const u32 nleaves_real = (n + LEAF - 1) / LEAF;
     const u32 nblocks = finish_blocks(ts);
     const u32 per = gridDim.x >> 3;  // the grid is a multiple of 8
     const u32 vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
@@ -513,22 +531,22 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
         __builtin_amdgcn_wave_barrier();  // (scheduling fence only: the reads below see the other lanes' writes)
         const u32 wave_leaf0 = (p - lane) / LEAF;  // first leaf of the wave's 64 points
         const uint4 piece = *reinterpret_cast<const uint4*>(stage + 4 * lane);
-        if (wave_leaf0 + (lane >> 3) < ts.nleaves) reinterpret_cast<uint4*>(leaves + wave_leaf0)[lane] = piece;
-        // (every lane of the 8-lane group takes part in the reduction, whatever it holds)
-        const float lx = leaf_min(live ? x[u] : inf), ly = leaf_min(live ? y[u] : inf), lz = leaf_min(live ? z[u] : inf);
-        const float hx = leaf_max(live ? x[u] : -inf), hy = leaf_max(live ? y[u] : -inf), hz = leaf_max(live ? z[u] : -inf);
-        if ((p % LEAF) == 0) {
+        if (wave_leaf0 + (lane >> 3) < nleaves_real) reinterpret_cast<uint4*>(leaves + wave_leaf0)[lane] = piece;
+        // (every lane of the group of UNIT_POINTS lanes takes part in the reduction, whatever it holds)
+        const float lx = unit_min(live ? x[u] : inf), ly = unit_min(live ? y[u] : inf), lz = unit_min(live ? z[u] : inf);
+        const float hx = unit_max(live ? x[u] : -inf), hy = unit_max(live ? y[u] : -inf), hz = unit_max(live ? z[u] : -inf);
+        if ((p % UNIT_POINTS) == 0) {
             NodeBox nb = padding_node();
-            if (p / LEAF < ts.nleaves) {
+            if (p / UNIT_POINTS < ts.nleaves) {
                 nb.set(lx, ly, lz, hx, hy, hz);
                 nb.poison = 0.f;
             }
-            lvl0[(threadIdx.x + u * FILL_BLOCK) / LEAF] = nb;
+            lvl0[(threadIdx.x + u * FILL_BLOCK) / UNIT_POINTS] = nb;
         }
     }
     // the block's leaf boxes, then the three levels above (32, 8 and 2 nodes per 128 leaves): every level leaves LDS as
     // 16-byte pieces of one contiguous run of the heap
-    const u32 l0 = vb * FILL_LEAVES;  // the block's first leaf
+    const u32 l0 = vb * FILL_UNITS;  // the block's first unit
     auto store_level = [&](const NodeBox* boxes, u32 count, int level, u32 first) {
         const u32 nw = ts.nwrite(level);
         uint4* dst = reinterpret_cast<uint4*>(nodes + TreeShape::level_start(level) + first);
@@ -536,20 +554,20 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_finish(const float4* __restrict_
             if (first + (t >> 1) < nw) dst[t] = reinterpret_cast<const uint4*>(boxes)[t];
     };
     __syncthreads();
-    store_level(lvl0, FILL_LEAVES, ts.depth, l0);
-    if (ts.depth >= 1 && threadIdx.x < FILL_LEAVES / 4) {
+    store_level(lvl0, FILL_UNITS, ts.depth, l0);
+    if (ts.depth >= 1 && threadIdx.x < FILL_UNITS / 4) {
         const u32 i = (l0 >> 2) + threadIdx.x;
         lvl1[threadIdx.x] = i < ts.nreal(ts.depth - 1) ? union_of_children(lvl0 + 4 * threadIdx.x) : padding_node();
     }
     __syncthreads();
-    if (ts.depth >= 1) store_level(lvl1, FILL_LEAVES / 4, ts.depth - 1, l0 >> 2);
-    if (ts.depth >= 2 && threadIdx.x < FILL_LEAVES / 16) {
+    if (ts.depth >= 1) store_level(lvl1, FILL_UNITS / 4, ts.depth - 1, l0 >> 2);
+    if (ts.depth >= 2 && threadIdx.x < FILL_UNITS / 16) {
         const u32 i = (l0 >> 4) + threadIdx.x;
         lvl2[threadIdx.x] = i < ts.nreal(ts.depth - 2) ? union_of_children(lvl1 + 4 * threadIdx.x) : padding_node();
     }
     __syncthreads();
-    if (ts.depth >= 2) store_level(lvl2, FILL_LEAVES / 16, ts.depth - 2, l0 >> 4);
-    if (ts.depth >= 3 && threadIdx.x < FILL_LEAVES / 64) {
+    if (ts.depth >= 2) store_level(lvl2, FILL_UNITS / 16, ts.depth - 2, l0 >> 4);
+    if (ts.depth >= 3 && threadIdx.x < FILL_UNITS / 64) {
         const u32 i = (l0 >> 6) + threadIdx.x;
         if (i < ts.nwrite(ts.depth - 3))
             nodes[TreeShape::level_start(ts.depth - 3) + i] = i < ts.nreal(ts.depth - 3) ? union_of_children(lvl2 + 4 * threadIdx.x) : padding_node();
@@ -832,7 +850,7 @@ void build_tree_set_shape(Index& ix, u32 nvalid)
 {
     const TreeShape ts = shape_of(nvalid);
     ix.n = nvalid;
-    ix.nleaves = ts.nleaves;
+    ix.nleaves = (nvalid + LEAF - 1) / LEAF;
     ix.depth = ts.depth;
     ix.leaf0 = static_cast<u32>(level_start(ts.depth));
 }

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
     }
 
     // real nodes of tree level l (the ones the build writes: the children of a real node need not be real)
-    auto nreal = [&](int l) { return (t.nleaves + (1u << (2 * (t.depth - l))) - 1u) >> (2 * (t.depth - l)); };
+    // (the tree's bottom level is UNITS of UNIT_LEAVES leaf records)
+    auto nreal = [&](int l) { return (t.nunits() + (1u << (2 * (t.depth - l))) - 1u) >> (2 * (t.depth - l)); };
     // box distance of node `node` of level l, +inf if it does not exist or is padding (NaN)
     auto box_at = [&](int l, u32 node, bool mine) {
         float v = inf;
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
     const int l0 = t.depth < 3 ? t.depth : 3;  // first level looked at: at most 64 nodes, lane = node
     const float bd0 = box_at(l0, lane, lane < (1u << (2 * l0)));
     int cur = 0;
-    u32 nbeam = keep_nearest(bd0, true, lane, l0 == t.depth ? BEAM : 4u, front[0], lane);
+    constexpr u32 BEAM_UNITS = BEAM / UNIT_LEAVES;  // the beam's last step keeps 64 points' worth of units
+    u32 nbeam = keep_nearest(bd0, true, lane, l0 == t.depth ? BEAM_UNITS : 4u, front[0], lane);
     __syncthreads();
     for (int d = l0; d < t.depth;) {
         const int s = t.depth - d >= 2 ? 2 : 1;  // levels this step goes down: 16 (or 4) descendants per beam node
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
         const u32 node = mine ? front[cur][lane >> (2 * s)] * fan + (lane & (fan - 1u)) : 0u;
         const float bd = box_at(d + s, node, mine);
         d += s;
-        nbeam = keep_nearest(bd, mine, node, d == t.depth ? BEAM : 4u, front[cur ^ 1], lane);
+        nbeam = keep_nearest(bd, mine, node, d == t.depth ? BEAM_UNITS : 4u, front[cur ^ 1], lane);
         cur ^= 1;
         __syncthreads();
     }
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
     float tau0 = inf;
     {
         float d2 = inf;
-        if (lane < 8u * nbeam) {
-            const u32 leaf = front[cur][lane >> 3];
+        if (lane < static_cast<u32>(UNIT_POINTS) * nbeam) {
+            const u32 leaf = front[cur][lane / UNIT_POINTS] * UNIT_LEAVES + (lane % UNIT_POINTS) / LEAF;
             if (leaf < t.nleaves) {
                 const Leaf& lf = t.leaves[leaf];
                 const float dx = lf.x[lane & 7u] - qx, dy = lf.y[lane & 7u] - qy, dz = lf.z[lane & 7u] - qz;
@@ -226,12 +228,12 @@ __global__ __launch_bounds__(64) void k_knn_few(TreeView t, const float* __restr
 
     // ---- 3. candidates: every point of the surviving leaves within tau0 and outside the eps-box ----
     u32 nc = 0;
-    for (u32 c0 = 0; c0 < 8u * m; c0 += 64u) {
+    for (u32 c0 = 0; c0 < static_cast<u32>(UNIT_POINTS) * m; c0 += 64u) {
         const u32 c = c0 + lane;
         bool take = false;
         u64 key = 0;
-        if (c < 8u * m) {
-            const u32 leaf = front[cur][c >> 3];
+        if (c < static_cast<u32>(UNIT_POINTS) * m) {
+            const u32 leaf = front[cur][c / UNIT_POINTS] * UNIT_LEAVES + (c % UNIT_POINTS) / LEAF;
             if (leaf < t.nleaves) {
                 const Leaf& lf = t.leaves[leaf];
                 const u32 s = c & 7u;

@@ -152,11 +152,12 @@ __device__ __forceinline__ void visit_group(const TreeView& t, const QueryView& 
     acc.begin(qx, qy, qz, p, valid);
     auto need = [&](const NodeBox& b) { return box_d2(b, qx, qy, qz) <= r2; };
     Walker wk;
-    u32 leaf = 0, nexp = 0, cnt = 0;
+    u32 unit = 0, nexp = 0, cnt = 0;  // (the walk yields UNITS of the tree's bottom level: UNIT_LEAVES consecutive leaf records each)
     bool more = wk.start(t, need, nexp);
-    if (!more) more = wk.next(t, need, leaf, nexp);
-    u32 base_leaf = leaf;  // wave-uniform: the epoch of the lists
+    if (!more) more = wk.next(t, need, unit, nexp);
+    u32 base_leaf = unit * UNIT_LEAVES;  // wave-uniform: the epoch of the lists
     while (more) {
+      for (u32 leaf = unit * UNIT_LEAVES; leaf < (unit + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) {
         if (leaf - base_leaf >= LIST_SPAN) {  // offsets from here on would not fit an entry
             flush_list(list, base_leaf * LEAF, lane, cnt, qx, qy, qz, acc);
             cnt = 0;
@@ -177,7 +178,8 @@ __device__ __forceinline__ void visit_group(const TreeView& t, const QueryView& 
             cnt = 0;
             base_leaf = leaf;
         }
-        more = wk.next(t, need, leaf, nexp);
+      }
+        more = wk.next(t, need, unit, nexp);
     }
     flush_list(list, base_leaf * LEAF, lane, cnt, qx, qy, qz, acc);
     if (valid) acc.finish(row);

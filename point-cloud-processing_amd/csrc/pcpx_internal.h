@@ -32,6 +32,18 @@ constexpr int LOGW = 2;    // log2 of the tree arity
 constexpr int W = 1 << LOGW;
 constexpr int GROUP = 64;  // queries per wavefront
 constexpr int LEAVES_PER_GROUP = GROUP / LEAF;
+// The boxes of the tree's bottom level are over UNITS of UNIT_LEAVES consecutive leaves: 1 (a box per leaf record), or 2 -- sixteen
+// points under one box, the records still eight points each; a last-level node then covers a whole query group's 64 points, the tree
+// is half a level shallower and a walk expands 28 % fewer nodes for 50 % more records looked at (tools/sim_unit16.py: -14 % scalar,
+// -11 % vector instructions in the walk by the model).  Measured, round 5 (every kernel and the build written for either; all parity
+// tests pass with 2): k_knn 1.5 % SLOWER (3.68-3.73 -> 3.75-3.78 ms uniform, 4.20 -> 4.24 clustered), k_range 2 % faster, the rebuild
+// 3 % slower.  1 stays.
+#ifndef PCPX_UNIT_LEAVES
+#define PCPX_UNIT_LEAVES 1
+#endif
+constexpr int UNIT_LEAVES = PCPX_UNIT_LEAVES;
+static_assert(UNIT_LEAVES == 1 || UNIT_LEAVES == 2, "units of one or two leaves");
+constexpr int UNIT_POINTS = UNIT_LEAVES * LEAF;
 constexpr int MAXDEPTH = 15;  // 4^15 leaves of 8 points: far beyond 2^32 points
 constexpr u32 INVALID_ID = 0xFFFFFFFFu;
 // The curve order only has to make leaves spatially compact: any order gives a correct tree (boxes come from the
@@ -77,14 +89,15 @@ struct NodeBox {
 static_assert(sizeof(NodeBox) == 32, "node box must be 32 bytes");
 
 // Heap layout: root = node 0, children of node h = 4h+1 .. 4h+4, so depth d starts at (4^d-1)/3.
-// Leaf j is node leaf0 + j with leaf0 = (4^depth - 1)/3; depth is the smallest with 4^depth >= nleaves.
+// Unit u (leaves UNIT_LEAVES u ...) is node leaf0 + u with leaf0 = (4^depth - 1)/3; depth is the smallest with 4^depth >= nunits.
 struct TreeView {
     const Leaf* leaves;    // nleaves records
     const NodeBox* nodes;  // (4^(depth+1)-1)/3 nodes
     u32 nleaves;
     u32 n;                 // indexed points
     int depth;
-    u32 leaf0;
+    u32 leaf0;             // heap id of unit 0
+    __host__ __device__ u32 nunits() const { return (nleaves + UNIT_LEAVES - 1) / UNIT_LEAVES; }
 };
 
 // Device outputs of the fused kNN kernel, one row per query (row index = input index of the query).

@@ -696,6 +696,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
 #else
     constexpr u32 seed_extra = KCAP <= 8 ? 0u : KCAP <= 16 ? 2u : 4u;
 #endif
+    static_assert(seed_extra % UNIT_LEAVES == 0 && LEAVES_PER_GROUP % UNIT_LEAVES == 0, "the seed range is whole units of the tree's bottom level");
     if (seed_extra > 0) {
         s0 = s0 > seed_extra ? s0 - seed_extra : 0u;
         s1 = s1 + seed_extra < t.nleaves ? s1 + seed_extra : t.nleaves;
@@ -984,22 +985,30 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                     asm("s_ff1_i32_b32 %0, %1\n\ts_bitset0_b32 %1, %0" : "=&s"(child), "+s"(direct));
                     loc = direct_first + child;
                 }
-                if (loc - s0 >= seed_count) {
+                // (`loc` is a UNIT of the tree's bottom level: UNIT_LEAVES consecutive leaf records under one box, looked at one after the
+                //  other for the lanes that need the unit; the seed range is whole units)
+                if (loc * UNIT_LEAVES - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
                     if (!packed_leaves) {
-                        fold_if_needed(true, false);
-                        candidates(loc, rounds != 0u);
+#pragma unroll 1
+                        for (u32 leaf = loc * UNIT_LEAVES; leaf < (loc + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) {
+                            fold_if_needed(true, false);
+                            candidates(leaf, rounds != 0u);
+                        }
                     } else {
                         const u32 c = loc & (W - 1u);
                         u64 who;
-                        u32 how_many;
+                        u32 how_many_unit;
                         asm("s_cmp_eq_u32 %[c], 2\n\ts_cselect_b64 %[w], %[n2], %[n3]\n\t"
                             "s_cmp_eq_u32 %[c], 1\n\ts_cselect_b64 %[w], %[n1], %[w]\n\t"
                             "s_cmp_eq_u32 %[c], 0\n\ts_cselect_b64 %[w], %[n0], %[w]\n\t"
                             "s_bcnt1_i32_b64 %[m], %[w]"
-                            : [w] "=&s"(who), [m] "=s"(how_many)
+                            : [w] "=&s"(who), [m] "=s"(how_many_unit)
                             : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
                             : "scc");
+#pragma unroll 1
+                        for (u32 leaf = loc * UNIT_LEAVES; leaf < (loc + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) {
+                        u32 how_many = how_many_unit;
                         // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
                         // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
                         const bool packed_form = how_many <= packed_limit;
@@ -1008,7 +1017,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                             if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false);
                             if (!packed_form) break;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            todo = packed_leaf(loc, todo, how_many);
+                            todo = packed_leaf(leaf, todo, how_many);
                             if (COST) st_steps += (how_many + 7u) >> 3;
                             if (STATS) {
                                 asm volatile("" ::"v"(wa));
@@ -1024,8 +1033,9 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                             //  `appended` figure was that difference and came out as 1.7e14)
                             if (STATS) ++st_leaves, ++st_sparse, st_owners += how_many;
                         } else {
-                            candidates(loc, rounds != 0u);
+                            candidates(leaf, rounds != 0u);
                         }
+                        }  // the unit's next leaf
                     }
                     if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
                 }

@@ -149,7 +149,8 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
     // the walk, with "is there another leaf" in the control flow rather than in a value (WalkerT::pop, pcpx_device.h)
     WalkerT<true, packed_leaves> wk;
     u32 nexp = 0;
-    if (wk.start(t, need, nexp)) leaf_points(0u);  // the root is the only leaf
+    if (wk.start(t, need, nexp))  // the root is the only unit
+        for (u32 leaf = 0; leaf < static_cast<u32>(UNIT_LEAVES) && leaf < t.nleaves; ++leaf) leaf_points(leaf);
     // A last-level node looks at its needed leaves itself (WalkerT::leaves_of) instead of pushing and popping them: the four
     // children written out, so that a child's record is an immediate offset from the node's first leaf and its lanes' ballot a
     // register pair known at compile time (height 0 is popped only when the root's own children are leaves).
@@ -159,20 +160,25 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
         if (h > 1 || (!PCPX_RANGE_DIRECT_LEAVES && h == 1)) {
             wk.expand(t, h, loc, need);
         } else if (h == 1) {
+            // (the children of a last-level node are UNITS of UNIT_LEAVES leaf records under one box)
             const u32 needed = wk.leaves_of(t, loc, need);
-            const Leaf* records = t.leaves + (loc << LOGW);
+            const Leaf* records = t.leaves + (loc << LOGW) * UNIT_LEAVES;
 #pragma unroll
             for (int c = 0; c < W; ++c) {
                 if ((needed >> c) & 1u) {
                     u32 how_many = GROUP;
                     if (packed_leaves) asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
-                    if (packed_leaves && how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c, wk.leaf_need[c], how_many);
-                    else leaf_record_points(load_const(records + c));
+#pragma unroll
+                    for (int r = 0; r < UNIT_LEAVES; ++r) {
+                        if (UNIT_LEAVES > 1 && ((loc << LOGW) + c) * UNIT_LEAVES + r >= t.nleaves) break;  // (the cloud's last unit may hold one leaf)
+                        if (packed_leaves && how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c * UNIT_LEAVES + r, wk.leaf_need[c], how_many);
+                        else leaf_record_points(load_const(records + c * UNIT_LEAVES + r));
+                    }
                 }
             }
         } else {
             wk.at_leaf(loc);
-            leaf_points(loc);
+            for (u32 leaf = loc * UNIT_LEAVES; leaf < (loc + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) leaf_points(leaf);
         }
     }
     if (valid && !FILL) out_cnt[(SELF && qv.by_position) ? p + qv.pos_bias : row] = cnt;
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
         }
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
         const u32 my_byte = (rank & 7u) << 3;
+#pragma nounroll
         for (u32 s = 0; s < how_many; s += 8u) {
             const float4 lo = pub_lo[s + i], hi = pub_hi[s + i];
             const bool in_here = (x >= lo.x) & (y >= lo.y) & (z >= lo.z) & (x <= hi.x) & (y <= hi.y) & (z <= hi.z);  // (NaN padding fails)
@@ -279,27 +286,40 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
     };
     WalkerT<true, packed_leaves> wk;
     u32 nexp = 0;
-    if (wk.start(t, need, nexp)) leaf_points(0u);
-    while (!wk.done()) {  // one pop per trip: a node is expanded; a last-level node looks at its needed leaves itself
+    if (wk.start(t, need, nexp))
+        for (u32 leaf = 0; leaf < static_cast<u32>(UNIT_LEAVES) && leaf < t.nleaves; ++leaf) leaf_points(leaf);
+    while (!wk.done()) {  // one pop per trip: a node is expanded; a last-level node looks at its needed units itself
         u32 loc;
         const int h = wk.pop(loc);
         if (h > 1 || (!packed_leaves && h == 1)) {
             wk.expand(t, h, loc, need);
         } else if (h == 1) {
-            const u32 needed = wk.leaves_of(t, loc, need);
-            const Leaf* records = t.leaves + (loc << LOGW);
-#pragma unroll
-            for (int c = 0; c < W; ++c) {
-                if ((needed >> c) & 1u) {
-                    u32 how_many = GROUP;
-                    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(how_many) : "s"(wk.leaf_need[c]) : "scc");
-                    if (how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(records + c, wk.leaf_need[c], how_many);
-                    else leaf_points((loc << LOGW) + c);
+            u32 needed = wk.leaves_of(t, loc, need);
+            // (one copy of the leaf forms, the needed children in a loop: written out four times two records they cost the count kernel
+            //  133 saved scalar registers)
+#pragma nounroll
+            while (needed != 0u) {
+                u32 c;
+                asm("s_ff1_i32_b32 %0, %1\n\ts_bitset0_b32 %1, %0" : "=&s"(c), "+s"(needed));
+                u64 who;
+                u32 how_many;
+                asm("s_cmp_eq_u32 %[c], 2\n\ts_cselect_b64 %[w], %[n2], %[n3]\n\t"
+                    "s_cmp_eq_u32 %[c], 1\n\ts_cselect_b64 %[w], %[n1], %[w]\n\t"
+                    "s_cmp_eq_u32 %[c], 0\n\ts_cselect_b64 %[w], %[n0], %[w]\n\t"
+                    "s_bcnt1_i32_b64 %[m], %[w]"
+                    : [w] "=&s"(who), [m] "=s"(how_many)
+                    : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
+                    : "scc");
+                const u32 first = ((loc << LOGW) + c) * UNIT_LEAVES;
+#pragma unroll 1
+                for (u32 leaf = first; leaf < first + UNIT_LEAVES && leaf < t.nleaves; ++leaf) {
+                    if (how_many <= static_cast<u32>(PCPX_RANGE_PACKED_LEAVES)) packed_leaf(t.leaves + leaf, who, how_many);
+                    else leaf_points(leaf);
                 }
             }
         } else {
             wk.at_leaf(loc);
-            leaf_points(loc);
+            for (u32 leaf = loc * UNIT_LEAVES; leaf < (loc + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) leaf_points(leaf);
         }
     }
     if (valid && !FILL) out_cnt[p] = cnt;
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(64) void k_range_one(TreeView t, float a0, float a1
     };
     auto level_base = [](int d) { return d == 0 ? 0u : (0x55555555u >> (32 - 2 * d)); };
     // real nodes of tree level l (the ones the build writes: the children of a real node need not be real)
-    auto nreal = [&](int l) { return (t.nleaves + (1u << (2 * (t.depth - l))) - 1u) >> (2 * (t.depth - l)); };
+    auto nreal = [&](int l) { return (t.nunits() + (1u << (2 * (t.depth - l))) - 1u) >> (2 * (t.depth - l)); };
     u32 cnt = 0, m = 0;
     bool overflow = false;
     int cur = 0;
@@ -370,13 +390,13 @@ __global__ __launch_bounds__(64) void k_range_one(TreeView t, float a0, float a1
             cur ^= 1;
             __syncthreads();
         }
-        // the points of the surviving leaves, one per lane, in leaf (= curve) order
-        for (u32 c0 = 0; c0 < 8u * m && !overflow; c0 += 64u) {
+        // the points of the surviving units, one per lane, in leaf (= curve) order
+        for (u32 c0 = 0; c0 < static_cast<u32>(UNIT_POINTS) * m && !overflow; c0 += 64u) {
             const u32 c = c0 + lane;
             bool in = false;
             u32 id = 0;
-            if (c < 8u * m) {
-                const u32 leaf = front[cur][c >> 3];
+            if (c < static_cast<u32>(UNIT_POINTS) * m) {
+                const u32 leaf = front[cur][c / UNIT_POINTS] * UNIT_LEAVES + (c % UNIT_POINTS) / LEAF;
                 if (leaf < t.nleaves) {
                     const Leaf& lf = t.leaves[leaf];
                     const u32 sl = c & 7u;
