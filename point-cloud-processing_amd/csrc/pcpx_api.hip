@@ -552,8 +552,8 @@ void free_index(Index* ix)
     index_block_free(ix->d_scratch);
     index_block_free(ix->d_nc4);
     index_block_free(ix->d_pos_of);
-    (void)hipFree(ix->sched.d_gtime);
-    (void)hipFree(ix->sched.d_order);
+    index_block_free(ix->sched.d_gtime);
+    index_block_free(ix->sched.d_order);
     (void)hipFree(ix->d_queue);
     (void)hipFree(ix->d_multi);
     free_shard(*ix);

@@ -917,6 +917,8 @@ int build_index(Index& ix, const float* d_xyz_src, u64 n, const pcpx_build_param
             continue;
         }
         build_tree_set_shape(ix, static_cast<u32>(n) - outside);
+        if (ix.tuning.lpt && n >= 64 * 512) (void)sched_reserve(ix, (n + GROUP - 1) / GROUP);  // (here, not in the first query; failure: no schedule)
+        (void)ensure_queue(ix);  // (likewise the persistent kernels' queue counters)
         return PCPX_OK;
     }
 }

@@ -455,6 +455,7 @@ int launch_wlop_repulsion(Index& samples, float h, float mu, const void* d_recor
 int prepare_queries(Index& ix, const float* d_q, u64 nq, QueryView& qv);
 int launch_invert_perm(const u32* d_perm, u64 n, u32* d_position_of, hipStream_t s);
 int ensure_queue(Index& ix);   // the counters' allocation (zeroed)
+int sched_reserve(Index& ix, u64 groups);  // the arrays of the recorded order for launches of up to `groups` query groups (Index::sched)
 int prepare_queue(Index& ix);  // which set of work-queue counters the next persistent launch uses (Index::queue_now) and which it zeroes (queue_clear)
 
 }  // namespace pcpx

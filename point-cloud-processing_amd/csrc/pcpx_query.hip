@@ -1595,23 +1595,26 @@ __global__ __launch_bounds__(1024) void k_make_order(const u32* __restrict__ gti
     }
 }
 
-static int sched_reserve(Index& ix, u64 groups)
+// (blocks of the device's index cache: a handle that is created, asked once and destroyed -- the drop-in's usual life -- does not pay
+//  two hipMalloc / hipFree pairs for them; build_index reserves them with the tree so that the first query does not either)
+int sched_reserve(Index& ix, u64 groups)
 {
     Index::Sched& sc = ix.sched;
     if (groups <= sc.cap) return PCPX_OK;
     PCPX_HIP(hipStreamSynchronize(ix.stream));
-    (void)hipFree(sc.d_gtime);
-    (void)hipFree(sc.d_order);
+    index_block_free(sc.d_gtime);
+    index_block_free(sc.d_order);
     sc = Index::Sched{};
     const u64 cap = groups + groups / 8 + 64;
-    if (hipMalloc(reinterpret_cast<void**>(&sc.d_gtime), cap * sizeof(u32)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&sc.d_order), order_entries(cap) * sizeof(u32)) != hipSuccess) {
+    void *a = nullptr, *b = nullptr;
+    if (index_block_alloc(&a, cap * sizeof(u32)) != hipSuccess || index_block_alloc(&b, order_entries(cap) * sizeof(u32)) != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipFree(sc.d_gtime);
-        (void)hipFree(sc.d_order);
-        sc = Index::Sched{};
+        index_block_free(a);
+        index_block_free(b);
         return PCPX_ERR_ALLOC;  // (the caller goes on without a schedule)
     }
+    sc.d_gtime = static_cast<u32*>(a);
+    sc.d_order = static_cast<u32*>(b);
     sc.cap = cap;
     return PCPX_OK;
 }
