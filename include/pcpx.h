@@ -413,6 +413,10 @@ int pcpx_debug_eps_test_mode(pcpx_index* idx, int mode);
  * normals and counts are written at curve positions and permuted by a gather instead of being scattered from the search kernel;
  * "gather_counts" (default 0: measured slower as well): the same for pcpx_range_count_self_dev's counts. */
 int pcpx_debug_set(pcpx_index* idx, const char* name, int64_t value);
+/* Figures of the handle: "build_redos" (builds repeated because the leaf kernel met a run of sort words it could not order),
+ * "full_buckets" (top-digit buckets that take every radix pass since), "schedule_state" (0: nothing recorded, 1: group times
+ * recorded, 2: the recorded order is in use). */
+int pcpx_debug_get(pcpx_index* idx, const char* name, int64_t* out_value);
 /* What the handle's last recorded self-kNN launch took per query group (shader-clock ticks / 64, search only; host array of
  * *out_groups entries, the launch's groups in curve order; 0 groups: nothing recorded).  PCPX_ERR_CAPACITY reports the size. */
 int pcpx_debug_group_times(pcpx_index* idx, uint32_t* out_ticks, uint64_t capacity, uint64_t* out_groups);

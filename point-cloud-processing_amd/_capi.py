@@ -77,6 +77,7 @@ SIGNATURES = {
     "pcpx_knn_group_costs_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_uint64, u64p]),
     "pcpx_shard_cuts_by_cost": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p]),
     "pcpx_debug_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "pcpx_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "pcpx_debug_group_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "pcpx_knn_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

@@ -1736,6 +1736,27 @@ int pcpx_debug_set(pcpx_index* h, const char* name, int64_t value)
     return PCPX_OK;
 }
 
+int pcpx_debug_get(pcpx_index* h, const char* name, int64_t* out_value)
+{
+    Index* ix = reinterpret_cast<Index*>(h);
+    if (!ix || !name || !out_value) return PCPX_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> serialise(ix->mu);
+    const std::string key(name);
+    if (key == "build_redos") {
+        *out_value = ix->build_redos;
+    } else if (key == "full_buckets") {
+        int64_t c = 0;
+        for (u32 w = 0; w < 8; ++w) c += __builtin_popcount(ix->full_buckets[w]);
+        *out_value = c;
+    } else if (key == "schedule_state") {
+        *out_value = ix->sched.state;
+    } else {
+        set_error("pcpx_debug_get: no figure called '%s'", name);
+        return PCPX_ERR_INVALID;
+    }
+    return PCPX_OK;
+}
+
 int pcpx_debug_group_times(pcpx_index* h, uint32_t* out_ticks, uint64_t capacity, uint64_t* out_groups)
 {
     Index* ix = reinterpret_cast<Index*>(h);

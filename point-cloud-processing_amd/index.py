@@ -325,6 +325,12 @@ class Index:
         """pcpx_debug_set: 'long_groups_first', 'gather_outputs' (how work is done, never what comes out)."""
         check(self._lib.pcpx_debug_set(self._h, name.encode(), int(value)))
 
+    def debug_get(self, name):
+        """pcpx_debug_get: 'build_redos', 'full_buckets', 'schedule_state'."""
+        v = C.c_int64(0)
+        check(self._lib.pcpx_debug_get(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def debug_group_times(self):
         """Ticks / 64 per query group of the last recorded self-kNN launch (uint32 array; empty: nothing recorded)."""
         ng = C.c_uint64(0)

@@ -275,3 +275,56 @@ def test_device_resident_range_lists_of_every_point(pkg, oracle, kind, n, radius
     for q, i in enumerate(sel[:200]):
         assert set(i2[o2[q]:o2[q + 1]].tolist()) == set(idx_h[off_h[i]:off_h[i + 1]].tolist())
     ix.close()
+
+
+@pytest.mark.parametrize("copies,k", [(300, 15), (70, 32), (5000, 8)])
+def test_build_with_runs_the_leaf_kernel_cannot_order(pkg, oracle, copies, k):
+    """The sort stops after two bucketed passes where runs are expected to stay short and k_finish orders runs of up to 64 words in
+    LDS (csrc/pcpx_build.hip).  Hundreds of coincident points in an otherwise sparse bucket are one long run of equal keys: the
+    build must notice, repeat itself with that bucket taking every pass, and give the same rows as brute force -- also on the
+    rebuild after it (the handle remembers the bucket) and through a rank-local handle."""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(copies)
+    base = pkg.synthetic.uniform_cloud(120_000, 5)
+    hot = base[rng.integers(0, len(base), 6)]
+    near = (hot[:, None, :] + rng.normal(0, 1e-6, (6, copies, 3)).astype(np.float32)).reshape(-1, 3)  # dense knots: one 24-bit cell each
+    same = np.repeat(hot[:3], copies, axis=0)                                                          # and exact copies
+    pts = np.clip(np.concatenate([base, near, same]), 0, 1).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    n = len(pts)
+    grid = np.array([0, 0, 0, 1, 1, 1], np.float32)
+    d_pts = torch.from_numpy(pts).to(dev)
+    ix = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid)
+    if copies <= 300:  # knots of a few hundred points: the plan (words per cell of the bucket's fullest 16-bit cell) lets their buckets stop early ...
+        assert ix.debug_get("build_redos") == 1 and 1 <= ix.debug_get("full_buckets") <= 12  # ... and the first attempt finds them out
+    else:              # knots of thousands: the plan sends their buckets through every pass from the start
+        assert ix.debug_get("build_redos") == 0
+    sel = np.concatenate([rng.integers(0, n, 400), np.nonzero((pts[:, None, :] == hot[None, :3, :]).all(2).any(1))[0][:100]])
+    oi, oc, od = oracle.knn_bruteforce(pts, pts[sel], k, nthreads=16, want_d2=True)
+    from test_gpu_parity import _assert_rows_exact
+    for attempt in range(2):  # the build that finds the runs out, and a rebuild that knows
+        idx = torch.full((n, k), -1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+        d2 = torch.full((n, k), float("inf"), dtype=torch.float32, device=dev)
+        ix.knn_self_dev(k, 1e-5, idx.data_ptr(), cnt.data_ptr(), d2.data_ptr())
+        ix.synchronize()
+        t = torch.from_numpy(sel).to(dev)
+        _assert_rows_exact(pts, pts[sel], k, idx[t].cpu().numpy().view(np.uint32), cnt[t].cpu().numpy().view(np.uint32), d2[t].cpu().numpy(), oi, oc, od)
+        want = oracle.range_count_bruteforce(pts, pts[sel], 0.01, nthreads=16)
+        rc = torch.zeros(n, dtype=torch.int32, device=dev)
+        ix.range_count_self_dev(0.01, rc.data_ptr())
+        ix.synchronize()
+        assert np.array_equal(rc[t].cpu().numpy(), want)
+        ix.rebuild_dev(d_pts.data_ptr(), n, voxel_grid=grid)
+        assert ix.debug_get("build_redos") == (1 if copies <= 300 else 0)  # (the rebuilds know the buckets: no second attempt)
+    sidx = torch.full((n, k), -1, dtype=torch.int32, device=dev)
+    scnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    for rank in range(2):
+        sh = pkg.Index.from_device(d_pts.data_ptr(), n, voxel_grid=grid, shard=(rank, 2), k_hint=k)
+        first, count = pkg.shard_range(sh.size(), rank, 2)
+        sh.knn_self_dev(k, 1e-5, sidx.data_ptr(), scnt.data_ptr(), None, first, count)
+        sh.synchronize()
+        sh.close()
+    assert torch.equal(scnt, cnt) and torch.equal(sidx, idx)
+    ix.close()
