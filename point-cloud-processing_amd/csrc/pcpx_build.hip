@@ -318,11 +318,14 @@ struct BuildCount {
     u32 n_in, known;
     __device__ u32 valid() const { return scalars ? n_in - scalars[6] : known; }
 };
+// (never 1: a tree of two to four leaves gets a level of one real node between the root and them, so that a walk meets leaves only
+//  under a last-level node -- k_knn's loop has no case for a leaf popped from the pending bits, which cost every pop a dozen scalar
+//  instructions for a shape only clouds of up to 32 points have)
 __host__ __device__ inline int depth_of(u32 nleaves)
 {
     int d = 0;
     while ((1ull << (2 * d)) < nleaves) ++d;
-    return d;
+    return d == 1 ? 2 : d;
 }
 // (TreeShape::nleaves is the number of nodes of the bottom level: UNITS of UNIT_LEAVES leaves)
 __host__ __device__ inline TreeShape shape_of(u32 nvalid)
@@ -616,11 +619,11 @@ __global__ __launch_bounds__(UPPER_BLOCK) void k_upper_levels(NodeBox* __restric
 
 inline u64 pow4(int d) { return 1ull << (2 * d); }
 inline u64 level_start(int d) { return (pow4(d) - 1) / 3; }
-inline int depth_for(u64 nleaves)
+inline int depth_for(u64 nleaves)  // (= depth_of)
 {
     int d = 0;
     while (pow4(d) < nleaves) ++d;
-    return d;
+    return d == 1 ? 2 : d;
 }
 
 // (out of memory: the handle's pool of staging blocks may be sitting on gigabytes -- give them back and try once more)

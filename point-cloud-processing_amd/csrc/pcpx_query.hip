@@ -158,6 +158,13 @@ __device__ __forceinline__ void bitonic_merge(u64 (&a)[N])
 #ifndef PCPX_PACKED_LEAVES
 #define PCPX_PACKED_LEAVES 24  // a walk leaf that 2 ... this many lanes need is looked at eight needing lanes x eight points at a time (0: off)
 #endif
+#ifndef PCPX_PACKED_NODE
+#define PCPX_PACKED_NODE 0  // a LAST-LEVEL node that at most this many lanes need is looked at TWO NEEDING LANES x ITS 32 POINTS at a time, its four
+                             // leaf boxes never tested (0: off; <= PCPX_PACKED_LEAVES: the publish row's slots)
+#endif
+#ifndef PCPX_PACKED_NODE_KCAP
+#define PCPX_PACKED_NODE_KCAP 16  // largest KCAP whose kernel has the node form (the k <= 32 kernel fills its buffer without the optimistic form's check: PCPX_PACKED_FREE)
+#endif
 #ifndef PCPX_PACKED_FREE
 #define PCPX_PACKED_FREE 3  // k <= 16 kernel: free rows every needing lane has when a packed leaf starts (0: LEAF of them, like the other forms -- no key can then find its column full).  The k <= 32 kernel always waits for LEAF rows: its fold is twice the network, and what the optimistic fill loses there it does not win back (measured)
 #endif
@@ -894,15 +901,30 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     // the publish row instead; the needing lane sees from the address it reads back that keys were lost, takes its column back
     // to where it was before the leaf (the rows written since hold PAD_KEY again), and the leaf is looked at once more for
     // those lanes after a fold.  Returns the lanes that want that (0: done).
-    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many) -> u64 {
+    // The same for a whole LAST-LEVEL NODE that few lanes need (`sh` = 5: lane 32 i + j forms the distance from the i-th published query
+    // to point j of the node's 32, two needing lanes a step; `sh` = 3: one leaf, as above): the node's four leaf boxes are then never
+    // tested -- d2 <= tau is the test that counts -- and its leaves cost one publish and read-back instead of one each.  A leaf of the
+    // node that is in the seed range (seen already), or beyond the cloud's last, shows NaN to every query.
+    auto packed_leaf = [&](const u32 leaf, const u64 who, const u32 how_many, const u32 sh) -> u64 {
         float4* const pub_q = reinterpret_cast<float4*>(pub);                     // [PCPX_PACKED_LEAVES] {qx, qy, qz, tau}
         u32* const pub_wa = reinterpret_cast<u32*>(pub) + 4 * PCPX_PACKED_LEAVES;  // [PCPX_PACKED_LEAVES] next free row of the column
         if (PCPX_PRIO_PACKED != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_PACKED);
         u32 lane_here = lane;
         asm volatile("" : "+v"(lane_here));  // (or everything below that depends on the lane alone sits in registers from group to group)
-        const u32 j = lane_here & 7u, i = lane_here >> 3;
-        const float* rec = reinterpret_cast<const float*>(t.leaves + leaf);
-        const float cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        const u32 j = PCPX_PACKED_NODE > 0 ? lane_here & ((1u << sh) - 1u) : lane_here & 7u, i = PCPX_PACKED_NODE > 0 ? lane_here >> sh : lane_here >> 3;
+        float cx, cy, cz;
+        if (PCPX_PACKED_NODE > 0) {
+            const u32 lf = leaf + (j >> 3);
+            const bool shown = lf < t.nleaves && lf - s0 >= s1 - s0;
+            cx = std::numeric_limits<float>::quiet_NaN(), cy = 0.f, cz = 0.f;
+            if (shown) {
+                const float* rec = reinterpret_cast<const float*>(t.leaves + lf);
+                cx = rec[j & 7u], cy = rec[LEAF + (j & 7u)], cz = rec[2 * LEAF + (j & 7u)];
+            }
+        } else {
+            const float* rec = reinterpret_cast<const float*>(t.leaves + leaf);
+            cx = rec[j], cy = rec[LEAF + j], cz = rec[2 * LEAF + j];
+        }
         const u32 posj = leaf * LEAF + j;
         const u32 r = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(who >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(who), 0u));
         const bool mine = __builtin_amdgcn_inverse_ballot_w64(who);
@@ -911,7 +933,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             pub_wa[r] = wa;
         }
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
-        for (u32 s = 0; s < how_many; s += 8u) {
+        for (u32 s = 0; s < how_many; s += PCPX_PACKED_NODE > 0 ? 64u >> sh : 8u) {
             const float4 q = pub_q[s + i];
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
             const float d2 = sq3(dx, dy, dz);
@@ -949,7 +971,12 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
     };
     const u32 seed_count = s1 - s0;
     u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;
+    constexpr bool packed_nodes = packed_leaves && PCPX_PACKED_NODE > 0 && KCAP <= PCPX_PACKED_NODE_KCAP;
+    static_assert(!packed_nodes || (UNIT_LEAVES == 1 && PCPX_PACKED_NODE <= PCPX_PACKED_LEAVES), "the node form: one leaf per unit, one publish slot per needing lane");
     for (u32 rounds = 0;;) {  // (rounds != 0: a shell round -- asked of the counter, a bool carried round the loop becomes a lane mask)
+        // (wave-uniform as it is, but carried round a loop whose exit hipcc takes for lane-dependent -- `cap` comes out of lane exchanges --
+        //  it counts as a vector value, and a scalar flag made from it is an "illegal VGPR to SGPR copy")
+        const u32 packed_limit_now = __builtin_amdgcn_readfirstlane(packed_limit);
         bool root_leaf = wk.start(t, need, st_expand);
         (void)root_leaf;  // depth 0: the only leaf is the seed chunk, already done
         // A trip of the outer loop pops one node: a node above the last level is expanded; a LAST-LEVEL node hands its needed
@@ -958,6 +985,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
         // at, as leaves direct_first + c.  A leaf inside the seed range was seen under a larger tau than any later one: skipped.
         if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
         u32 direct = 0, direct_first = 0;
+        u32 sh = 3u;  // (packed_nodes: 5 while `direct` stands for a last-level node as a whole)
         for (;;) {
             if (direct == 0) {
                 if (wk.done()) break;
@@ -967,15 +995,33 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                 ++st_expand;
                 if (h > 1) {
                     wk.expand(t, h, node, need);
-                } else if (h == 1) {
-                    direct = wk.leaves_of(t, node, need);
+                } else {
                     direct_first = node << LOGW;
-                } else {  // (a leaf is popped only when the root's own children are leaves; as a block before the loop -- `if (t.depth == 1)
-                          //  direct = the root's child mask` -- this cost every k_knn kernel 50 ... 300 B of scratch: hipcc 7.2)
-                    wk.at_leaf(node);
-                    direct = 1u << (node & (W - 1u));
-                    direct_first = node & ~(W - 1u);
+                    if (packed_nodes) {
+                        // (the node's own box -- a child box of its parent's record -- says how many lanes need it NOW; none: tau has shrunk since the parent was expanded)
+                        sh = 3u;
+                        u32 lanes_now = ~0u;
+                        u64 lanes = 0;
+                        if (packed_limit_now != 0) {
+                            const NodeBox own = load_const(t.nodes + (wk.level_base(t.depth - 1) + node));
+                            lanes = __builtin_amdgcn_ballot_w64(need(own));
+                            asm("s_bcnt1_i32_b64 %0, %1" : "=s"(lanes_now) : "s"(lanes) : "scc");  // (as __builtin_popcountll hipcc counts on the vector side)
+                        }
+                        if (lanes_now <= static_cast<u32>(PCPX_PACKED_NODE)) {
+                            wk.leaf_need[0] = lanes;
+                            wk.l = 0;
+                            wk.ploc = node;
+                            direct = __builtin_amdgcn_readfirstlane(lanes_now < 1u ? lanes_now : 1u);  // (wave-uniform as it is; hipcc 7.2 forms it on the vector side and then fails to bring it back: "illegal VGPR to SGPR copy")
+                            sh = 5u;
+                        } else {
+                            direct = wk.leaves_of(t, node, need);
+                        }
+                    } else {
+                        direct = wk.leaves_of(t, node, need);
+                    }
                 }
+                // (h = 0 is never popped: the build gives no tree a depth of 1 -- depth_of, pcpx_build.hip -- so leaves are only ever met under a
+                //  last-level node.  The case for it cost EVERY pop of the walk nine scalar instructions of dispatch.)
                 if (PCPX_PRIO_WALK != PCPX_PRIO_BASE) __builtin_amdgcn_s_setprio(PCPX_PRIO_BASE);
             }
             while (direct != 0) {
@@ -987,13 +1033,14 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                 }
                 // (`loc` is a UNIT of the tree's bottom level: UNIT_LEAVES consecutive leaf records under one box, looked at one after the
                 //  other for the lanes that need the unit; the seed range is whole units)
-                if (loc * UNIT_LEAVES - s0 >= seed_count) {
+                if ((packed_nodes && sh == 5u) || loc * UNIT_LEAVES - s0 >= seed_count) {
                     if (STATS) tc_walk += __builtin_amdgcn_s_memtime() - tc_mark;
                     if (!packed_leaves) {
 #pragma unroll 1
-                        for (u32 leaf = loc * UNIT_LEAVES; leaf < (loc + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) {
+                        for (u32 leaf = loc * UNIT_LEAVES;; ++leaf) {  // (a needed unit's first leaf exists; UNIT_LEAVES = 1: no loop)
                             fold_if_needed(true, false);
                             candidates(leaf, rounds != 0u);
+                            if (UNIT_LEAVES == 1 || leaf + 1u == (loc + 1u) * UNIT_LEAVES || leaf + 1u >= t.nleaves) break;
                         }
                     } else {
                         const u32 c = loc & (W - 1u);
@@ -1007,26 +1054,40 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                             : [c] "s"(c), [n0] "s"(wk.leaf_need[0]), [n1] "s"(wk.leaf_need[1]), [n2] "s"(wk.leaf_need[2]), [n3] "s"(wk.leaf_need[3])
                             : "scc");
 #pragma unroll 1
-                        for (u32 leaf = loc * UNIT_LEAVES; leaf < (loc + 1u) * UNIT_LEAVES && leaf < t.nleaves; ++leaf) {
+                        for (u32 leaf = loc * UNIT_LEAVES;; ++leaf) {  // (a needed unit's first leaf exists; UNIT_LEAVES = 1: no loop)
                         u32 how_many = how_many_unit;
                         // Only a lane that needs the leaf can take keys from it (its box distance was within a tau that has only
                         // shrunk since, and no point of the leaf is nearer than its box): fold if one of THOSE could not take LEAF more.
-                        const bool packed_form = how_many <= packed_limit;
+                        // (The form is a NUMBER in a scalar register and "once more, after a fold" a threshold of 0: as two bools carried round
+                        //  the loop hipcc kept them as 64-bit lane masks -- a dozen scalar instructions per leaf to set, copy and test them.)
+                        u32 packed_form, full_from;
+                        asm("s_cmp_le_u32 %[m], %[lim]\n\ts_cselect_b32 %[pf], 1, 0\n\ts_cselect_b32 %[thr], %[tp], %[td]"
+                            : [pf] "=&s"(packed_form), [thr] "=&s"(full_from)
+                            : [m] "s"(how_many), [lim] "s"(packed_limit_now), [tp] "s"(wa_packed_full), [td] "s"(wa_full)
+                            : "scc");
                         u64 todo = who;  // (the lanes the leaf is still to be looked at for)
-                        for (bool again = false;; again = true) {  // (one call site of the fold: one copy of the selection network)
-                            if (again || (__builtin_amdgcn_ballot_w64(wa >= (packed_form ? wa_packed_full : wa_full)) & todo) != 0) fold(false);
-                            if (!packed_form) break;
+                        for (;;) {  // (one call site of the fold: one copy of the selection network)
+                            if ((__builtin_amdgcn_ballot_w64(wa >= full_from) & todo) != 0) fold(false);
+                            if (packed_form == 0u) break;
                             if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
-                            todo = packed_leaf(leaf, todo, how_many);
-                            if (COST) st_steps += (how_many + 7u) >> 3;
+                            todo = packed_leaf(leaf, todo, how_many, sh);
+                            if (COST) st_steps += (how_many + (64u >> sh) - 1u) >> (6u - sh);
                             if (STATS) {
                                 asm volatile("" ::"v"(wa));
                                 tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
                             }
                             if (todo == 0) break;  // (else, PCPX_PACKED_FREE > 0 only and rare: columns ran full -- fold, and once more for their lanes)
                             how_many = static_cast<u32>(__builtin_popcountll(todo));
+                            full_from = 0u;  // (every lane of `todo` has a full column, whatever its address was taken back to: fold)
+                            if (packed_nodes && sh == 5u) {  // (a node: its 32 points may be more than a column holds -- leaf by leaf for those lanes)
+                                sh = 3u;
+                                direct = (1u << W) - 1u;
+#pragma unroll
+                                for (int cc = 0; cc < W; ++cc) wk.leaf_need[cc] = todo;
+                                break;
+                            }
                         }
-                        if (packed_form) {
+                        if (packed_form != 0u) {
                             if (COST) ++st_sparse;
                             // ([14], [15]: the packed leaves and their needing lanes.  The keys they took are counted where they are folded:
                             //  a column's address goes back to its first row at every fold, so "address now - address before" is not a count -- round 4's
@@ -1035,6 +1096,7 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                         } else {
                             candidates(leaf, rounds != 0u);
                         }
+                        if (UNIT_LEAVES == 1 || leaf + 1u == (loc + 1u) * UNIT_LEAVES || leaf + 1u >= t.nleaves) break;
                         }  // the unit's next leaf
                     }
                     if (STATS) tc_mark = __builtin_amdgcn_s_memtime();
