@@ -933,18 +933,48 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             pub_wa[r] = wa;
         }
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's order)
-        for (u32 s = 0; s < how_many; s += PCPX_PACKED_NODE > 0 ? 64u >> sh : 8u) {
+        // A step takes its keys with the lanes that have none switched off (v_cmpx, like the lane-per-query leaves) instead of a branch
+        // round them: five scalar-pipe instructions less per step, and nearly every step has a lane that takes one.  A row address
+        // beyond the column (PCPX_PACKED_FREE > 0) becomes the spare word's by bit arithmetic: a compare and select through VCC costs a
+        // register for the spare address and two wait states.
+        const u64 saved = save_exec();
+        const u32 per_step = PCPX_PACKED_NODE > 0 ? 64u >> sh : 8u;
+        u32 s = 0;  // (how_many >= 1: some lane needs the leaf)
+        do {
             const float4 q = pub_q[s + i];
+            // (the step's query is on its way from LDS while the point comes from memory, which is waited for HERE, as a whole: left to
+            //  itself hipcc puts three s_waitcnt vmcnt in every step, one in front of each subtraction)
+            asm volatile("" : "+v"(cx), "+v"(cy), "+v"(cz));
             const float dx = cx - q.x, dy = cy - q.y, dz = cz - q.z;
             const float d2 = sq3(dx, dy, dz);
-            if (d2 <= q.w) {  // (NaN padding points fail; so does every point against an empty slot's tau = -1)
-                u32 one_row = 512u;
-                asm volatile("" : "+v"(one_row));  // (a v_mov here, not a register held from group to group)
-                u32 at = atomicAdd(pub_wa + s + i, one_row);
-                if (packed_free > 0) at = at < wa_end ? at : wa_end + 480u;  // (the publish row's last 32 bytes are nobody's)
-                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(at), "v"(posj), "v"(d2) : "memory");
-            }
-        }
+            const u32 slot = lds_address(pub_wa + s + i);
+            u32 at, inside;
+            // (NaN padding points fail d2 <= tau; so does every point against an empty slot's tau = -1)
+            if (packed_free > 0)
+                asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                             "v_mov_b32_e32 %[at], 0x200\n\t"
+                             "ds_add_rtn_u32 %[at], %[slot], %[at]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_subrev_u32_e32 %[m], %[end], %[at]\n\t"      // address - end of the buffer: negative while inside it
+                             "v_ashrrev_i32_e32 %[m], 31, %[m]\n\t"
+                             "v_bfi_b32 %[at], %[m], %[at], %[spare]\n\t"    // inside ? address : the publish row's last 32 bytes, which are nobody's
+                             "ds_write2_b32 %[at], %[pos], %[d2] offset1:1\n\t"
+                             "s_mov_b64 exec, %[saved]"
+                             : [at] "=&v"(at), [m] "=&v"(inside)
+                             : [d2] "v"(d2), [tau] "v"(q.w), [slot] "v"(slot), [end] "s"(wa_end), [spare] "s"(wa_end + 480u), [pos] "v"(posj), [saved] "s"(saved)
+                             : "vcc", "memory");
+            else
+                asm volatile("v_cmpx_le_f32_e32 %[d2], %[tau]\n\t"
+                             "v_mov_b32_e32 %[at], 0x200\n\t"
+                             "ds_add_rtn_u32 %[at], %[slot], %[at]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "ds_write2_b32 %[at], %[pos], %[d2] offset1:1\n\t"
+                             "s_mov_b64 exec, %[saved]"
+                             : [at] "=&v"(at)
+                             : [d2] "v"(d2), [tau] "v"(q.w), [slot] "v"(slot), [pos] "v"(posj), [saved] "s"(saved)
+                             : "vcc", "memory");
+            s += per_step;
+        } while (s < how_many);
         __builtin_amdgcn_wave_barrier();
         u32 now = wa;
         if (mine) {
@@ -957,17 +987,18 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
             wa = now;
             return 0ull;
         }
-        const u32 column_end = col_addr + (static_cast<u32>(BUF) << 9);
-        const bool lost_keys = now > column_end;  // (a lane that does not need the leaf: now = wa <= column_end)
-        const u64 lost = __builtin_amdgcn_ballot_w64(lost_keys);
-        if (lost != 0) {  // rare
-            if (lost_keys) {
-                const u64 pad = pad_key_here();
-                for (u32 a = wa; a < column_end; a += 512u) asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(pad) : "memory");
-            }
+        // (a lane whose column ran full keeps its address of before the leaf: packed_take_back, the caller's rare branch)
+        const bool lost_keys = now > col_addr + (static_cast<u32>(BUF) << 9);  // (a lane that does not need the leaf: now = wa <= the column's end)
+        wa = lost_keys ? wa : now;
+        return __builtin_amdgcn_ballot_w64(lost_keys);
+    };
+    // the rows a lane wrote in a leaf that then overran its column hold PAD_KEY again
+    auto packed_take_back = [&](const u64 lost) {
+        if (__builtin_amdgcn_inverse_ballot_w64(lost)) {
+            const u32 column_end = col_addr + (static_cast<u32>(BUF) << 9);
+            const u64 pad = pad_key_here();
+            for (u32 a = wa; a < column_end; a += 512u) asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(pad) : "memory");
         }
-        if (!lost_keys) wa = now;
-        return lost;
     };
     const u32 seed_count = s1 - s0;
     u32 packed_limit = packed_leaves ? PCPX_PACKED_LEAVES : 0;
@@ -1076,7 +1107,8 @@ __device__ __forceinline__ void knn_group(const TreeView& tree, const u32 g, con
                                 asm volatile("" ::"v"(wa));
                                 tc_leaf += __builtin_amdgcn_s_memtime() - tc_mark;
                             }
-                            if (todo == 0) break;  // (else, PCPX_PACKED_FREE > 0 only and rare: columns ran full -- fold, and once more for their lanes)
+                            if (__builtin_expect(todo == 0, 1)) break;  // (else, PCPX_PACKED_FREE > 0 only and rare: columns ran full -- fold, and once more for their lanes)
+                            packed_take_back(todo);
                             how_many = static_cast<u32>(__builtin_popcountll(todo));
                             full_from = 0u;  // (every lane of `todo` has a full column, whatever its address was taken back to: fold)
                             if (packed_nodes && sh == 5u) {  // (a node: its 32 points may be more than a column holds -- leaf by leaf for those lanes)
