@@ -159,7 +159,8 @@ __device__ __forceinline__ void range_group(const TreeView& t, const QueryView& 
         const int h = wk.pop(loc);
         if (h > 1 || (!PCPX_RANGE_DIRECT_LEAVES && h == 1)) {
             wk.expand(t, h, loc, need);
-        } else if (h == 1) {
+        } else if (PCPX_RANGE_DIRECT_LEAVES || h == 1) {  // (no tree has depth 1 -- depth_of, pcpx_build.hip --: with last-level nodes looking
+                                                          //  at their leaves themselves no leaf is ever popped, and the case below is not compiled)
             // (the children of a last-level node are UNITS of UNIT_LEAVES leaf records under one box)
             const u32 needed = wk.leaves_of(t, loc, need);
             const Leaf* records = t.leaves + (loc << LOGW) * UNIT_LEAVES;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_range_aabb(TreeView t,
         const int h = wk.pop(loc);
         if (h > 1 || (!packed_leaves && h == 1)) {
             wk.expand(t, h, loc, need);
-        } else if (h == 1) {
+        } else if (packed_leaves || h == 1) {  // (as in range_group: no leaf is ever popped)
             u32 needed = wk.leaves_of(t, loc, need);
             // (one copy of the leaf forms, the needed children in a loop: written out four times two records they cost the count kernel
             //  133 saved scalar registers)
