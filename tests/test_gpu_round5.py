@@ -328,3 +328,43 @@ def test_build_with_runs_the_leaf_kernel_cannot_order(pkg, oracle, copies, k):
         sh.close()
     assert torch.equal(scnt, cnt) and torch.equal(sidx, idx)
     ix.close()
+
+
+@pytest.mark.parametrize("n", [9, 12, 16, 17, 24, 25, 31, 32, 33])
+def test_trees_of_two_to_five_leaves(pkg, oracle, n):
+    """No tree has depth 1 (csrc/pcpx_build.hip, depth_of): clouds of 9 ... 32 points -- two to four leaves -- get a level of one real
+    node between the root and the leaves, so that every walk meets leaves only under a last-level node (k_knn, k_range and
+    k_range_aabb have no case for a leaf popped from the pending bits).  Every query form on such clouds against brute force."""
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3), dtype=np.float32)
+    q = (rng.random((40, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    ix = pkg.Index(pts)
+    from test_gpu_parity import _assert_rows_exact
+    for k in (1, 5, 15, 32):
+        gi, gc, gd = ix.knn_self(k, want_d2=True)
+        oi, oc, od = oracle.knn_bruteforce(pts, pts, k, nthreads=4, want_d2=True)
+        _assert_rows_exact(pts, pts, k, gi, gc, gd, oi, oc, od)
+        gi, gc, gd = ix.knn(q, k, want_d2=True)  # (few queries: the latency kernel; 40 > ... both batch forms by size)
+        oi, oc, od = oracle.knn_bruteforce(pts, q, k, nthreads=4, want_d2=True)
+        _assert_rows_exact(pts, q, k, gi, gc, gd, oi, oc, od)
+    big = np.repeat(q, 20, axis=0)  # 800 queries: the throughput kernel
+    gi, gc, gd = ix.knn(big, 15, want_d2=True)
+    oi, oc, od = oracle.knn_bruteforce(pts, big, 15, nthreads=4, want_d2=True)
+    _assert_rows_exact(pts, big, 15, gi, gc, gd, oi, oc, od)
+    for r in (0.05, 0.3, 2.0):
+        assert np.array_equal(ix.range_count_self(r), oracle.range_count_bruteforce(pts, pts, r, nthreads=4))
+        assert np.array_equal(ix.range_count(big, r), oracle.range_count_bruteforce(pts, big, r, nthreads=4))
+        off, idx = ix.range_sphere(q, r)
+        d2 = ((pts[None, :, :].astype(np.float32) - q[:, None, :]) ** 2)
+        d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+        for i in range(len(q)):
+            assert sorted(idx[int(off[i]):int(off[i + 1])].tolist()) == np.nonzero(d2[i] <= np.float32(r) * np.float32(r))[0].tolist()
+    lo = (rng.random((50, 3), dtype=np.float32) * 0.8).astype(np.float32)
+    boxes = np.concatenate([lo, lo + rng.random((50, 3), dtype=np.float32) * 0.6], axis=1).astype(np.float32)
+    off, idx = ix.range_aabb(boxes)
+    for i, b in enumerate(boxes):
+        inside = np.nonzero(((pts >= b[:3]) & (pts <= b[3:])).all(1))[0].tolist()
+        assert sorted(idx[int(off[i]):int(off[i + 1])].tolist()) == inside
+    nrm = ix.normals_knn_self(min(8, n - 1))
+    assert np.isfinite(nrm).all()
+    ix.close()
