@@ -426,6 +426,29 @@ int pcpx_debug_sort_keys(const uint64_t* keys, uint64_t n, int first_bit, int de
 int pcpx_profile_begin(pcpx_index* idx);
 int pcpx_profile_end(pcpx_index* idx, pcpx_profile* out);
 
+/* ---- kd-tree for K > 3 coordinates -------------------------------------------------------------------------------------
+ * The reference's pcp::basic_linked_kdtree_t is generic in K (include/pcp/kdtree/linked_kdtree.hpp:64); the index above holds
+ * three coordinates (K = 1, 2, 3 go through it, missing axes carried as 0).  For 4 <= K <= PCPX_KD_MAX_DIMS the two queries of the
+ * class are answered by exhaustive search on the GPU (csrc/pcpx_kd.hip), with the reference's results:
+ *   pcpx_kd_knn_batch        nearest_neighbours (linked_kdtree.hpp:200-262, :436-540): per query the k points of smallest squared
+ *                            distance (sum over the axes in order, common/norm.hpp:123-141), nearest first, a point with
+ *                            |p[a] - q[a]| < eps on every axis left out; ties in index order.  out_idx nq x k (0xFFFFFFFF beyond
+ *                            out_count[q]), opt_out_d2 nq x k (+inf beyond) or NULL.  Any k.
+ *   pcpx_kd_range_aabb_batch range_search with a kd box (linked_kdtree.hpp:270-311): boxes nb x 2 dims (min[dims] then max[dims]),
+ *                            min <= p <= max on every axis; CSR offsets nb + 1 and indices, unordered inside a box;
+ *                            PCPX_ERR_CAPACITY with the offsets filled if idx_capacity (or a NULL out_idx) does not hold them.
+ * points / queries: host arrays, row-major (n x dims).  Fewer than 2^32 - 1 points.  One call at a time per handle. */
+#define PCPX_KD_MAX_DIMS 16
+typedef struct pcpx_kd_index pcpx_kd_index;
+int pcpx_kd_create(const float* points, uint64_t n, uint32_t dims, int device, pcpx_kd_index** out);
+void pcpx_kd_destroy(pcpx_kd_index* idx);
+uint64_t pcpx_kd_size(const pcpx_kd_index* idx);
+uint32_t pcpx_kd_dims(const pcpx_kd_index* idx);
+int pcpx_kd_knn_batch(pcpx_kd_index* idx, const float* queries, uint64_t nq, uint32_t k, float eps, uint32_t* out_idx, uint32_t* out_count,
+                      float* opt_out_d2);
+int pcpx_kd_range_aabb_batch(pcpx_kd_index* idx, const float* boxes, uint64_t nb, uint64_t* out_offsets, uint32_t* out_idx,
+                             uint64_t idx_capacity);
+
 #ifdef __cplusplus
 }
 #endif

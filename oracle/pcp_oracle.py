@@ -291,3 +291,42 @@ def wlop(xyz, sample, mu, h, K, uniform=True, f64_yardstick=False, nthreads=1):
     lib().orc_wlop(_p(xyz, _f32p), C.c_uint64(len(xyz)), _p(sample, C.POINTER(C.c_uint64)), C.c_uint64(len(sample)), C.c_double(mu),
                    C.c_double(h), C.c_uint64(K), C.c_int(int(uniform)), _p(out, _f32p), C.c_int(int(f64_yardstick)), C.c_int(nthreads))
     return out
+
+
+# ---- K-dimensional kd-tree queries (numpy restatement; K > 3 has no caller in the reference's tests or examples, so these are
+#      pinned through K = 3: tests/test_oracle.py checks them against the C++ restatement above, which the reference's KATs pin) ----
+def kd_knn_bruteforce(points, queries, k, eps=1e-5):
+    """pcp::basic_linked_kdtree_t::nearest_neighbours for any K (include/pcp/kdtree/linked_kdtree.hpp:200-262, recurse_knn :436-540):
+    the k points of smallest squared distance -- std::inner_product of the coordinate differences with itself from 0, in float,
+    axis by axis (include/pcp/common/norm.hpp:123-141) --, nearest first, a point with |p[a] - q[a]| < eps on every axis skipped
+    (common::floating_point_equals, vector3d_queries.hpp:31-35).  Equal distances in index order (the reference: heap order).
+    Returns idx (nq, k) padded with 0xFFFFFFFF, count (nq,), d2 (nq, k) padded with +inf."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, pts.shape[1])
+    n, dims = pts.shape
+    idx = np.full((len(q), k), 0xFFFFFFFF, np.uint32)
+    d2o = np.full((len(q), k), np.inf, np.float32)
+    cnt = np.zeros(len(q), np.uint32)
+    eps32 = np.float32(eps) if eps > 0 else np.float32(0)
+    for j in range(len(q)):
+        acc = np.zeros(n, np.float32)
+        same = np.ones(n, bool)
+        for a in range(dims):
+            d = pts[:, a] - q[j, a]
+            acc = acc + d * d
+            same &= np.abs(d) < eps32
+        keep = np.nonzero(~same & ~np.isnan(acc))[0]
+        order = keep[np.lexsort((keep, acc[keep]))][:k]
+        cnt[j] = len(order)
+        idx[j, :len(order)] = order
+        d2o[j, :len(order)] = acc[order]
+    return idx, cnt, d2o
+
+
+def kd_range_aabb(points, boxes):
+    """range_search with a kd_axis_aligned_bounding_box_t (linked_kdtree.hpp:270-311; contains: min <= p <= max on every axis,
+    include/pcp/common/axis_aligned_bounding_box.hpp): per box the sorted indices of the points inside."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    dims = pts.shape[1]
+    b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 2 * dims)
+    return [np.nonzero(((pts >= bb[:dims]) & (pts <= bb[dims:])).all(1))[0] for bb in b]

@@ -133,6 +133,12 @@ SIGNATURES = {
     "pcpx_debug_sort_keys": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),
     "pcpx_profile_begin": (C.c_int, [C.c_void_p]),
     "pcpx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
+    "pcpx_kd_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "pcpx_kd_destroy": (None, [C.c_void_p]),
+    "pcpx_kd_size": (C.c_uint64, [C.c_void_p]),
+    "pcpx_kd_dims": (C.c_uint32, [C.c_void_p]),
+    "pcpx_kd_knn_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcpx_kd_range_aabb_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
 }
 
 _lib = None

@@ -13,7 +13,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ_DIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libpcpx.so")
 SOURCES = ["pcpx_query.hip", "pcpx_few.hip", "pcpx_range.hip", "pcpx_filter.hip", "pcpx_normals.hip", "pcpx_prep.hip", "pcpx_orient.hip", "pcpx_build.hip", "pcpx_shard.hip", "pcpx_sort.hip",
-           "pcpx_comm.hip", "pcpx_api.hip"]
+           "pcpx_comm.hip", "pcpx_kd.hip", "pcpx_api.hip"]
 HEADERS = [os.path.join(CSRC, "pcpx_internal.h"), os.path.join(CSRC, "pcpx_device.h"), os.path.join(CSRC, "pcpx_eig3.h"), os.path.join(CSRC, "pcpx_curve.h"),
            os.path.join(CSRC, "pcpx_curve_table.h"),
            os.path.join(INCLUDE, "pcpx.h")]

@@ -436,6 +436,57 @@ class LinkedKdTree(Index):
         return self.range_sphere(centers, radius)
 
 
+class KdTreeK:
+    """pcp::basic_linked_kdtree_t for K > 3 coordinates (4 ... 16): nearest_neighbours and range_search with a kd box, by
+    exhaustive search on the GPU (include/pcpx.h: pcpx_kd_*; csrc/pcpx_kd.hip).  K <= 3 goes through LinkedKdTree."""
+
+    def __init__(self, points, device=0):
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        if pts.ndim != 2:
+            raise ValueError("points: an (n, K) array")
+        self.n_in, self.dims = int(pts.shape[0]), int(pts.shape[1])
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        check(self._lib.pcpx_kd_create(_vp(pts), self.n_in, self.dims, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pcpx_kd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(self._lib.pcpx_kd_size(self._h))
+
+    def nearest_neighbours(self, targets, k, eps=1e-5, want_d2=False):
+        """(idx (nq, k) uint32 padded with 0xFFFFFFFF, count (nq,)[, d2 (nq, k) padded with +inf]): ascending (d2, index)."""
+        q = _f32(targets, self.dims)
+        idx = np.empty((len(q), k), np.uint32)
+        cnt = np.empty(len(q), np.uint32)
+        d2 = np.empty((len(q), k), np.float32) if want_d2 else None
+        check(self._lib.pcpx_kd_knn_batch(self._h, _vp(q), len(q), k, eps, _vp(idx), _vp(cnt), _vp(d2)))
+        return (idx, cnt, d2) if want_d2 else (idx, cnt)
+
+    def range_search(self, boxes):
+        """CSR (offsets, indices) of the points inside each kd box; boxes (nb, 2 K): min then max."""
+        b = _f32(boxes, 2 * self.dims)
+        off = np.zeros(len(b) + 1, np.uint64)
+        st = self._lib.pcpx_kd_range_aabb_batch(self._h, _vp(b), len(b), _vp(off), None, 0)
+        if st == _capi.PCPX_OK:
+            return off, np.empty(0, np.uint32)
+        if st != _capi.PCPX_ERR_CAPACITY:
+            check(st)
+        out = np.empty(int(off[-1]), np.uint32)
+        check(self._lib.pcpx_kd_range_aabb_batch(self._h, _vp(b), len(b), _vp(off), _vp(out), len(out)))
+        return off, out
+
+
 def estimate_normals(tree, k, eps=1e-5):
     """pcp::algorithm::estimate_normals with knn_map = tree.nearest_neighbours(point, k): one normal
     per indexed point (examples/simple_example.cpp:83-99)."""

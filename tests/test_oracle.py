@@ -266,3 +266,24 @@ def test_oracle_normals_on_analytic_cases_that_enter_the_qr_iteration(oracle):
         general += householder
         sweeps += qr_steps >= 2
     assert general >= 12 and sweeps >= 8  # the general tridiagonalisation and >= 2 QR steps are really exercised
+
+
+def test_k_dimensional_restatement_agrees_with_the_pinned_one_at_three(oracle):
+    """oracle.kd_knn_bruteforce / kd_range_aabb (numpy, any K: what tests/test_gpu_kd_wide.py checks pcpx_kd_* against) give, at
+    K = 3, the rows of the C++ restatement that the reference's own known answers pin."""
+    rng = np.random.default_rng(77)
+    pts = rng.random((3000, 3), dtype=np.float32)
+    pts[100:120] = pts[5]  # coincident points: the eps rule and ties
+    q = np.concatenate([pts[:50], rng.random((30, 3), dtype=np.float32)])
+    for k, eps in ((1, 1e-5), (15, 1e-5), (40, 0.0), (8, 0.05)):
+        ki, kc, kd = oracle.kd_knn_bruteforce(pts, q, k, eps=eps)
+        oi, oc, od = oracle.knn_bruteforce(pts, q, k, eps=eps, want_d2=True)
+        assert np.array_equal(kc, oc)
+        valid = np.arange(k)[None, :] < oc[:, None]
+        assert np.array_equal(kd[valid], od[valid])
+        for j in np.nonzero((ki != oi).any(1))[0]:  # only among exact ties with the row's last distance
+            cols = np.nonzero(ki[j] != oi[j])[0]
+            assert np.all(od[j, cols] == od[j, oc[j] - 1])
+    boxes = np.concatenate([rng.random((20, 3), dtype=np.float32) * 0.5, 0.5 + rng.random((20, 3), dtype=np.float32) * 0.5], axis=1)
+    for b, inside in zip(boxes, oracle.kd_range_aabb(pts, boxes)):
+        assert np.array_equal(inside, np.nonzero(((pts >= b[:3]) & (pts <= b[3:])).all(1))[0])
