@@ -487,6 +487,61 @@ class device_index_t
     mutable std::unique_ptr<std::mutex> mu_ = std::make_unique<std::mutex>();
 };
 
+// RAII owner of a pcpx_kd_index (include/pcpx.h: kd-tree queries for K > 3 coordinates, exhaustive search on the GPU).
+class kd_wide_index_t
+{
+  public:
+    kd_wide_index_t() = default;
+    kd_wide_index_t(kd_wide_index_t const&)            = delete;
+    kd_wide_index_t& operator=(kd_wide_index_t const&) = delete;
+    kd_wide_index_t(kd_wide_index_t&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    kd_wide_index_t& operator=(kd_wide_index_t&& o) noexcept
+    {
+        if (this != &o)
+        {
+            reset();
+            h_ = std::exchange(o.h_, nullptr);
+        }
+        return *this;
+    }
+    ~kd_wide_index_t() { reset(); }
+    void reset()
+    {
+        if (h_) pcpx_kd_destroy(h_);
+        h_ = nullptr;
+    }
+    bool valid() const { return h_ != nullptr; }
+    // rows: n x dims floats
+    void build(float const* rows, std::uint64_t n, std::uint32_t dims, int device = 0)
+    {
+        reset();
+        check(pcpx_kd_create(rows, n, dims, device, &h_), "pcpx_kd_create");
+    }
+    // idx: nq x k (0xFFFFFFFF beyond count[q]); nearest first
+    void knn(float const* queries, std::uint64_t nq, std::uint32_t k, float eps, std::vector<std::uint32_t>& idx,
+             std::vector<std::uint32_t>& count) const
+    {
+        idx.assign(nq * k, 0xFFFFFFFFu);
+        count.assign(nq, 0u);
+        if (nq == 0 || k == 0) return;
+        check(pcpx_kd_knn_batch(h_, queries, nq, k, eps, idx.data(), count.data(), nullptr), "pcpx_kd_knn_batch");
+    }
+    // boxes: nb x 2 dims (min then max); CSR offsets (nb + 1) and indices
+    void range_boxes(float const* boxes, std::uint64_t nb, std::vector<std::uint64_t>& off, std::vector<std::uint32_t>& idx) const
+    {
+        off.assign(nb + 1, 0);
+        idx.clear();
+        int st = pcpx_kd_range_aabb_batch(h_, boxes, nb, off.data(), nullptr, 0);
+        if (st == PCPX_OK) return;
+        if (st != PCPX_ERR_CAPACITY) check(st, "pcpx_kd_range_aabb_batch");
+        idx.resize(off[nb]);
+        check(pcpx_kd_range_aabb_batch(h_, boxes, nb, off.data(), idx.data(), idx.size()), "pcpx_kd_range_aabb_batch");
+    }
+
+  private:
+    pcpx_kd_index* h_ = nullptr;
+};
+
 } // namespace gpu
 } // namespace pcp
 

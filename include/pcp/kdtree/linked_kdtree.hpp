@@ -5,8 +5,9 @@
 //
 // Same template parameters <Element, K, CoordinateMap>, constructor, member names and result conventions
 // (ascending kNN, eps-coincident points skipped per coordinate, range results unordered and including the
-// query point).  K = 1, 2 or 3 (the reference is generic in K; the device index is three-dimensional: missing axes are
-// carried as 0, which changes no distance, no eps-box test and no box containment); K > 3 does not compile.  The
+// query point).  K = 1, 2 or 3 goes through the device index (three-dimensional: missing axes are carried as 0, which changes
+// no distance, no eps-box test and no box containment); 4 <= K <= 16 is answered by exhaustive search on the GPU (pcpx_kd_*,
+// include/pcpx.h: same rows; nearest_neighbours and range_search with the tree's own box type).  The
 // construction parameters are accepted for source compatibility: they shaped the reference's median-split
 // tree (depth, leaf size), not the query results.  Storage keeps the elements in input order (the
 // reference permutes its storage with nth_element; that order was never specified).
@@ -47,7 +48,8 @@ struct construction_params_t
 template <class Element, std::size_t K, class CoordinateMap>
 class basic_linked_kdtree_t
 {
-    static_assert(K >= 1 && K <= 3, "the device index holds up to 3 coordinates per point");
+    static_assert(K >= 1 && K <= PCPX_KD_MAX_DIMS, "1 ... 16 coordinates per point");
+    static constexpr bool wide = K > 3;  // (beyond the device index's three coordinates: pcpx_kd_*)
     // coordinate a of a K-dimensional point as the device sees it (0 beyond K)
     template <class C>
     static float axis(C const& c, std::size_t a)
@@ -95,7 +97,7 @@ class basic_linked_kdtree_t
         }
         if (!copied) storage_.assign(begin, end);
         std::size_t const n = storage_.size();
-        xyz_.resize(3 * n);
+        xyz_.resize((wide ? K : 3) * n);  // (K > 3: rows of K coordinates)
         unsigned const pieces = n >= gpu::parallel_capture_threshold ? gpu::capture_threads(n) : 1u;
         aabb_type none;
         for (std::size_t a = 0; a < K; ++a)
@@ -109,9 +111,16 @@ class basic_linked_kdtree_t
             for (std::size_t i = first; i < last; ++i)
             {
                 auto const c   = coordinate_map_(storage_[i]);
-                xyz_[3 * i]     = axis(c, 0);
-                xyz_[3 * i + 1] = axis(c, 1);
-                xyz_[3 * i + 2] = axis(c, 2);
+                if constexpr (wide)
+                {
+                    for (std::size_t a = 0; a < K; ++a) xyz_[K * i + a] = static_cast<float>(c[a]);
+                }
+                else
+                {
+                    xyz_[3 * i]     = axis(c, 0);
+                    xyz_[3 * i + 1] = axis(c, 1);
+                    xyz_[3 * i + 2] = axis(c, 2);
+                }
                 for (std::size_t a = 0; a < K; ++a)
                 {
                     if (c[a] < b.min[a]) b.min[a] = c[a];
@@ -138,6 +147,7 @@ class basic_linked_kdtree_t
         storage_.clear();
         xyz_.clear();
         index_.reset();
+        wide_index_.reset();
     }
     iterator begin() { return storage_.begin(); }
     iterator end() { return storage_.end(); }
@@ -149,9 +159,20 @@ class basic_linked_kdtree_t
                                                  coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
     {
         if (k == 0 || storage_.empty()) return {};
-        float const q[3] = {axis(target, 0), axis(target, 1), axis(target, 2)};
-        auto const row = index().knn_one(q, static_cast<std::uint32_t>(k), static_cast<float>(eps));
-        return gather(row.data(), row.size());
+        if constexpr (wide)
+        {
+            float q[K];
+            for (std::size_t a = 0; a < K; ++a) q[a] = static_cast<float>(target[a]);
+            std::vector<std::uint32_t> idx, count;
+            wide_index().knn(q, 1, static_cast<std::uint32_t>(k), static_cast<float>(eps), idx, count);
+            return gather(idx.data(), count[0]);
+        }
+        else
+        {
+            float const q[3] = {axis(target, 0), axis(target, 1), axis(target, 2)};
+            auto const row = index().knn_one(q, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+            return gather(row.data(), row.size());
+        }
     }
     std::vector<element_type> nearest_neighbours(element_type const& element_target, std::size_t k,
                                                  coordinate_type eps = static_cast<coordinate_type>(1e-5)) const
@@ -170,7 +191,24 @@ class basic_linked_kdtree_t
         if (storage_.empty()) return {};
         std::vector<std::uint64_t> off;
         std::vector<std::uint32_t> idx;
-        if constexpr (K == 3 && std::is_same_v<Range, sphere_a<coordinate_type>>)
+        if constexpr (wide && std::is_same_v<Range, aabb_type>)
+        {
+            float b[2 * K];
+            for (std::size_t a = 0; a < K; ++a)
+            {
+                b[a]     = static_cast<float>(range.min[a]);
+                b[K + a] = static_cast<float>(range.max[a]);
+            }
+            wide_index().range_boxes(b, 1, off, idx);
+        }
+        else if constexpr (wide)
+        {
+            std::vector<element_type> out;
+            for (auto const& e : storage_)
+                if (range.contains(coordinate_map_(e))) out.push_back(e);
+            return out;
+        }
+        else if constexpr (K == 3 && std::is_same_v<Range, sphere_a<coordinate_type>>)
         {
             float const c[3] = {axis(range.position, 0), axis(range.position, 1), axis(range.position, 2)};
             idx = index().range_sphere_one(c, static_cast<float>(range.radius));
@@ -200,25 +238,50 @@ class basic_linked_kdtree_t
         for (; begin != end; ++begin)
         {
             auto const c = coordinate_map_(*begin);
-            q.push_back(axis(c, 0));
-            q.push_back(axis(c, 1));
-            q.push_back(axis(c, 2));
+            if constexpr (wide)
+            {
+                for (std::size_t a = 0; a < K; ++a) q.push_back(static_cast<float>(c[a]));
+            }
+            else
+            {
+                q.push_back(axis(c, 0));
+                q.push_back(axis(c, 1));
+                q.push_back(axis(c, 2));
+            }
         }
-        std::size_t const nq = q.size() / 3;
+        std::size_t const nq = q.size() / (wide ? K : 3);
         std::vector<std::vector<element_type>> rows(nq);
         if (k == 0 || storage_.empty() || nq == 0) return rows;
-        auto const r = index().knn(q.data(), nq, static_cast<std::uint32_t>(k), static_cast<float>(eps));
-        for (std::size_t i = 0; i < nq; ++i) rows[i] = gather(r.idx.data() + i * k, r.count[i]);
+        if constexpr (wide)
+        {
+            std::vector<std::uint32_t> idx, count;
+            wide_index().knn(q.data(), nq, static_cast<std::uint32_t>(k), static_cast<float>(eps), idx, count);
+            for (std::size_t i = 0; i < nq; ++i) rows[i] = gather(idx.data() + i * k, count[i]);
+        }
+        else
+        {
+            auto const r = index().knn(q.data(), nq, static_cast<std::uint32_t>(k), static_cast<float>(eps));
+            for (std::size_t i = 0; i < nq; ++i) rows[i] = gather(r.idx.data() + i * k, r.count[i]);
+        }
         return rows;
     }
     std::vector<std::uint32_t> range_count_self(float radius) const
     {
+        static_assert(!wide, "sphere ranges are three-dimensional (pcp::sphere_a)");
         if (storage_.empty()) return {};
         return index().range_count(xyz_.data(), storage_.size(), radius);
     }
 
+    gpu::kd_wide_index_t const& wide_index() const
+    {
+        static_assert(wide, "K <= 3 goes through index()");
+        std::lock_guard<std::mutex> lock(*mutex_);
+        if (!wide_index_.valid()) wide_index_.build(xyz_.data(), storage_.size(), static_cast<std::uint32_t>(K));
+        return wide_index_;
+    }
     gpu::device_index_t const& index() const
     {
+        static_assert(!wide, "K > 3 goes through wide_index()");
         std::lock_guard<std::mutex> lock(*mutex_);
         if (!index_.valid()) index_.build(xyz_.data(), storage_.size());
         return index_;
@@ -237,11 +300,12 @@ class basic_linked_kdtree_t
     }
 
     gpu::element_storage_t<element_type> storage_;
-    gpu::coord_buffer_t xyz_;  // element i of storage_ at [3 i, 3 i + 3)
+    gpu::coord_buffer_t xyz_;  // element i of storage_ at [3 i, 3 i + 3); K > 3: at [K i, K i + K)
     CoordinateMap coordinate_map_;
     kdtree::construction_params_t params_;
     aabb_type aabb_{};
     mutable gpu::device_index_t index_;
+    mutable gpu::kd_wide_index_t wide_index_;  // K > 3
     mutable std::unique_ptr<std::mutex> mutex_ = std::make_unique<std::mutex>();
 };
 

@@ -1,6 +1,7 @@
-// The kd-tree container in 1 and 2 dimensions (the reference's basic_linked_kdtree_t is generic in K:
+// The kd-tree container in 1, 2, 3 and more dimensions (the reference's basic_linked_kdtree_t is generic in K:
 // include/pcp/kdtree/linked_kdtree.hpp:64-65): k nearest neighbours and box ranges against brute force on the host.
-// Missing axes travel as 0 to the device index, so every distance and every containment test is the K-dimensional one.
+// K <= 3: missing axes travel as 0 to the device index, so every distance and every containment test is the K-dimensional one;
+// K > 3: the exhaustive search of pcpx_kd_* (include/pcpx.h).
 #include "pcp/kdtree/linked_kdtree.hpp"
 
 #include <algorithm>
@@ -61,6 +62,17 @@ int run(unsigned seed)
         if (in.size() != expect) { ++bad; std::printf("  query %d: %zu in the box, brute force %zu\n", q, in.size(), expect); }
         for (auto const& e : in) if (!box.contains(e.c)) ++bad;
     }
+    {  // the batched form gives the rows of the single calls
+        std::vector<element> some(pts.begin(), pts.begin() + 25);
+        auto const rows = tree.nearest_neighbours_batch(some.begin(), some.end(), 7);
+        for (std::size_t i = 0; i < some.size(); ++i)
+        {
+            auto const one = tree.nearest_neighbours(some[i], 7);
+            if (rows[i].size() != one.size()) { ++bad; continue; }
+            for (std::size_t j = 0; j < one.size(); ++j)
+                if (d2(rows[i][j].c, some[i].c) != d2(one[j].c, some[i].c)) ++bad;
+        }
+    }
     auto const bb = tree.aabb();
     for (auto const& e : pts) if (!bb.contains(e.c)) ++bad;
     std::printf("K = %zu: %d mismatches\n", K, bad);
@@ -70,6 +82,7 @@ int run(unsigned seed)
 int main()
 {
     int bad = run<1>(11) + run<2>(12) + run<3>(13);
+    bad += run<4>(14) + run<5>(15) + run<8>(18) + run<16>(26);  // K > 3: pcpx_kd_* (exhaustive search on the GPU)
     std::printf(bad == 0 ? "ok\n" : "FAILED\n");
     return bad == 0 ? 0 : 1;
 }
